@@ -1,0 +1,84 @@
+"""Seeded synthetic FASTQ generator (SURVEY.md §8d workload definition).
+
+Uniform-random genome of length G, reads sampled uniformly, strand 50/50,
+per-base substitution 0.5 %, N 0.1 %, ids ``@SRR000001.<i> <i>/1``, qualities
+iid from {2,14,22,27,33,37,40}+33.  Deterministic for a given
+(n_reads, read_len, genome_len, seed) and numpy version-independent
+(uses only PCG64 integer/uniform draws).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[_a] = _b
+_QUALS = np.array([2, 14, 22, 27, 33, 37, 40], dtype=np.uint8) + 33
+
+
+def synth_reads(n_reads: int, read_len: int, genome_len: int, seed: int,
+                sub_rate: float = 0.005, n_rate: float = 0.001) -> np.ndarray:
+    """Return an (n_reads, read_len) uint8 array of ASCII bases (ACGTN)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    genome = _ACGT[rng.integers(0, 4, size=genome_len, dtype=np.uint8)]
+    out = np.empty((n_reads, read_len), dtype=np.uint8)
+    chunk = 1 << 18
+    ar = np.arange(read_len, dtype=np.int64)
+    for s in range(0, n_reads, chunk):
+        e = min(n_reads, s + chunk)
+        m = e - s
+        pos = rng.integers(0, genome_len - read_len + 1, size=m, dtype=np.int64)
+        strand = rng.integers(0, 2, size=m, dtype=np.uint8)
+        r = genome[pos[:, None] + ar[None, :]]
+        rc = _COMP[r[:, ::-1]]
+        r = np.where(strand[:, None] == 1, rc, r)
+        u = rng.random(size=(m, read_len))
+        sub = u < sub_rate
+        alt = _ACGT[rng.integers(0, 4, size=(m, read_len), dtype=np.uint8)]
+        r = np.where(sub, alt, r)
+        isn = (u >= sub_rate) & (u < sub_rate + n_rate)
+        r = np.where(isn, np.uint8(ord("N")), r)
+        out[s:e] = r
+    return out
+
+
+def synth_quals(n_reads: int, read_len: int, seed: int) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
+    return _QUALS[rng.integers(0, len(_QUALS), size=(n_reads, read_len), dtype=np.uint8)]
+
+
+def read_id(i: int, mate: int = 1) -> bytes:
+    return b"@SRR000001.%d %d/%d" % (i + 1, i + 1, mate)
+
+
+def write_fastq(path: str, reads: np.ndarray, quals: np.ndarray | None = None,
+                seed: int = 0, mate: int = 1) -> None:
+    n, L = reads.shape
+    if quals is None:
+        quals = synth_quals(n, L, seed)
+    with open(path, "wb") as f:
+        buf = []
+        for i in range(n):
+            buf.append(read_id(i, mate))
+            buf.append(b"\n")
+            buf.append(reads[i].tobytes())
+            buf.append(b"\n+\n")
+            buf.append(quals[i].tobytes())
+            buf.append(b"\n")
+            if len(buf) >= 1 << 16:
+                f.write(b"".join(buf))
+                buf = []
+        f.write(b"".join(buf))
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("out")
+    ap.add_argument("--reads", type=int, default=10000)
+    ap.add_argument("--len", type=int, default=100)
+    ap.add_argument("--genome", type=int, default=200000)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    write_fastq(a.out, synth_reads(a.reads, a.len, a.genome, a.seed), seed=a.seed)
