@@ -1,0 +1,125 @@
+"""ctypes binding of the C ABI in include/fqsx.h (libfqsx.so, HIP/gfx950).
+
+The product path has no CPU implementation: constructing a DnaCodec without the
+built HIP library or without a GPU raises.  (tests/emu passes the path of the
+host-emulation build of the *same kernels* explicitly; nothing in this package
+ever selects it.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_PKG, "libfqsx.so")
+
+STAT_NAMES = ["gprobe", "gslot", "lprobe", "lslot", "gins", "gins_slot", "siv_words", "ctx_slots",
+              "coded", "lins", "mail", "bases"]
+
+
+class FqsxError(RuntimeError):
+    pass
+
+
+def _load(path: str):
+    if not os.path.exists(path):
+        raise FqsxError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    lib.fqsx_dna_create.restype = C.c_int
+    lib.fqsx_dna_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.fqsx_dna_destroy.argtypes = [C.c_void_p]
+    lib.fqsx_dna_encode_block.restype = C.c_int
+    lib.fqsx_dna_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.fqsx_dna_encode_block_dev.restype = C.c_int
+    lib.fqsx_dna_encode_block_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.fqsx_dna_stats.restype = C.c_int
+    lib.fqsx_dna_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.fqsx_dna_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.fqsx_dna_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.fqsx_last_error.restype = C.c_char_p
+    lib.fqsx_version.restype = C.c_char_p
+    return lib
+
+
+_libs = {}
+
+
+def load_library(path: Optional[str] = None):
+    path = path or DEFAULT_LIB
+    if path not in _libs:
+        _libs[path] = _load(path)
+    return _libs[path]
+
+
+class DnaCodec:
+    """One .fqs file's DNA-stream encoder state on one GPU (fqsx_dna_*)."""
+
+    def __init__(self, header: bytes, device: int = 0, lib_path: Optional[str] = None):
+        if len(header) != 17:
+            raise ValueError("header must be the 17 .fqs parameter bytes")
+        self._lib = load_library(lib_path)
+        self.T = header[4]
+        self._h = C.c_void_p()
+        rc = self._lib.fqsx_dna_create(bytes(header), device, C.byref(self._h))
+        if rc:
+            raise FqsxError(f"fqsx_dna_create: {rc}: {self._lib.fqsx_last_error().decode()}")
+        self._streams = (C.c_void_p * self.T)()
+        self._lens = (C.c_uint64 * self.T)()
+
+    def _collect(self) -> List[bytes]:
+        return [C.string_at(self._streams[w], self._lens[w]) if self._lens[w] else b"" for w in range(self.T)]
+
+    def encode_block(self, bases: np.ndarray, read_off: np.ndarray, generation: int) -> List[bytes]:
+        """Host-buffer entry point: returns the T per-worker DNA streams of the block."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        rc = self._lib.fqsx_dna_encode_block(self._h, bases.ctypes.data, read_off.ctypes.data, len(read_off) - 1,
+                                             generation, self._streams, self._lens)
+        if rc:
+            raise FqsxError(f"fqsx_dna_encode_block: {rc}: {self._lib.fqsx_last_error().decode()}")
+        return self._collect()
+
+    def encode_block_dev(self, d_bases_ptr: int, d_off_ptr: int, read_off: np.ndarray, generation: int,
+                         collect: bool = True):
+        """Device-resident entry point (inputs already in HBM)."""
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        rc = self._lib.fqsx_dna_encode_block_dev(self._h, d_bases_ptr, d_off_ptr, read_off.ctypes.data,
+                                                 len(read_off) - 1, generation, self._streams, self._lens)
+        if rc:
+            raise FqsxError(f"fqsx_dna_encode_block_dev: {rc}: {self._lib.fqsx_last_error().decode()}")
+        if collect:
+            return self._collect()
+        return sum(self._lens[w] for w in range(self.T))
+
+    def stats(self) -> dict:
+        a = (C.c_uint64 * 16)()
+        rc = self._lib.fqsx_dna_stats(self._h, a)
+        if rc:
+            raise FqsxError(f"fqsx_dna_stats: {rc}: {self._lib.fqsx_last_error().decode()}")
+        return dict(zip(STAT_NAMES, list(a)))
+
+    def set_profiling(self, on: bool) -> None:
+        self._lib.fqsx_dna_set_profiling(self._h, int(on))
+
+    def kernel_times(self) -> dict:
+        a = (C.c_double * 6)()
+        self._lib.fqsx_dna_kernel_times(self._h, a)
+        return {"encode_ms": a[0], "insert_ms": a[1], "other_ms": a[2],
+                "encode_launches": int(a[3]), "insert_launches": int(a[4]), "other_launches": int(a[5])}
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.fqsx_dna_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,679 @@
+// fqsx_api.hip -- kernels, device-memory management and the C ABI (include/fqsx.h).
+//
+// Host side of the FQSX DNA path: it owns the HBM-resident state of all T logical workers,
+// sizes the per-block buffers, and drives the kernel schedule of one reads block:
+//
+//   for seg in 0..S:  k_encode_segment  (T workgroups, one wavefront = one worker)
+//                     k_insert_phase    (T workgroups, one per table owner)
+//                     clear local tables
+//   k_finish_block
+//
+// which is the barrier structure of the reference worker loop (fqs/application.cpp:610-669)
+// with kernel boundaries in place of CBarrier.  Built with hipcc for gfx950; the FQSX_EMU
+// build (tests/emu only) runs the same kernels as plain loops for debugging without a GPU.
+#include "fqsx_dev.h"
+#include "../../include/fqsx.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+extern "C" const char *fqsx_last_error(void) { return g_err.c_str(); }
+extern "C" const char *fqsx_version(void) {
+#ifdef FQSX_EMU
+  return "fqsx 0.1 (host emulation build - tests only)";
+#else
+  return "fqsx 0.1 (HIP gfx950)";
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
+// kernels
+FQ_KERNEL64 void k_encode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
+  FQ_SHARED WgShared sm;
+  encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
+}
+FQ_KERNEL64 void k_insert_phase(DevCfg cfg) {
+  FQ_SHARED WgShared sm;
+  insert_phase_body(cfg, &sm, FQ_BLOCK);
+}
+FQ_KERNEL64 void k_finish_block(DevCfg cfg, u64 *lens /*[T+1]*/) {
+  if (FQ_LANE == 0) {
+    finish_block_body(cfg, FQ_BLOCK);
+    lens[FQ_BLOCK] = cfg.ws[FQ_BLOCK].out_len;
+  }
+}
+// gathers the per-worker accounting counters: out[i] = sum over workers of stat[i]
+FQ_KERNEL64 void k_gather_stats(DevCfg cfg, u64 *out) {
+  for (u32 i = FQ_LANE; i < 16; i += FQ_WAVE) {
+    u64 s = 0;
+    for (u32 t = 0; t < cfg.T; ++t) s += cfg.ws[t].stat[i];
+    out[i] = s;
+  }
+}
+// owner `blk` demand of the coming insert phase: entries addressed to it, per table
+FQ_KERNEL64 void k_phase_demand(DevCfg cfg, u32 *demand /*[2][T]*/) {
+  const u32 tid = FQ_BLOCK, T = cfg.T;
+  u32 s = 0, b = 0;
+  for (u32 src = FQ_LANE; src < T; src += FQ_WAVE) {
+    s += cfg.mail[MAIL_S].count[(u64)src * T + tid];
+    b += cfg.mail[MAIL_B].count[(u64)src * T + tid];
+  }
+  s = wave_sum32(s);
+  b = wave_sum32(b);
+  if (FQ_LANE == 0) {
+    demand[tid] = s;
+    demand[T + tid] = b;
+    if (tid == 0) demand[2 * T] = *cfg.err;
+  }
+}
+// re-insert every occupied slot of `o` into the (empty, larger) table `n`; layout-free, so parallel
+FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub) {
+  const u64 ocap = o.cap_mask + 1;
+  const u64 total = ocap * n_sub;
+#ifndef FQSX_EMU
+  const u64 gstride = (u64)gridDim.x * blockDim.x;
+  for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gstride) {
+#else
+  for (u64 g = 0; g < total; ++g) {
+#endif
+    u32 sub = (u32)(g / ocap);
+    u64 it = o.slots[(u64)sub * o.stride + (g % ocap)];
+    if (!it) continue;
+    u64 *s = n.slots + (u64)sub * n.stride;
+    u64 p = tab_home(n, it >> n.cbits);
+    for (;;) {
+      if (s[p] == 0 && atomic_cas64(&s[p], 0, it) == 0) break;
+      p = (p + 1) & n.cap_mask;
+    }
+  }
+}
+FQ_KERNEL void k_rehash_ctx(const u64 *o, u64 ocap_mask, u64 *n, u64 ncap_mask, u32 T) {
+  const u64 ocap = ocap_mask + 1, total = ocap * T;
+#ifndef FQSX_EMU
+  const u64 gstride = (u64)gridDim.x * blockDim.x;
+  for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gstride) {
+#else
+  for (u64 g = 0; g < total; ++g) {
+#endif
+    u32 w = (u32)(g / ocap);
+    const u64 *src = o + 4 * g;
+    u64 q1 = src[1];
+    u32 tag = slot_tag(q1);
+    if (!tag) continue;
+    u64 key = src[0];
+    u64 *b = n + 4 * (u64)w * (ncap_mask + 1);
+    u64 h = murmur64(key ^ ((u64)tag * 0x9E3779B97F4A7C15ULL)) & ncap_mask;
+    for (;;) {
+      u64 *p = b + 4 * h;
+      if (p[1] == 0 && atomic_cas64(&p[1], 0, q1) == 0) {
+        p[0] = key; p[2] = src[2]; p[3] = src[3];
+        break;
+      }
+      h = (h + 1) & ncap_mask;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backend
+#ifndef FQSX_EMU
+#define HIPCHK(x)                                                                             \
+  do {                                                                                        \
+    hipError_t e_ = (x);                                                                      \
+    if (e_ != hipSuccess) {                                                                   \
+      g_err = std::string(#x) + ": " + hipGetErrorString(e_);                                 \
+      return FQSX_E_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+#endif
+
+struct fqsx_dna {
+  DevCfg cfg;
+  u32 T;
+  int device;
+#ifndef FQSX_EMU
+  hipStream_t stream;
+  hipEvent_t ev0, ev1;
+#endif
+  bool profiling;
+  double k_ms[3];
+  u64 k_n[3];
+  // capacities (host mirror)
+  u64 gs_cap, gb_cap, ls_cap, lb_cap, ctx_cap, out_cap;
+  u32 pool_chunks[3];
+  u64 dev_bases_cap, dev_off_cap;
+  u8 *d_bases;
+  u64 *d_off;
+  u32 *d_demand;
+  u64 *d_lens;
+  std::vector<u32> h_demand, h_filled;
+  std::vector<u8> h_out;
+  std::vector<u64> h_lens;
+  std::vector<void *> allocs;
+};
+
+namespace {
+
+int dalloc(fqsx_dna *c, void **p, u64 bytes, bool zero) {
+  if (bytes == 0) bytes = 8;
+#ifndef FQSX_EMU
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    g_err = "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e);
+    return FQSX_E_NOMEM;
+  }
+  if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, c->stream));
+#else
+  *p = zero ? calloc(1, bytes) : malloc(bytes);
+  if (!*p) { g_err = "host allocation failed"; return FQSX_E_NOMEM; }
+#endif
+  c->allocs.push_back(*p);
+  return FQSX_OK;
+}
+void dfree(fqsx_dna *c, void *p) {
+  if (!p) return;
+  auto it = std::find(c->allocs.begin(), c->allocs.end(), p);
+  if (it != c->allocs.end()) c->allocs.erase(it);
+#ifndef FQSX_EMU
+  (void)hipFree(p);
+#else
+  free(p);
+#endif
+}
+int dzero(fqsx_dna *c, void *p, u64 bytes) {
+#ifndef FQSX_EMU
+  HIPCHK(hipMemsetAsync(p, 0, bytes, c->stream));
+#else
+  (void)c;
+  memset(p, 0, bytes);
+#endif
+  return FQSX_OK;
+}
+int h2d(fqsx_dna *c, void *d, const void *h, u64 bytes) {
+#ifndef FQSX_EMU
+  HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+#else
+  (void)c;
+  memcpy(d, h, bytes);
+#endif
+  return FQSX_OK;
+}
+int d2d(fqsx_dna *c, void *d, const void *s, u64 bytes) {
+#ifndef FQSX_EMU
+  HIPCHK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, c->stream));
+#else
+  (void)c;
+  memcpy(d, s, bytes);
+#endif
+  return FQSX_OK;
+}
+int d2h_sync(fqsx_dna *c, void *h, const void *d, u64 bytes) {
+#ifndef FQSX_EMU
+  HIPCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+#else
+  (void)c;
+  memcpy(h, d, bytes);
+#endif
+  return FQSX_OK;
+}
+
+#ifndef FQSX_EMU
+#define LAUNCH(c, kidx, kern, grid, block, ...)                                     \
+  do {                                                                              \
+    if ((c)->profiling) HIPCHK(hipEventRecord((c)->ev0, (c)->stream));              \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); \
+    HIPCHK(hipGetLastError());                                                      \
+    if ((c)->profiling) {                                                           \
+      HIPCHK(hipEventRecord((c)->ev1, (c)->stream));                                \
+      HIPCHK(hipEventSynchronize((c)->ev1));                                        \
+      float ms_ = 0;                                                                \
+      HIPCHK(hipEventElapsedTime(&ms_, (c)->ev0, (c)->ev1));                        \
+      (c)->k_ms[kidx] += ms_;                                                       \
+      (c)->k_n[kidx] += 1;                                                          \
+    }                                                                               \
+  } while (0)
+#else
+#define LAUNCH(c, kidx, kern, grid, block, ...)       \
+  do {                                                \
+    fq_emu_nblocks = (grid);                          \
+    for (u32 b_ = 0; b_ < (u32)(grid); ++b_) {        \
+      fq_emu_block = b_;                              \
+      kern(__VA_ARGS__);                              \
+    }                                                 \
+    (c)->k_n[kidx] += 1;                              \
+  } while (0)
+#endif
+
+#ifndef FQSX_EMU
+#define REHASH_GRID 2048
+#else
+#define REHASH_GRID 1  /* the emulated kernel body already walks every slot */
+#endif
+
+u64 pow2_at_least(u64 x) {
+  u64 p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+KGeom make_geom(u32 k) {  // kmer.h:279-298
+  KGeom g;
+  g.k = k;
+  g.shift = 64 - 2 * k;
+  g.mask = (~0ull) << g.shift;
+  g.kernel_mask = ((1ull << (2 * k - 8)) - 1ull) << (64 - 2 * k + 4);
+  return g;
+}
+
+void mt_seed(u32 *s, u32 seed) {
+  s[0] = seed;
+  for (int i = 1; i < 624; ++i) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + (u32)i;
+}
+
+// (re)allocate a k-mer table of n_sub sub-tables with `cap` slots each, empty
+int ktab_alloc(fqsx_dna *c, KTab &t, u32 n_sub, u64 cap, u32 k, u32 cbits, bool with_filled) {
+  void *p = nullptr;
+  int rc = dalloc(c, &p, cap * n_sub * sizeof(u64), true);
+  if (rc) return rc;
+  t.slots = (u64 *)p;
+  t.cap_mask = cap - 1;
+  t.stride = cap;
+  t.k = k;
+  t.cbits = cbits;
+  if (with_filled) {
+    rc = dalloc(c, &p, (u64)n_sub * sizeof(u32), true);
+    if (rc) return rc;
+    t.filled = (u32 *)p;
+  }
+  return FQSX_OK;
+}
+
+int grow_global(fqsx_dna *c, KTab &t, u64 &cap_field, u64 new_cap) {
+  KTab n = t;
+  int rc = ktab_alloc(c, n, c->T, new_cap, t.k, t.cbits, false);
+  if (rc) return rc;
+  LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, c->T);
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  dfree(c, t.slots);
+  t = n;
+  cap_field = new_cap;
+  return FQSX_OK;
+}
+
+int grow_ctx(fqsx_dna *c, u64 new_cap) {
+  void *p = nullptr;
+  int rc = dalloc(c, &p, new_cap * c->T * sizeof(CtxSlot), true);
+  if (rc) return rc;
+  LAUNCH(c, 2, k_rehash_ctx, REHASH_GRID, 256, (const u64 *)c->cfg.ctx, c->cfg.ctx_cap_mask, (u64 *)p, new_cap - 1, c->T);
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  dfree(c, c->cfg.ctx);
+  c->cfg.ctx = (CtxSlot *)p;
+  c->cfg.ctx_cap_mask = new_cap - 1;
+  c->ctx_cap = new_cap;
+  return FQSX_OK;
+}
+
+int mail_alloc(fqsx_dna *c, u32 kind, u32 chunks) {
+  Mail &m = c->cfg.mail[kind];
+  if (m.pool) { dfree(c, m.pool); dfree(c, m.next); }
+  void *p = nullptr;
+  int rc = dalloc(c, &p, (u64)c->T * chunks * FQSX_CHUNK * sizeof(u64), false);
+  if (rc) return rc;
+  m.pool = (u64 *)p;
+  rc = dalloc(c, &p, (u64)c->T * chunks * sizeof(u32), false);
+  if (rc) return rc;
+  m.next = (u32 *)p;
+  m.pool_chunks = chunks;
+  c->pool_chunks[kind] = chunks;
+  return FQSX_OK;
+}
+
+int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u64 *h_off, u32 n_reads, u32 generation,
+                      const u8 **streams, u64 *lens) {
+  const u32 T = c->T;
+  DevCfg &cfg = c->cfg;
+  // ---- schedule (PartitionForWorkers reads_block.h:197-214; calc_no_synchronizations application.h:85-92)
+  u64 S = generation < 100u ? 100u - generation : 0u;
+  u64 cap_s = (u64)n_reads / T / 2;
+  if (S > cap_s) S = cap_s;
+  if (S) --S;
+  u64 max_wbases = 0, max_seg_bases = 0, max_seg_reads = 0, max_wreads = 0;
+  std::vector<u64> wbases(T);
+  for (u32 t = 0; t < T; ++t) {
+    u64 first = (u64)t * n_reads / T, last = ((u64)t + 1) * n_reads / T;
+    if (t) first &= ~1ull;
+    if (t + 1 < T) last &= ~1ull;
+    wbases[t] = h_off[last] - h_off[first];
+    max_wbases = std::max(max_wbases, wbases[t]);
+    max_wreads = std::max(max_wreads, last - first);
+    u64 cur = first;
+    for (u64 seg = 0; seg <= S; ++seg) {
+      u64 stop = seg < S ? (seg + 1) * (last - first) / (S + 1) + first + 1 : last;
+      if (stop > last) stop = last;
+      if (stop > cur) {
+        max_seg_bases = std::max(max_seg_bases, h_off[stop] - h_off[cur]);
+        max_seg_reads = std::max(max_seg_reads, stop - cur);
+        cur = stop;
+      }
+    }
+  }
+  int rc;
+  void *p = nullptr;
+  // ---- per-block buffers
+  u64 need_out = max_wbases + 16 * max_wreads + 1024;
+  if (need_out > c->out_cap) {
+    if (cfg.out) dfree(c, cfg.out);
+    c->out_cap = pow2_at_least(need_out);
+    if ((rc = dalloc(c, &p, c->out_cap * T, false))) return rc;
+    cfg.out = (u8 *)p;
+    cfg.out_cap = c->out_cap;
+  }
+  const u64 mail_entries[3] = {2 * max_seg_bases + 2 * max_seg_reads, max_seg_bases, 2 * max_seg_bases};
+  for (u32 k = 0; k < 3; ++k) {
+    u64 chunks = mail_entries[k] / FQSX_CHUNK + T + 2;
+    if (chunks > c->pool_chunks[k] && (rc = mail_alloc(c, k, (u32)(chunks + chunks / 4)))) return rc;
+  }
+  u64 need_lb = pow2_at_least(4 * max_seg_bases + 64), need_ls = pow2_at_least(2 * max_seg_bases + 64);
+  if (need_lb > c->lb_cap) {
+    dfree(c, cfg.l_b.slots);
+    if ((rc = ktab_alloc(c, cfg.l_b, T, need_lb, cfg.bmer, 6, false))) return rc;
+    c->lb_cap = need_lb;
+  }
+  if (need_ls > c->ls_cap) {
+    dfree(c, cfg.l_s.slots);
+    if ((rc = ktab_alloc(c, cfg.l_s, T, need_ls, cfg.smer, 12, false))) return rc;
+    c->ls_cap = need_ls;
+  }
+  // active geometry of the local tables for this block (cleared after every phase)
+  cfg.l_b.cap_mask = need_lb - 1; cfg.l_b.stride = need_lb;
+  cfg.l_s.cap_mask = need_ls - 1; cfg.l_s.stride = need_ls;
+  // ---- context tables: every coded symbol creates at most two contexts
+  if ((rc = d2h_sync(c, c->h_filled.data(), cfg.ctx_filled, T * sizeof(u32)))) return rc;
+  {
+    u64 need = 0;
+    for (u32 t = 0; t < T; ++t) need = std::max<u64>(need, (u64)c->h_filled[t] + 2 * wbases[t] + 64);
+    if (need * 2 > c->ctx_cap && (rc = grow_ctx(c, pow2_at_least(need * 2)))) return rc;
+  }
+  cfg.bases = d_bases;
+  cfg.read_off = d_off;
+
+  for (u32 seg = 0; seg <= (u32)S; ++seg) {
+    LAUNCH(c, 0, k_encode_segment, T, 64, cfg, n_reads, (u32)S, seg);
+    // size the global tables for this phase's inserts (exact per-owner demand)
+    LAUNCH(c, 2, k_phase_demand, T, 64, cfg, c->d_demand);
+    if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, (2 * T + 1) * sizeof(u32)))) return rc;
+    if (c->h_demand[2 * T]) {
+      g_err = "device error " + std::to_string(c->h_demand[2 * T]) + " in encode kernel";
+      return FQSX_E_DEVICE;
+    }
+    for (int which = 0; which < 2; ++which) {
+      KTab &t = which ? cfg.g_b : cfg.g_s;
+      u64 &cap = which ? c->gb_cap : c->gs_cap;
+      if ((rc = d2h_sync(c, c->h_filled.data(), t.filled, T * sizeof(u32)))) return rc;
+      u64 need = 0;
+      for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_filled[o] + c->h_demand[which * T + o]);
+      if (need * 2 > cap && (rc = grow_global(c, t, cap, pow2_at_least(need * 2 + 2)))) return rc;
+    }
+    LAUNCH(c, 1, k_insert_phase, T, 64, cfg);
+    // ClearKmersToHT, dna.cpp:2475-2488 (mailbox counters are rewritten by the next encode launch)
+    if ((rc = dzero(c, cfg.l_b.slots, need_lb * T * sizeof(u64)))) return rc;
+    if ((rc = dzero(c, cfg.l_s.slots, need_ls * T * sizeof(u64)))) return rc;
+    if ((rc = dzero(c, cfg.l_b.filled, T * sizeof(u32)))) return rc;
+    if ((rc = dzero(c, cfg.l_s.filled, T * sizeof(u32)))) return rc;
+  }
+  LAUNCH(c, 2, k_finish_block, T, 64, cfg, c->d_lens);
+  // ---- results
+  if ((rc = d2h_sync(c, c->h_lens.data(), c->d_lens, T * sizeof(u64)))) return rc;
+  u32 err = 0;
+  if ((rc = d2h_sync(c, &err, cfg.err, sizeof(u32)))) return rc;
+  if (err) {
+    g_err = "device error " + std::to_string(err) + " while encoding block " + std::to_string(generation);
+    return FQSX_E_DEVICE;
+  }
+  u64 total = 0;
+  for (u32 t = 0; t < T; ++t) {
+    if (c->h_lens[t] > c->out_cap) { g_err = "stream overflow"; return FQSX_E_DEVICE; }
+    total += c->h_lens[t];
+  }
+  c->h_out.resize(total ? total : 1);
+  u64 pos = 0;
+  for (u32 t = 0; t < T; ++t) {
+#ifndef FQSX_EMU
+    HIPCHK(hipMemcpyAsync(c->h_out.data() + pos, cfg.out + (u64)t * cfg.out_cap, c->h_lens[t], hipMemcpyDeviceToHost, c->stream));
+#else
+    memcpy(c->h_out.data() + pos, cfg.out + (u64)t * cfg.out_cap, c->h_lens[t]);
+#endif
+    streams[t] = c->h_out.data() + pos;
+    lens[t] = c->h_lens[t];
+    pos += c->h_lens[t];
+  }
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  return FQSX_OK;
+}
+
+int create_impl(fqsx_dna *c, const u8 *h) {
+  const u32 T = c->T;
+  DevCfg &cfg = c->cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.T = T;
+  cfg.mode = h[5];
+  cfg.prefix = h[10]; cfg.pmer = h[11]; cfg.smer = h[12]; cfg.bmer = h[13];
+  cfg.gp = make_geom(cfg.pmer); cfg.gs = make_geom(cfg.smer); cfg.gb = make_geom(cfg.bmer);
+  cfg.pmer_mod_shift = 2 * cfg.pmer - 12;          // dna.cpp:2381
+  cfg.ps_nobytes_n = (2 * cfg.pmer + 7) / 8;       // dna.cpp:130
+  int rc;
+  void *p = nullptr;
+  // p-mer vector: 4^pmer 2-bit counters (application.cpp:86, bit_vec.h:29-36)
+  if ((rc = dalloc(c, &p, (1ull << (2 * cfg.pmer)) / 4, true))) return rc;
+  cfg.siv = (u64 *)p;
+  if ((rc = dalloc(c, &p, 2 * sizeof(u64), true))) return rc;
+  cfg.siv_stats = (u64 *)p;
+  // owner-sharded global tables (application.cpp:87-88; counters defs.h:26-27)
+  c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(1024, (1ull << 22) / T));
+  if ((rc = ktab_alloc(c, cfg.g_s, T, c->gs_cap, cfg.smer, 12, true))) return rc;
+  if ((rc = ktab_alloc(c, cfg.g_b, T, c->gb_cap, cfg.bmer, 6, true))) return rc;
+  // local tables: geometry chosen per block; counters allocated here
+  c->ls_cap = c->lb_cap = 1024;
+  if ((rc = ktab_alloc(c, cfg.l_s, T, c->ls_cap, cfg.smer, 12, true))) return rc;
+  if ((rc = ktab_alloc(c, cfg.l_b, T, c->lb_cap, cfg.bmer, 6, true))) return rc;
+  // contexts
+  c->ctx_cap = 1u << 14;
+  if ((rc = dalloc(c, &p, c->ctx_cap * T * sizeof(CtxSlot), true))) return rc;
+  cfg.ctx = (CtxSlot *)p;
+  cfg.ctx_cap_mask = c->ctx_cap - 1;
+  if ((rc = dalloc(c, &p, T * sizeof(u32), true))) return rc;
+  cfg.ctx_filled = (u32 *)p;
+  // small models: all stats 1 (rc.h:69-72), 256-symbol models lazily
+  {
+    std::vector<u16> tpl(SM_OFF_BYTE, 0);
+    auto fill = [&](u32 off, u32 entries, u32 stride, u32 n) {
+      for (u32 e = 0; e < entries; ++e) {
+        for (u32 i = 0; i < n; ++i) tpl[off + e * stride + i] = 1;
+        tpl[off + e * stride + n] = (u16)n;
+      }
+    };
+    fill(SM_OFF_FLAGS, 256, SM_FLAGS_N + 1, SM_FLAGS_N);
+    fill(SM_OFF_NS, 32, SM_NS_N + 1, SM_NS_N);
+    fill(SM_OFF_PSF, 65536, SM_PSF_N + 1, SM_PSF_N);
+    fill(SM_OFF_PSNB, 65536, 6, cfg.ps_nobytes_n);
+    fill(SM_OFF_NIB, 68, SM_NIB_N + 1, SM_NIB_N);
+    if ((rc = dalloc(c, &p, (u64)T * SM_TOTAL_U16 * sizeof(u16), false))) return rc;
+    cfg.small = (u16 *)p;
+    if ((rc = h2d(c, cfg.small, tpl.data(), tpl.size() * sizeof(u16)))) return rc;
+#ifndef FQSX_EMU
+    HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+    for (u32 t = 1; t < T; ++t)
+      if ((rc = d2d(c, cfg.small + (u64)t * SM_TOTAL_U16, cfg.small, tpl.size() * sizeof(u16)))) return rc;
+    if ((rc = dalloc(c, &p, (u64)T * SM_BYTE_ENTRIES, true))) return rc;
+    cfg.byte_init = (u8 *)p;
+  }
+  // worker state: four std::mt19937 seeded 5481 (utils.h:296), everything else zero (dna.cpp:148-171)
+  {
+    std::vector<WState> ws(1);
+    memset(ws.data(), 0, sizeof(WState));
+    for (int g = 0; g < 4; ++g) {
+      mt_seed(ws[0].mt[g], 5481);
+      ws[0].mt_idx[g] = 624;
+    }
+    if ((rc = dalloc(c, &p, (u64)T * sizeof(WState), false))) return rc;
+    cfg.ws = (WState *)p;
+    for (u32 t = 0; t < T; ++t)
+      if ((rc = h2d(c, cfg.ws + t, ws.data(), sizeof(WState)))) return rc;
+#ifndef FQSX_EMU
+    HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  }
+  for (u32 k = 0; k < 3; ++k) {
+    if ((rc = dalloc(c, &p, (u64)T * T * sizeof(u32), true))) return rc;
+    cfg.mail[k].head = (u32 *)p;
+    if ((rc = dalloc(c, &p, (u64)T * T * sizeof(u32), true))) return rc;
+    cfg.mail[k].count = (u32 *)p;
+    if ((rc = mail_alloc(c, k, T + 64))) return rc;
+  }
+  if ((rc = dalloc(c, &p, sizeof(u32) * 4, true))) return rc;
+  cfg.err = (u32 *)p;
+  if ((rc = dalloc(c, &p, (2 * (u64)T + 1) * sizeof(u32), true))) return rc;
+  c->d_demand = (u32 *)p;
+  if ((rc = dalloc(c, &p, ((u64)T + 16) * sizeof(u64), true))) return rc;
+  c->d_lens = (u64 *)p;
+  c->h_demand.assign(2 * T + 1, 0);
+  c->h_filled.assign(T, 0);
+  c->h_lens.assign(T + 16, 0);
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  return FQSX_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) {
+  if (!h || !out || h[0] != 'K' || h[1] != 'C' || h[2] != 'S' || h[3] != 'D') {  // params.h:102-129
+    g_err = "malformed .fqs parameter header";
+    return FQSX_E_ARG;
+  }
+  if (h[4] == 0) { g_err = "no_threads must be >= 1"; return FQSX_E_ARG; }
+  if (h[5] > 1) { g_err = "dna_mode not implemented (paired-end)"; return FQSX_E_ARG; }
+  if (h[11] < 12 || h[11] > 18 || h[12] <= h[11] || h[13] <= h[12] + 1 || h[13] > 27 || h[10] >= h[11]) {
+    g_err = "unsupported k-mer lengths";
+    return FQSX_E_ARG;
+  }
+#ifndef FQSX_EMU
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_err = "no HIP device available (libfqsx has no CPU path)";
+    return FQSX_E_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { g_err = "bad device ordinal"; return FQSX_E_ARG; }
+  HIPCHK(hipSetDevice(device));
+#endif
+  fqsx_dna *c = new fqsx_dna();
+  c->T = h[4];
+  c->device = device;
+  c->profiling = false;
+  c->k_ms[0] = c->k_ms[1] = c->k_ms[2] = 0;
+  c->k_n[0] = c->k_n[1] = c->k_n[2] = 0;
+  c->out_cap = 0;
+  c->pool_chunks[0] = c->pool_chunks[1] = c->pool_chunks[2] = 0;
+  c->dev_bases_cap = c->dev_off_cap = 0;
+  c->d_bases = nullptr;
+  c->d_off = nullptr;
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamCreate(&c->stream));
+  HIPCHK(hipEventCreate(&c->ev0));
+  HIPCHK(hipEventCreate(&c->ev1));
+#endif
+  int rc = create_impl(c, h);
+  if (rc) {
+    fqsx_dna_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return FQSX_OK;
+}
+
+void fqsx_dna_destroy(fqsx_dna *c) {
+  if (!c) return;
+#ifndef FQSX_EMU
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+#endif
+  std::vector<void *> a = c->allocs;
+  for (void *p : a) dfree(c, p);
+#ifndef FQSX_EMU
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+#endif
+  delete c;
+}
+
+int fqsx_dna_encode_block_dev(fqsx_dna *c, const uint8_t *d_bases, const uint64_t *d_off, const uint64_t *h_off,
+                              uint32_t n_reads, uint32_t generation, const uint8_t **streams, uint64_t *lens) {
+  if (!c || !d_bases || !d_off || !h_off || !streams || !lens) { g_err = "null argument"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  return encode_block_impl(c, d_bases, d_off, h_off, n_reads, generation, streams, lens);
+}
+
+int fqsx_dna_encode_block(fqsx_dna *c, const uint8_t *bases, const uint64_t *off, uint32_t n_reads, uint32_t generation,
+                          const uint8_t **streams, uint64_t *lens) {
+  if (!c || !bases || !off || !streams || !lens) { g_err = "null argument"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  int rc;
+  void *p = nullptr;
+  u64 nb = off[n_reads] + 64, no = ((u64)n_reads + 1) * sizeof(u64);
+  if (nb > c->dev_bases_cap) {
+    dfree(c, c->d_bases);
+    if ((rc = dalloc(c, &p, nb + nb / 4, false))) return rc;
+    c->d_bases = (u8 *)p;
+    c->dev_bases_cap = nb + nb / 4;
+  }
+  if (no > c->dev_off_cap) {
+    dfree(c, c->d_off);
+    if ((rc = dalloc(c, &p, no + no / 4, false))) return rc;
+    c->d_off = (u64 *)p;
+    c->dev_off_cap = no + no / 4;
+  }
+  if ((rc = h2d(c, c->d_bases, bases, off[n_reads]))) return rc;
+  if ((rc = h2d(c, c->d_off, off, no))) return rc;
+  return encode_block_impl(c, c->d_bases, c->d_off, off, n_reads, generation, streams, lens);
+}
+
+int fqsx_dna_stats(fqsx_dna *c, uint64_t out[16]) {
+  if (!c || !out) return FQSX_E_ARG;
+  LAUNCH(c, 2, k_gather_stats, 1, 64, c->cfg, c->d_lens + c->T);
+  return d2h_sync(c, out, c->d_lens + c->T, 16 * sizeof(u64));
+}
+
+int fqsx_dna_set_profiling(fqsx_dna *c, int enable) {
+  if (!c) return FQSX_E_ARG;
+  c->profiling = enable != 0;
+  return FQSX_OK;
+}
+int fqsx_dna_kernel_times(fqsx_dna *c, double out[6]) {
+  if (!c || !out) return FQSX_E_ARG;
+  for (int i = 0; i < 3; ++i) { out[i] = c->k_ms[i]; out[3 + i] = (double)c->k_n[i]; }
+  return FQSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1412 @@
+// fqsx_dev.h -- device code of the FQSX DNA encoder (gfx950; wave-uniform, see fqsx_plat.h).
+//
+// Bit-exact re-design of the FQSqueezer 1.1 DNA hot path.  Each function cites the
+// reference lines whose *behaviour* it reproduces (paths relative to /root/reference/fqs);
+// the data structures and the execution model are this repo's own (fqsx_layout.h).
+#pragma once
+#include "fqsx_layout.h"
+
+// ---------------------------------------------------------------------------------------
+// workgroup-shared (LDS) state of one worker
+struct WgShared {
+  u32 mt[4][624];              // MT19937 states of cinc_b, cinc_s, cinc_lb, cinc_ls
+  u32 mt_idx[4];
+  u32 mail_count[3][256];      // entries pushed per destination in this phase
+  u32 mail_tail[3][256];       // current chunk per destination
+  u32 mail_nchunks[3];
+  u8 rd[FQSX_RD_LDS];          // 2-bit codes (0..4) of the current read
+  u64 bk_key[256];             // probe batch: normalised k-mers
+  u32 bk_res[256][4];          // probe batch: counts
+  u8 bk_dir[256];              // probe batch: orientation
+};
+
+struct C4 { u32 c[4]; };
+struct Kmer { u64 dir, rc; u32 cur; };
+struct Cinc { u32 thr, mult, maxv; };
+struct Enc { u64 low, range, len, cap; u8 *out; };
+
+struct Wk {
+  const DevCfg *cfg;
+  WgShared *sm;
+  WState *ws;
+  u32 tid;
+  Enc enc;
+  Kmer pm, sm_, bm, pm_u, sm_u, bm_u;   // corrected and uncorrected rolling k-mers (dna.h:160-168)
+  u64 ctx_letters;
+  u32 cor_pos, N_run;
+  u64 s_let[4];
+  double avg_code, avg_letters;
+  u64 hidden;
+  u64 st[ST_N];
+  u32 err;
+};
+
+#define CINC_B (Cinc{7u, 2u, 63u})            /* dna.cpp:162,164 */
+#define CINC_S (Cinc{2047u, 1u, 4095u})       /* dna.cpp:163,165 */
+
+FQ_DEV u64 murmur64(u64 h) {  // ht_kmer.h:123-127, context_hm.h:81-85
+  h ^= h >> 33;
+  h *= 0xff51afd7ed558ccdULL;
+  h ^= h >> 33;
+  h *= 0xc4ceb9fe1a85ec53ULL;
+  h ^= h >> 33;
+  return h;
+}
+FQ_DEV u32 dna_code(u8 c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u; }  // dna.cpp:19-24
+
+FQ_DEV void c4_zero(C4 &c) { c.c[0] = c.c[1] = c.c[2] = c.c[3] = 0; }
+FQ_DEV bool c4_any(const C4 &c) { return (c.c[0] | c.c[1] | c.c[2] | c.c[3]) != 0; }
+FQ_DEV void c4_add(C4 &c, u32 sym, u32 v) {
+  c.c[0] += sym == 0 ? v : 0;
+  c.c[1] += sym == 1 ? v : 0;
+  c.c[2] += sym == 2 ? v : 0;
+  c.c[3] += sym == 3 ? v : 0;
+}
+FQ_DEV u32 c4_get(const C4 &c, u32 i) { return i == 0 ? c.c[0] : i == 1 ? c.c[1] : i == 2 ? c.c[2] : c.c[3]; }
+FQ_DEV u64 sl_get(const u64 *s, u32 i) { return i == 0 ? s[0] : i == 1 ? s[1] : i == 2 ? s[2] : s[3]; }
+
+// ---------------------------------------------------------------------------------------
+// std::mt19937 in LDS; regeneration of the 624-word state is wave-parallel
+FQ_DEV void mt_twist(u32 *s) {
+  for (u32 base = 0; base < 624; base += FQ_WAVE) {
+    u32 i = base + FQ_LANE, v = 0;
+    if (i < 624) {
+      u32 nxt = s[i == 623 ? 0 : i + 1];
+      u32 far = s[i < 227 ? i + 397 : i - 227];
+      u32 y = (s[i] & 0x80000000u) | (nxt & 0x7fffffffu);
+      v = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    FQ_SYNC();
+    if (i < 624) s[i] = v;
+    FQ_SYNC();
+  }
+}
+FQ_DEV u32 mt_temper(u32 y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+FQ_DEV u32 mt_next(WgShared *sm, u32 g) {
+  u32 idx = sm->mt_idx[g];
+  if (idx >= 624) {
+    mt_twist(sm->mt[g]);
+    idx = 0;
+  }
+  u32 y = sm->mt[g][idx];
+  FQ_SYNC();
+  if (FQ_LANE == 0) sm->mt_idx[g] = idx + 1;
+  FQ_SYNC();
+  return mt_temper(y);
+}
+
+// ---------------------------------------------------------------------------------------
+// CCounterIncrementer (utils.h:256-335) with the mapping table in closed form
+FQ_DEV u32 cinc_map(const Cinc &c, u32 i) {  // v_mapping[i], utils.h:303-311
+  if (i <= c.thr) return i;
+  if (i > c.maxv) i = c.maxv;
+  u32 n = i - c.thr;
+  return c.thr + c.mult * (n * (n + 1) / 2);
+}
+FQ_DEV u32 cinc_decode(const Cinc &c, u32 v) {  // utils.h:264-270
+  if (v <= c.thr) return v;
+  return (cinc_map(c, v) + cinc_map(c, v + 1)) / 2;
+}
+FQ_DEV u32 cinc_encode(WgShared *sm, u32 g, const Cinc &c, u32 real) {  // utils.h:272-290
+  if (real <= c.thr) return real;
+  u32 lo = c.thr, hi = (real < c.maxv ? real : c.maxv);
+  while (lo < hi) {  // last position whose mapped value is <= real (upper_bound - 1)
+    u32 mid = (lo + hi + 1) / 2;
+    if (cinc_map(c, mid) <= real) lo = mid; else hi = mid - 1;
+  }
+  u32 pos = lo;
+  if (pos >= c.maxv) return c.maxv;
+  u32 mp = cinc_map(c, pos);
+  u32 rest = real - mp;
+  if (mt_next(sm, g) % (cinc_map(c, pos + 1) - mp) < rest) ++pos;
+  return pos;
+}
+FQ_DEV u32 cinc_merge(WgShared *sm, u32 g, const Cinc &c, u32 a, u32 b) {  // Increment(a,b), utils.h:327-333
+  return cinc_encode(sm, g, c, cinc_decode(c, a) + cinc_decode(c, b));
+}
+FQ_DEV u32 cinc_inc1(WgShared *sm, u32 g, const Cinc &c, u32 v) {  // Increment(c), utils.h:314-325
+  if (v <= c.thr) return v + 1;
+  return (mt_next(sm, g) % (c.mult * (v - c.thr)) == 0) ? v + 1 : v;
+}
+
+// ---------------------------------------------------------------------------------------
+// rolling canonical k-mer (kmer.h), symbols left-aligned
+FQ_DEV void km_reset(Kmer &k) { k.dir = k.rc = 0; k.cur = 0; }
+FQ_DEV void km_insert(Kmer &k, const KGeom &g, u64 sym) {  // kmer.h:80-96
+  k.rc >>= 2;
+  k.rc += (3 - sym) << 62;
+  k.rc &= g.mask;
+  if (k.cur == g.k) {
+    k.dir <<= 2;
+    k.dir += sym << g.shift;
+  } else {
+    ++k.cur;
+    k.dir += sym << (64 - 2 * k.cur);
+  }
+}
+FQ_DEV void km_insert_zero(Kmer &k, const KGeom &g) {  // kmer.h:99-115
+  k.rc >>= 2;
+  k.rc += 3ull << 62;
+  k.rc &= g.mask;
+  if (k.cur == g.k) k.dir <<= 2; else ++k.cur;
+}
+FQ_DEV void km_replace(Kmer &k, u64 sym, u32 pos) {  // kmer.h:153-160,172-178
+  u32 sh = 62 - 2 * pos;
+  k.dir = (k.dir & ~(3ull << sh)) + (sym << sh);
+  sh = 64 - 2 * k.cur + 2 * pos;
+  k.rc = (k.rc & ~(3ull << sh)) + ((3 - sym) << sh);
+}
+FQ_DEV void km_replace_last(Kmer &k, u64 sym) {  // kmer.h:163-169,181-185
+  u32 sh = 64 - 2 * k.cur;
+  k.dir = (k.dir & ~(3ull << sh)) + (sym << sh);
+  k.rc = ((k.rc << 2) >> 2) + ((3 - sym) << 62);
+}
+FQ_DEV bool km_norm_dir(const Kmer &k, const KGeom &g) { return (k.dir & g.kernel_mask) < (k.rc & g.kernel_mask); }
+FQ_DEV u64 km_norm(const Kmer &k, const KGeom &g) { return km_norm_dir(k, g) ? k.dir : k.rc; }
+FQ_DEV u64 km_aligned_dir(const Kmer &k) { return k.cur ? k.dir >> (64 - 2 * k.cur) : 0; }  // kmer.h:398 (quirk 18)
+FQ_DEV u64 km_aligned_rc(const Kmer &k) { return k.cur ? k.rc >> (64 - 2 * k.cur) : 0; }
+FQ_DEV u64 km_symbol(const Kmer &k, u32 pos) { return (k.dir >> (62 - 2 * pos)) & 3; }
+FQ_DEV bool km_full(const Kmer &k, const KGeom &g) { return k.cur == g.k; }
+FQ_DEV bool km_almost_full(const Kmer &k, const KGeom &g, u32 margin) { return k.cur + margin >= g.k; }
+
+// ---------------------------------------------------------------------------------------
+// k-mer tables
+FQ_DEV u32 sb_owner(const DevCfg *cfg, u64 kmer_norm) { return (u32)(((kmer_norm >> 46) & 0x3fffull) % cfg->T); }  // dna.cpp:825
+FQ_DEV u32 p_owner(const DevCfg *cfg, u64 idx) { return (u32)((idx >> cfg->pmer_mod_shift) % cfg->T); }           // dna.cpp:658
+
+FQ_DEV u64 tab_home(const KTab &t, u64 v) {
+  u64 kern = (v >> 4) & ((1ull << (2 * t.k - 8)) - 1ull);
+  return murmur64(kern) & t.cap_mask;
+}
+// one cluster scan: counts of the 4 sibling k-mers (_update_counts_full, ht_kmer.h:205-263)
+FQ_DEV void tab_scan(const KTab &t, u32 sub, u64 kmer_norm, bool is_dir, C4 &c, u64 &nslots) {
+  const u64 *s = t.slots + (u64)sub * t.stride;
+  const u32 k2 = 2 * t.k;
+  u64 v = kmer_norm >> (64 - k2);
+  u64 p = tab_home(t, v);
+  const u64 cm = (1ull << t.cbits) - 1ull;
+  const u64 lowmask = (1ull << (k2 - 2)) - 1ull;
+  const u64 grp = is_dir ? (v >> 2) : (v & lowmask);
+  for (u64 n = 0; n <= t.cap_mask; ++n) {
+    u64 it = s[p];
+    ++nslots;
+    if (!it) break;
+    u64 iv = it >> t.cbits;
+    if (is_dir) {
+      if ((iv >> 2) == grp) c4_add(c, (u32)(iv & 3), (u32)(it & cm));
+    } else {
+      if ((iv & lowmask) == grp) c4_add(c, 3u - (u32)(iv >> (k2 - 2)), (u32)(it & cm));
+    }
+    p = (p + 1) & t.cap_mask;
+  }
+}
+// exact look-up (count(), ht_kmer.h:330-362,441-453)
+FQ_DEV u32 tab_count(const KTab &t, u32 sub, u64 kmer_norm, u64 &nslots) {
+  const u64 *s = t.slots + (u64)sub * t.stride;
+  u64 v = kmer_norm >> (64 - 2 * t.k);
+  u64 p = tab_home(t, v);
+  for (u64 n = 0; n <= t.cap_mask; ++n) {
+    u64 it = s[p];
+    ++nslots;
+    if (!it) return 0;
+    if ((it >> t.cbits) == v) return (u32)(it & ((1ull << t.cbits) - 1ull));
+    p = (p + 1) & t.cap_mask;
+  }
+  return 0;
+}
+// wave-uniform insert used for the worker-private local tables (insert(), ht_kmer.h:420-438)
+FQ_DEV void tab_insert_uniform(Wk &w, const KTab &t, u32 sub, u64 kmer_norm, u32 rng, const Cinc &ci) {
+  u64 *s = t.slots + (u64)sub * t.stride;
+  u64 v = kmer_norm >> (64 - 2 * t.k);
+  u64 p = tab_home(t, v);
+  const u64 cm = (1ull << t.cbits) - 1ull;
+  for (u64 n = 0; n <= t.cap_mask; ++n) {
+    u64 it = s[p];
+    if (!it) {
+      u32 f = t.filled[sub];
+      if ((u64)f * 10 >= (t.cap_mask + 1) * 9) { w.err = FQSX_ERR_LTAB_FULL; return; }
+      s[p] = (v << t.cbits) | 1ull;  // Increment(0) == 1
+      t.filled[sub] = f + 1;
+      return;
+    }
+    if ((it >> t.cbits) == v) {
+      u32 cnt = (u32)(it & cm);
+      if (cnt < (u32)cm && cinc_inc1(w.sm, rng, ci, cnt) != cnt) s[p] = it + 1;
+      return;
+    }
+    p = (p + 1) & t.cap_mask;
+  }
+  w.err = FQSX_ERR_LTAB_FULL;
+}
+
+// probe the first n entries of the LDS batch (keys/orientations) lane-parallel
+FQ_DEV void batch_scan(Wk &w, const KTab &t, bool global, u32 n) {
+  WgShared *sm = w.sm;
+  u64 ns = 0;
+  FQ_SYNC();
+  for (u32 i = FQ_LANE; i < n; i += FQ_WAVE) {
+    C4 c;
+    c4_zero(c);
+    u64 key = sm->bk_key[i];
+    tab_scan(t, global ? sb_owner(w.cfg, key) : w.tid, key, sm->bk_dir[i] != 0, c, ns);
+    sm->bk_res[i][0] = c.c[0];
+    sm->bk_res[i][1] = c.c[1];
+    sm->bk_res[i][2] = c.c[2];
+    sm->bk_res[i][3] = c.c[3];
+  }
+  FQ_SYNC();
+  w.st[global ? ST_GPROBE : ST_LPROBE] += n;
+  w.st[global ? ST_GSLOT : ST_LSLOT] += wave_sum64(ns);
+}
+FQ_DEV void batch_count(Wk &w, const KTab &t, u32 n) {  // exact counts of the batch keys (global table)
+  WgShared *sm = w.sm;
+  u64 ns = 0;
+  FQ_SYNC();
+  for (u32 i = FQ_LANE; i < n; i += FQ_WAVE) {
+    u64 key = sm->bk_key[i];
+    sm->bk_res[i][0] = tab_count(t, sb_owner(w.cfg, key), key, ns);
+  }
+  FQ_SYNC();
+  w.st[ST_GPROBE] += n;
+  w.st[ST_GSLOT] += wave_sum64(ns);
+}
+
+// find / find_full / find_partial (ht_kmer.h:189-203,266-327,504-510)
+FQ_DEV bool kt_find(Wk &w, const KTab &t, bool global, const KGeom &g, const Kmer &km, u32 rng, const Cinc &ci, C4 &out) {
+  c4_zero(out);
+  if (km.cur == g.k) {
+    u64 ns = 0;
+    u64 key = km_norm(km, g);
+    tab_scan(t, global ? sb_owner(w.cfg, key) : w.tid, key, km_norm_dir(km, g), out, ns);
+    w.st[global ? ST_GPROBE : ST_LPROBE] += 1;
+    w.st[global ? ST_GSLOT : ST_LSLOT] += ns;
+    return c4_any(out);
+  }
+  // partial k-mer: all 4^m front paddings, position 0 is the fastest odometer digit (ht_kmer.h:291-310)
+  WgShared *sm = w.sm;
+  const u32 m = g.k - km.cur;
+  const u32 trials = 1u << (2 * m);
+  const u64 dir_pad = km.dir >> (2 * m);
+  u64 rc_pad = km.rc & (~0ull << (64 - 2 * km.cur));  // rc already holds cur symbols at the top
+  for (u32 base = 0; base < trials; base += 256) {
+    u32 n = trials - base < 256 ? trials - base : 256;
+    FQ_SYNC();
+    for (u32 i = FQ_LANE; i < n; i += FQ_WAVE) {
+      u32 t_i = base + i;
+      u64 d = dir_pad, r = rc_pad;
+      for (u32 j = 0; j < m; ++j) {
+        u64 sym = (t_i >> (2 * j)) & 3;
+        d |= sym << (62 - 2 * j);
+        r |= (3 - sym) << (64 - 2 * g.k + 2 * j);
+      }
+      bool nd = (d & g.kernel_mask) < (r & g.kernel_mask);
+      sm->bk_key[i] = nd ? d : r;
+      sm->bk_dir[i] = nd ? 1 : 0;
+    }
+    batch_scan(w, t, global, n);
+    for (u32 i = 0; i < n; ++i)
+      for (u32 s = 0; s < 4; ++s) {
+        u32 loc = sm->bk_res[i][s];
+        if (loc) out.c[s] = cinc_merge(sm, rng, ci, out.c[s], loc);  // ht_kmer.h:321-323
+      }
+  }
+  return c4_any(out);
+}
+
+// ---------------------------------------------------------------------------------------
+// p-mer vector (bit_vec.h)
+FQ_DEV u64 siv_test(const DevCfg *cfg, u64 idx) { return (cfg->siv[idx >> 5] >> (2 * (idx & 31))) & 3; }  // bit_vec.h:69-81
+FQ_DEV void siv_counts(Wk &w, u64 idx, C4 &c) {  // counts(), bit_vec.h:83-96
+  u64 d = w.cfg->siv[idx >> 5];
+  u32 sh = 2 * (u32)((idx & 31) & ~3ull);
+  c.c[0] = (u32)((d >> sh) & 3);
+  c.c[1] = (u32)((d >> (sh + 2)) & 3);
+  c.c[2] = (u32)((d >> (sh + 4)) & 3);
+  c.c[3] = (u32)((d >> (sh + 6)) & 3);
+  w.st[ST_SIV_WORDS] += 1;
+}
+FQ_DEV u64 word_field_sum(u64 d) {  // sum of the 32 2-bit fields
+  u64 x = (d & 0x3333333333333333ULL) + ((d >> 2) & 0x3333333333333333ULL);
+  x = (x & 0x0f0f0f0f0f0f0f0fULL) + ((x >> 4) & 0x0f0f0f0f0f0f0f0fULL);
+  return (x * 0x0101010101010101ULL) >> 56;
+}
+// sum of fields [start,end)  (test_shorter, bit_vec.h:113-188), lane-parallel over words
+FQ_DEV u64 siv_range_sum(Wk &w, u64 start, u64 end) {
+  if (start >= end) return 0;
+  const u64 *sv = w.cfg->siv;
+  u64 w0 = start >> 5, w1 = (end - 1) >> 5, r = 0;
+  for (u64 x = w0 + FQ_LANE; x <= w1; x += FQ_WAVE) {
+    u64 d = sv[x];
+    if (x == w0) d &= ~0ull << (2 * (start & 31));
+    if (x == w1 && (end & 31)) d &= ~(~0ull << (2 * (end & 31)));
+    r += word_field_sum(d);
+  }
+  w.st[ST_SIV_WORDS] += w1 - w0 + 1;
+  return wave_sum64(r);
+}
+// #{ i in (lo,hi) : field(i) == flag }  -- the p-mer rank sweep of compress_prefix_sorted, dna.cpp:600-605
+FQ_DEV u64 siv_count_equal(Wk &w, u64 lo, u64 hi, u64 flag) {
+  u64 start = lo + 1;
+  if (start >= hi) return 0;
+  const u64 *sv = w.cfg->siv;
+  const u64 rep = flag * 0x5555555555555555ULL;
+  u64 w0 = start >> 5, w1 = (hi - 1) >> 5, r = 0;
+  for (u64 x = w0 + FQ_LANE; x <= w1; x += FQ_WAVE) {
+    u64 d = sv[x] ^ rep;
+    u64 eq = ~(d | (d >> 1)) & 0x5555555555555555ULL;
+    if (x == w0) eq &= ~0ull << (2 * (start & 31));
+    if (x == w1 && (hi & 31)) eq &= ~(~0ull << (2 * (hi & 31)));
+    r += popc64(eq);
+  }
+  w.st[ST_SIV_WORDS] += w1 - w0 + 1;
+  return wave_sum64(r);
+}
+
+// ---------------------------------------------------------------------------------------
+// range coder (CRangeEncoder, sub_rc.h:32-87) writing into the worker's HBM stream
+FQ_DEV void rc_put(Wk &w, u8 b) {
+  if (w.enc.len < w.enc.cap) w.enc.out[w.enc.len] = b; else w.err = FQSX_ERR_OUT_OVERFLOW;
+  ++w.enc.len;
+}
+FQ_DEV void rc_encode(Wk &w, u32 freq, u32 cum, u32 tot) {
+  const u64 Top = 0x00ffffffffffffULL, M = 0xff00000000000000ULL;
+  u64 range = w.enc.range / tot, low = w.enc.low;
+  low += range * cum;
+  range *= freq;
+  while (range <= Top) {
+    if ((low ^ (low + range)) & M) range = (low | Top) - low;
+    rc_put(w, (u8)(low >> 56));
+    low <<= 8;
+    range <<= 8;
+  }
+  w.enc.low = low;
+  w.enc.range = range;
+  w.st[ST_CODED] += 1;
+}
+
+// small direct-indexed adaptive model in HBM: N stats + total (CSimpleModel, rc.h:20-173; Encode rc.h:397-405)
+FQ_DEV void sm_encode(Wk &w, u16 *m, u32 n, u32 max_total, u32 x) {
+  u32 cum = 0;
+  for (u32 i = 0; i < x; ++i) cum += m[i];
+  u32 f = m[x], tot = m[n];
+  rc_encode(w, f, cum, tot);
+  f += 4;
+  tot += 4;
+  m[x] = (u16)f;
+  if (tot >= max_total) {  // rescale, rc.h:28-39
+    while (tot >= max_total) {
+      tot = 0;
+      for (u32 i = 0; i < n; ++i) {
+        u32 v = (m[i] + 1u) / 2u;
+        m[i] = (u16)v;
+        tot += v;
+      }
+    }
+  }
+  m[n] = (u16)tot;
+}
+// 256-symbol model (prefix_sorted_bytes): cumulative sum and rescale are lane-parallel
+FQ_DEV void sm_encode256(Wk &w, u16 *m, u8 *init_flag, u32 x) {
+  if (!*init_flag) {
+    FQ_SYNC();
+    for (u32 i = FQ_LANE; i < 256; i += FQ_WAVE) m[i] = 1;
+    m[256] = 256;
+    *init_flag = 1;
+    FQ_SYNC();
+  }
+  u32 part = 0;
+  for (u32 i = FQ_LANE; i < x; i += FQ_WAVE) part += m[i];
+  u32 cum = wave_sum32(part);
+  u32 f = m[x], tot = m[256];
+  rc_encode(w, f, cum, tot);
+  tot += 4;
+  FQ_SYNC();
+  m[x] = (u16)(f + 4);
+  FQ_SYNC();
+  while (tot >= (1u << 15)) {
+    u32 p = 0;
+    for (u32 i = FQ_LANE; i < 256; i += FQ_WAVE) {
+      u32 v = (m[i] + 1u) / 2u;
+      m[i] = (u16)v;
+      p += v;
+    }
+    tot = wave_sum32(p);
+    FQ_SYNC();
+  }
+  m[256] = (u16)tot;
+}
+
+// ---------------------------------------------------------------------------------------
+// context map of 5-symbol models (CContextHM, context_hm.h:21-248; exact map semantics:
+// inserting an existing key leaves the earlier entry in place, which is what shadows the
+// later duplicate in the reference's linear probe)
+struct Slot4 { u64 q0, q1, q2, q3; };  // key | counter,tag,total | st0..3 | st4
+FQ_DEV u64 *ctx_base(Wk &w) { return (u64 *)(w.cfg->ctx + (u64)w.tid * (w.cfg->ctx_cap_mask + 1)); }
+FQ_DEV u64 ctx_hash(Wk &w, u32 tag, u64 key) { return murmur64(key ^ ((u64)tag * 0x9E3779B97F4A7C15ULL)) & w.cfg->ctx_cap_mask; }
+FQ_DEV u32 slot_counter(const Slot4 &s) { return (u32)s.q1; }
+FQ_DEV u32 slot_tag(u64 q1) { return (u32)(q1 >> 32) & 0xffffu; }
+FQ_DEV u32 ctx_find(Wk &w, u32 tag, u64 key, Slot4 &s) {
+  const u64 *b = ctx_base(w);
+  u64 h = ctx_hash(w, tag, key);
+  for (u64 n = 0; n <= w.cfg->ctx_cap_mask; ++n) {
+    const u64 *p = b + 4 * h;
+    u64 q0 = p[0], q1 = p[1];
+    w.st[ST_CTX] += 1;
+    u32 tg = slot_tag(q1);
+    if (!tg) return FQSX_NIL;
+    if (tg == tag && q0 == key) {
+      s.q0 = q0; s.q1 = q1; s.q2 = p[2]; s.q3 = p[3];
+      return (u32)h;
+    }
+    h = (h + 1) & w.cfg->ctx_cap_mask;
+  }
+  return FQSX_NIL;
+}
+// insert (key -> model copy, counter 0) unless present; returns the slot holding the key
+FQ_DEV u32 ctx_insert(Wk &w, u32 tag, u64 key, u64 q2, u64 q3, u32 total, Slot4 &s) {
+  u64 *b = ctx_base(w);
+  u64 h = ctx_hash(w, tag, key);
+  for (u64 n = 0; n <= w.cfg->ctx_cap_mask; ++n) {
+    u64 *p = b + 4 * h;
+    u64 q0 = p[0], q1 = p[1];
+    u32 tg = slot_tag(q1);
+    if (!tg) {
+      u32 f = w.cfg->ctx_filled[w.tid];
+      if ((u64)f * 10 >= (w.cfg->ctx_cap_mask + 1) * 9) { w.err = FQSX_ERR_CTX_FULL; return FQSX_NIL; }
+      w.cfg->ctx_filled[w.tid] = f + 1;
+      s.q0 = key;
+      s.q1 = ((u64)tag << 32) | ((u64)total << 48);
+      s.q2 = q2;
+      s.q3 = q3;
+      p[0] = s.q0; p[1] = s.q1; p[2] = s.q2; p[3] = s.q3;
+      return (u32)h;
+    }
+    if (tg == tag && q0 == key) {
+      s.q0 = q0; s.q1 = q1; s.q2 = p[2]; s.q3 = p[3];
+      return (u32)h;
+    }
+    h = (h + 1) & w.cfg->ctx_cap_mask;
+  }
+  w.err = FQSX_ERR_CTX_FULL;
+  return FQSX_NIL;
+}
+FQ_DEV void ctx_store_counter(Wk &w, u32 idx, Slot4 &s, u32 counter) {
+  s.q1 = (s.q1 & 0xffffffff00000000ULL) | counter;
+  ctx_base(w)[4 * (u64)idx + 1] = s.q1;
+}
+
+// level thresholds (dna.h:33,36)
+FQ_DEV u32 code_thr(u32 i) {
+  const u32 t[12] = {1, 32, 64, 64, 128, 512, 1024, 32, 128, 256, 2048, 4};
+  return t[i];
+}
+FQ_DEV u32 letters_thr(u32 i) {
+  const u32 t[12] = {1, 32, 64, 128, 256, 512, 2048, 4096, 8192, 16384, 16384, 4};
+  return t[i];
+}
+
+// find_rc_code_context / find_rc_letters_context (dna.cpp:2107-2286): hierarchical level
+// search with lazy clone-on-threshold; returns slot index (model + already incremented counter in s)
+FQ_DEV u32 find_leveled(Wk &w, u32 tag, const u64 *lev, int n_levels, double &avg, u64 tpl_q2, u64 tpl_q3, u32 tpl_total, Slot4 &s) {
+  int i;
+  Slot4 q;
+  const bool letters = tag == 2;
+  int start = (int)(avg + 0.49);
+  u32 p = ctx_find(w, tag, lev[start], s);
+  if (p != FQSX_NIL && slot_counter(s) < (letters ? letters_thr(start) : code_thr(start))) {
+    ctx_store_counter(w, p, s, slot_counter(s) + 1);
+    avg = ema_update(avg, (double)start);
+    return p;
+  }
+  if (p == FQSX_NIL) {
+    for (i = start - 1; i >= 0; --i) {
+      p = ctx_find(w, tag, lev[i], s);
+      if (p != FQSX_NIL) break;
+    }
+  } else {
+    for (i = start + 1; i < n_levels; ++i) {
+      u32 qi = ctx_find(w, tag, lev[i], q);
+      if (qi == FQSX_NIL) break;
+      if (slot_counter(q) < code_thr(i)) {  // both routines use the *code* thresholds here (quirk, dna.cpp:2244)
+        avg = ema_update(avg, (double)i);
+        ctx_store_counter(w, qi, q, slot_counter(q) + 1);
+        s = q;
+        return qi;
+      }
+      p = qi;
+      s = q;
+    }
+    --i;
+  }
+  if (p == FQSX_NIL) {  // nothing known: create level 0 from the template
+    p = ctx_insert(w, tag, lev[0], tpl_q2, tpl_q3, tpl_total, s);
+    if (p == FQSX_NIL) return p;
+    ctx_store_counter(w, p, s, slot_counter(s) + 1);
+    i = 0;
+  }
+  if (slot_counter(s) >= code_thr(i) && i + 1 < n_levels) {  // clone into the next level (dna.cpp:2177-2184)
+    u32 total = (u32)(s.q1 >> 48);
+    Slot4 c;
+    u32 ci = ctx_insert(w, tag, lev[i + 1], s.q2, s.q3, total, c);
+    if (ci == FQSX_NIL) return ci;
+    ctx_store_counter(w, ci, c, slot_counter(c) + 1);
+    s = c;
+    p = ci;
+  } else
+    ctx_store_counter(w, p, s, slot_counter(s) + 1);
+  avg = ema_update(avg, (double)i);
+  return p;
+}
+
+// Encode with a context slot's 5-symbol model (CSimpleModelFixedSize<5>, rc.h:178-338,478-488)
+FQ_DEV void slot_encode(Wk &w, u32 idx, Slot4 &s, u32 x) {
+  u32 st[5];
+  st[0] = (u32)(s.q2 & 0xffff); st[1] = (u32)((s.q2 >> 16) & 0xffff);
+  st[2] = (u32)((s.q2 >> 32) & 0xffff); st[3] = (u32)(s.q2 >> 48);
+  st[4] = (u32)(s.q3 & 0xffff);
+  u32 tot = (u32)(s.q1 >> 48);
+  u32 cum = 0, f = 0;
+  for (u32 i = 0; i < 5; ++i) {
+    cum += i < x ? st[i] : 0;
+    f = i == x ? st[i] : f;
+  }
+  rc_encode(w, f, cum, tot);
+  for (u32 i = 0; i < 5; ++i) st[i] += i == x ? 4u : 0u;
+  tot += 4;
+  while (tot >= (1u << 15)) {
+    tot = 0;
+    for (u32 i = 0; i < 5; ++i) {
+      st[i] = (st[i] + 1) / 2;
+      tot += st[i];
+    }
+  }
+  s.q2 = (u64)st[0] | ((u64)st[1] << 16) | ((u64)st[2] << 32) | ((u64)st[3] << 48);
+  s.q3 = (s.q3 & ~0xffffULL) | st[4];
+  s.q1 = (s.q1 & 0x0000ffffffffffffULL) | ((u64)tot << 48);
+  u64 *p = ctx_base(w) + 4 * (u64)idx;
+  p[1] = s.q1; p[2] = s.q2; p[3] = s.q3;
+}
+
+// ---------------------------------------------------------------------------------------
+// context keys (code_ctx.cpp)
+FQ_DEV u64 conv_lev1(u64 c, u32 cl) {  // code_ctx.cpp:26-81
+  u64 f = (u64)cl << 5;
+  if (cl == 0) {
+    if (c < 5) return f + c;
+    if (c < 8) return f + 5;
+    if (c < 16) return f + 6;
+    if (c < 32) return f + 7;
+    if (c < 64) return f + 8;
+    return f + 9;
+  }
+  const u32 lim[21] = {16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 288, 384, 512, 1024, 2048};
+  if (c < 8) return f + c;
+  for (u32 i = 0; i < 21; ++i)
+    if (c < lim[i]) return f + 8 + i;
+  return f + 29;
+}
+FQ_DEV u64 conv_low(u64 c, u32 cl, bool lev3) {  // shared rows of code_ctx.cpp:84-110 and :167-198
+  u64 f = (u64)cl << 5;
+  if (cl == 0) {
+    if (c < 3) return f + c;
+    if (c < 5) return f + 3;
+    return f + 4;
+  }
+  if (cl == 1) {
+    if (c < 5) return f + c;
+    if (c < 8) return f + 5;
+    if (c < 13) return f + 6;
+    if (c < 20) return f + 7;
+    if (c < 30) return f + 8;
+    return f + 9;
+  }
+  // cl == 2
+  if (c < 10) return f + c;
+  if (c < (lev3 ? 13u : 15u)) return f + 10;
+  if (c < 20) return f + 11;
+  if (c < 30) return f + 12;
+  if (c < 50) return f + 13;
+  return f + 14;
+}
+FQ_DEV u64 conv_lev24(u64 c, u32 cl) {  // code_ctx.cpp:84-164
+  if (cl < 3) return conv_low(c, cl, false);
+  u64 f = (u64)cl << 5;
+  const u32 lim[19] = {16, 24, 32, 48, 64, 128, 256, 512, 1024, 2048, 2080, 2112, 2176, 2240, 2304, 2432, 2560, 2816, 3072};
+  if (c < 10) return f + c;
+  for (u32 i = 0; i < 19; ++i)
+    if (c < lim[i]) return f + 10 + i;
+  return f + 29;
+}
+FQ_DEV u64 conv_lev3(u64 c, u32 cl) {  // code_ctx.cpp:167-239
+  if (cl < 3) return conv_low(c, cl, true);
+  u64 f = (u64)cl << 5;
+  const u32 lim[14] = {18, 20, 25, 30, 40, 50, 60, 64, 68, 72, 76, 80, 84, 88};
+  if (c < 15) return f + c;
+  for (u32 i = 0; i < 14; ++i)
+    if (c < lim[i]) return f + 15 + i;
+  return f + 29;
+}
+enum { LV_NONE = 0, LV_PMER = 1, LV_SMER = 2, LV_BMER = 3, LV_MIXED = 4, LV_BMER_UNC = 5 };  // defs.h:45
+FQ_DEV u64 conv_count(u64 c, u32 level, u32 cl) {  // code_ctx.cpp:15-23
+  if (level == LV_PMER) return conv_lev1(c, cl);
+  if (level == LV_BMER) return conv_lev3(c, cl);
+  return conv_lev24(c, cl);
+}
+FQ_DEV void sort_desc4(u32 d[4], const C4 &c) {  // sort_copy_stats, utils.cpp:109-126 (descending, stable)
+  u32 a = c.c[0], b = c.c[1], e = c.c[2], f = c.c[3], t;
+  // insertion network that only swaps on strict "greater", i.e. stable
+  if (b > a) { t = a; a = b; b = t; }
+  if (e > b) { t = b; b = e; e = t; if (b > a) { t = a; a = b; b = t; } }
+  if (f > e) { t = e; e = f; f = t; if (e > b) { t = b; b = e; e = t; if (b > a) { t = a; a = b; b = t; } } }
+  d[0] = a; d[1] = b; d[2] = e; d[3] = f;
+}
+
+#define SH_POS 0
+#define SH_LEVEL 14
+#define SH_C0 17
+#define SH_C1 24
+#define SH_C2 31
+#define SH_C3 38
+#define SH_RSYM 45
+#define SH_LETMAX 49
+#define SH_CORZ 52
+#define EN_POS (0x3fffull << SH_POS)
+#define EN_LEVEL (7ull << SH_LEVEL)
+#define EN_CN(i) (0x7full << (SH_C0 + 7 * (i)))
+#define EN_RSYM (0xfull << SH_RSYM)
+#define EN_LETMAX (7ull << SH_LETMAX)
+#define EN_CORZ (7ull << SH_CORZ)
+
+FQ_DEV u32 let_max(const C4 &c, const u64 *sl) {  // let_max_element, code_ctx.cpp:327-338; also dna.cpp:335-340
+  u32 r = 0;
+  for (u32 i = 1; i < 4; ++i) {
+    u32 ci = c4_get(c, i), cr = c4_get(c, r);
+    if (ci > cr) r = i;
+    else if (ci == cr && sl_get(sl, i) > sl_get(sl, r)) r = i;
+  }
+  return r;
+}
+// determine_ctx_codes, code_ctx.cpp:257-324
+FQ_DEV void ctx_codes(u64 a[7], const DevCfg *cfg, const C4 &counts, const u64 *sl, u32 pos, u32 level, u32 cor_zone, u64 ctx_r_sym, u32 read_len) {
+  u64 mask = ~0ull, ctx = 0;
+  u32 plim = level == 0 ? 0u : level == 1 ? cfg->pmer : level == 2 ? cfg->smer : cfg->bmer;
+  u32 srt[4];
+  sort_desc4(srt, counts);
+  a[0] = ctx | mask;
+  mask ^= EN_LEVEL | EN_CN(0) | EN_CN(1) | EN_CN(2) | EN_CN(3) | EN_POS;
+  ctx += (u64)level << SH_LEVEL;
+  ctx += conv_count(srt[0], level, 1) << SH_C0;
+  ctx += conv_count(srt[1], level, 1) << SH_C1;
+  ctx += conv_count(srt[2], level, 0) << SH_C2;
+  ctx += conv_count(srt[3], level, 0) << SH_C3;
+  const bool in_lim = pos < plim, eor = pos + 5 >= read_len;
+  const u64 eor_v = 0x3fffull - (u64)(u32)(read_len - pos);
+  if (in_lim) ctx += (u64)pos << SH_POS;
+  else if (eor) ctx += eor_v << SH_POS;
+  else ctx += (u64)(plim + pos / 16) << SH_POS;
+  a[1] = ctx | mask;
+  mask ^= EN_CORZ | EN_RSYM;
+  ctx += (u64)cor_zone << SH_CORZ;
+  ctx += (u64)popc64(ctx_r_sym) << SH_RSYM;  // transform_r_sym, code_ctx.cpp:371-373
+  a[2] = ctx | mask;
+  ctx &= ~(EN_CN(0) | EN_CN(1));
+  ctx += conv_count(srt[0], level, 2) << SH_C0;
+  ctx += conv_count(srt[1], level, 2) << SH_C1;
+  a[3] = ctx | mask;
+  ctx &= ~(EN_CN(0) | EN_CN(1) | EN_CN(2) | EN_CN(3));
+  ctx += conv_count(srt[0], level, 3) << SH_C0;
+  ctx += conv_count(srt[1], level, 3) << SH_C1;
+  ctx += conv_count(srt[2], level, 1) << SH_C2;
+  ctx += conv_count(srt[3], level, 1) << SH_C3;
+  a[4] = ctx | mask;
+  mask ^= EN_LETMAX;
+  ctx += (u64)let_max(counts, sl) << SH_LETMAX;
+  a[5] = ctx | mask;
+  ctx &= ~EN_POS;
+  if (in_lim) ctx += ((u64)pos + (1u << 13)) << SH_POS;
+  else if (eor) ctx += eor_v << SH_POS;
+  else ctx += ((u64)plim + pos / 8 + (1u << 13)) << SH_POS;
+  a[6] = ctx | mask;
+}
+// determine_ctx_letters, code_ctx.cpp:465-490
+FQ_DEV void ctx_letters_keys(u64 a[10], const DevCfg *cfg, u32 pos, u64 letters, u32 read_len) {
+  u64 mask = ~0ull ^ 0x3fffull, ctx = 0;
+  if (pos < cfg->pmer) ctx += (u64)pos;
+  else if (pos + 5 > read_len) ctx += 0x3fffull - (u64)(u32)(read_len - pos);
+  for (u32 i = 0; i < 10; ++i) {
+    ctx += ((letters >> (4 * i)) & 7ull) << (14 + 3 * i);
+    mask ^= 7ull << (14 + 3 * i);
+    a[i] = ctx | mask;
+  }
+}
+
+// templates (dna.cpp:106-117): letters {10,10,10,10,1}, codes {20,6,3,2,1}
+#define TPL_CODES_Q2 (20ull | (6ull << 16) | (3ull << 32) | (2ull << 48))
+#define TPL_CODES_Q3 1ull
+#define TPL_CODES_TOT 32u
+#define TPL_LET_Q2 (10ull | (10ull << 16) | (10ull << 32) | (10ull << 48))
+#define TPL_LET_Q3 1ull
+#define TPL_LET_TOT 41u
+
+// ---------------------------------------------------------------------------------------
+// mailboxes (my_*_to_add push_back, dna.cpp:657-660,818-852)
+FQ_DEV void mail_push(Wk &w, u32 kind, u32 dst, u64 x) {
+  WgShared *sm = w.sm;
+  const Mail &m = w.cfg->mail[kind];
+  u32 c = sm->mail_count[kind][dst];
+  u32 tail = sm->mail_tail[kind][dst];
+  u32 slot = c & (FQSX_CHUNK - 1);
+  FQ_SYNC();
+  if (slot == 0) {  // open a new chunk of this (src,dst) chain
+    u32 id = sm->mail_nchunks[kind];
+    if (id >= m.pool_chunks) { w.err = FQSX_ERR_MAIL_FULL; return; }
+    u64 pc = (u64)w.tid * m.pool_chunks;
+    m.next[pc + id] = FQSX_NIL;
+    if (c == 0) m.head[(u64)w.tid * w.cfg->T + dst] = id; else m.next[pc + tail] = id;
+    tail = id;
+    if (FQ_LANE == 0) {
+      sm->mail_nchunks[kind] = id + 1;
+      sm->mail_tail[kind][dst] = id;
+    }
+  }
+  m.pool[((u64)w.tid * m.pool_chunks + tail) * FQSX_CHUNK + slot] = x;
+  if (FQ_LANE == 0) sm->mail_count[kind][dst] = c + 1;
+  FQ_SYNC();
+  w.st[ST_MAIL] += 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// the coder proper
+FQ_DEV u32 rank_sym(const Wk &w, const C4 &counts, u32 sym) {  // rank(), dna.cpp:177-193
+  if (sym == 4) return 4;
+  u32 r = 0, cs = c4_get(counts, sym);
+  u64 ss = sl_get(w.s_let, sym);
+  for (u32 i = 0; i < 4; ++i) {
+    u32 ci = c4_get(counts, i);
+    u64 si = sl_get(w.s_let, i);
+    if (ci != cs) r += cs < ci;
+    else if (si != ss) r += ss < si;
+    else r += sym > i;
+  }
+  return r;
+}
+
+FQ_DEV bool find_counts_p(Wk &w, C4 &counts) {  // find_counts_p, dna.cpp:210-226
+  const DevCfg *cfg = w.cfg;
+  if (w.pm.cur != cfg->gp.k) {
+    Kmer t = w.pm;
+    u64 sh = 2 * (u64)cfg->pmer - 2 * (u64)t.cur;
+    for (u32 j = 0; j < 4; ++j) {
+      km_replace_last(t, j);
+      u64 idx = km_aligned_rc(t);
+      counts.c[j] = (u32)siv_range_sum(w, idx << sh, (idx + 1) << sh);
+    }
+  } else
+    siv_counts(w, km_aligned_dir(w.pm), counts);
+  return c4_any(counts);
+}
+FQ_DEV bool rough_p(Wk &w, C4 &counts) {  // find_counts_rough_p, dna.cpp:229-254 (order-free sums)
+  const DevCfg *cfg = w.cfg;
+  u32 n = 4 * (cfg->pmer - 1);
+  u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (u32 q = FQ_LANE; q < n; q += FQ_WAVE) {
+    u32 i = q >> 2;
+    u64 j = q & 3;
+    u32 sh = 62 - 2 * i;
+    u64 d = (w.pm.dir & ~(3ull << sh)) + (j << sh);
+    u64 idx = d >> (64 - 2 * w.pm.cur);
+    u64 word = cfg->siv[idx >> 5];
+    u32 fs = 2 * (u32)((idx & 31) & ~3ull);
+    a0 += (u32)((word >> fs) & 3);
+    a1 += (u32)((word >> (fs + 2)) & 3);
+    a2 += (u32)((word >> (fs + 4)) & 3);
+    a3 += (u32)((word >> (fs + 6)) & 3);
+  }
+  counts.c[0] = wave_sum32(a0);
+  counts.c[1] = wave_sum32(a1);
+  counts.c[2] = wave_sum32(a2);
+  counts.c[3] = wave_sum32(a3);
+  w.st[ST_SIV_WORDS] += n;
+  return c4_any(counts);
+}
+// find_counts_rough_s / _b, dna.cpp:257-330: Hamming-1 neighbourhood, probes batched, merges serial
+FQ_DEV bool rough_kt(Wk &w, const KTab &t, const KGeom &g, const Kmer &can, u32 rng, const Cinc &ci, C4 &counts) {
+  WgShared *sm = w.sm;
+  c4_zero(counts);
+  const u32 n = 4 * (g.k - 1);
+  FQ_SYNC();
+  for (u32 q = FQ_LANE; q < n; q += FQ_WAVE) {
+    u32 i = q >> 2;
+    u64 j = q & 3;
+    u32 sh = 62 - 2 * i;
+    u64 d = (can.dir & ~(3ull << sh)) + (j << sh);
+    sh = 64 - 2 * g.k + 2 * i;
+    u64 r = (can.rc & ~(3ull << sh)) + ((3 - j) << sh);
+    bool nd = (d & g.kernel_mask) < (r & g.kernel_mask);
+    sm->bk_key[q] = nd ? d : r;
+    sm->bk_dir[q] = nd ? 1 : 0;
+  }
+  batch_scan(w, t, true, n);
+  for (u32 q = 0; q < n; ++q) {
+    u32 l0 = sm->bk_res[q][0], l1 = sm->bk_res[q][1], l2 = sm->bk_res[q][2], l3 = sm->bk_res[q][3];
+    if (l0 | l1 | l2 | l3) {  // merges all four counters, zeros included (dna.cpp:324-326)
+      counts.c[0] = cinc_merge(sm, rng, ci, counts.c[0], l0);
+      counts.c[1] = cinc_merge(sm, rng, ci, counts.c[1], l1);
+      counts.c[2] = cinc_merge(sm, rng, ci, counts.c[2], l2);
+      counts.c[3] = cinc_merge(sm, rng, ci, counts.c[3], l3);
+    }
+  }
+  return c4_any(counts);
+}
+
+FQ_DEV u32 find_counts(Wk &w, C4 &counts) {  // find_counts, dna.cpp:457-502
+  const DevCfg *cfg = w.cfg;
+  c4_zero(counts);
+  u32 bmargin = cfg->bmer - cfg->smer - 1;
+  u32 smargin = cfg->smer - cfg->pmer + 1;
+  if (km_almost_full(w.bm, cfg->gb, bmargin)) {
+    if (kt_find(w, cfg->g_b, true, cfg->gb, w.bm, RNG_B, CINC_B, counts)) {
+      u32 sat = (counts.c[0] == 63) + (counts.c[1] == 63) + (counts.c[2] == 63) + (counts.c[3] == 63);
+      if (sat > 1) {
+        C4 c2;
+        kt_find(w, cfg->g_s, true, cfg->gs, w.sm_, RNG_S, CINC_S, c2);
+        counts.c[0] += c2.c[0]; counts.c[1] += c2.c[1]; counts.c[2] += c2.c[2]; counts.c[3] += c2.c[3];
+        return LV_MIXED;
+      }
+      return LV_BMER;
+    } else {
+      if (kt_find(w, cfg->l_b, false, cfg->gb, w.bm, RNG_LB, CINC_B, counts)) return LV_BMER;
+      if (w.bm.dir != w.bm_u.dir && kt_find(w, cfg->g_b, true, cfg->gb, w.bm_u, RNG_B, CINC_B, counts)) return LV_BMER_UNC;
+    }
+  }
+  if (km_almost_full(w.sm_, cfg->gs, smargin)) {
+    if (kt_find(w, cfg->g_s, true, cfg->gs, w.sm_, RNG_S, CINC_S, counts)) return LV_SMER;
+    if (kt_find(w, cfg->l_s, false, cfg->gs, w.sm_, RNG_LS, CINC_S, counts)) return LV_SMER;
+  } else if (find_counts_p(w, counts))
+    return LV_PMER;
+  return LV_NONE;
+}
+
+FQ_DEV bool repair_existing(Wk &w, u32 pos, const C4 &counts, u32 sym) {  // repair_kmers_existing, dna.cpp:333-370
+  u32 mx = let_max(counts, w.s_let);
+  if (sym != 4) {
+    if (mx == sym) return false;
+    if (c4_get(counts, sym) != 0) return false;
+    if (c4_get(counts, mx) <= 3) return false;
+  }
+  km_replace_last(w.pm, mx);
+  km_replace_last(w.sm_, mx);
+  km_replace_last(w.bm, mx);
+  w.cor_pos = pos;
+  return true;
+}
+FQ_DEV bool repair_missing(Wk &w, u32 pos) {  // repair_kmers_missing, dna.cpp:374-454
+  const DevCfg *cfg = w.cfg;
+  WgShared *sm = w.sm;
+  u64 nu = cfg->siv_stats[0], nf = cfg->siv_stats[1];
+  double aff = nf ? (double)nu / (double)nf : 0.0;  // avg_filling_factor, bit_vec.h:204-210
+  if (aff < 7.0) return false;
+  // 5 positions x 4 symbols; the entries equal to the current symbol are skipped
+  FQ_SYNC();
+  for (u32 q = FQ_LANE; q < 20; q += FQ_WAVE) {
+    u32 j = 1 + (q >> 2);
+    u64 c = q & 3;
+    Kmer t = w.bm;
+    km_replace(t, c, t.cur - 1 - j);
+    sm->bk_key[q] = km_norm(t, cfg->gb);
+  }
+  batch_count(w, cfg->g_b, 20);
+  int best_c = 4, best_count = 0, best_pos = 0;
+  for (u32 q = 0; q < 20; ++q) {
+    u32 j = 1 + (q >> 2), c = q & 3;
+    if (km_symbol(w.bm, w.bm.cur - 1 - j) == c) continue;
+    int cnt = (int)sm->bk_res[q][0];
+    if (cnt >= best_count && cnt >= 2) { best_c = (int)c; best_count = cnt; best_pos = (int)j; }
+  }
+  w.st[ST_GPROBE] -= 5;  // the 5 skipped look-ups are not part of the algorithm
+  if (best_pos) {
+    km_replace(w.bm, (u64)best_c, w.bm.cur - 1 - best_pos);
+    if (best_pos < (int)w.sm_.cur) km_replace(w.sm_, (u64)best_c, w.sm_.cur - 1 - best_pos);
+    if (best_pos < (int)w.pm.cur) km_replace(w.pm, (u64)best_c, w.pm.cur - 1 - best_pos);
+    u32 np = pos - (u32)best_pos;
+    w.cor_pos = w.cor_pos > np ? w.cor_pos : np;
+    return true;
+  }
+  return false;
+}
+
+FQ_DEV void code_letter(Wk &w, u32 pos, u32 sym, u32 read_len) {  // dna.cpp:520-528,776-785
+  u64 lev[10];
+  ctx_letters_keys(lev, w.cfg, pos, w.ctx_letters, read_len);
+  Slot4 s;
+  u32 idx = find_leveled(w, 2, lev, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
+  if (idx != FQSX_NIL) slot_encode(w, idx, s, sym);
+}
+
+FQ_DEV u16 *small_base(Wk &w) { return w.cfg->small + (u64)w.tid * SM_TOTAL_U16; }
+
+FQ_DEV void push_p_both(Wk &w) {
+  u64 x = km_aligned_dir(w.pm);
+  mail_push(w, MAIL_P, p_owner(w.cfg, x), x);
+  x = km_aligned_rc(w.pm);
+  mail_push(w, MAIL_P, p_owner(w.cfg, x), x);
+}
+FQ_DEV void push_b_local(Wk &w) {
+  u64 x = km_norm(w.bm, w.cfg->gb);
+  mail_push(w, MAIL_B, sb_owner(w.cfg, x), x);
+  tab_insert_uniform(w, w.cfg->l_b, w.tid, x, RNG_LB, CINC_B);
+  w.st[ST_LINS] += 1;
+}
+
+FQ_DEV void insert_all(Wk &w, u64 sym) {
+  const DevCfg *cfg = w.cfg;
+  km_insert(w.pm, cfg->gp, sym); km_insert(w.sm_, cfg->gs, sym); km_insert(w.bm, cfg->gb, sym);
+  km_insert(w.pm_u, cfg->gp, sym); km_insert(w.sm_u, cfg->gs, sym); km_insert(w.bm_u, cfg->gb, sym);
+}
+
+FQ_DEV u32 rd_sym(Wk &w, const u8 *p, u32 i, u32 size) { return size <= FQSX_RD_LDS ? (u32)w.sm->rd[i] : dna_code(p[i]); }
+
+FQ_DEV void prefix_direct(Wk &w, const u8 *p, u32 size) {  // compress_prefix_direct, dna.cpp:506-546
+  w.ctx_letters = ~0ull;
+  for (u32 i = 0; i < w.cfg->prefix; ++i) {
+    u32 sym = rd_sym(w, p, i, size);
+    code_letter(w, i, sym, 0);
+    w.ctx_letters = (w.ctx_letters << 4) + sym;
+    if (sym == 4) { sym = 0; w.cor_pos = i; }
+    insert_all(w, sym);
+  }
+}
+
+FQ_DEV void prefix_sorted(Wk &w, const u8 *p, u32 size) {  // compress_prefix_sorted, dna.cpp:549-661
+  const DevCfg *cfg = w.cfg;
+  WState *ws = w.ws;
+  u16 *sb = small_base(w);
+  w.ctx_letters = ~0ull;
+  bool was_N = false;
+  for (u32 i = 0; i < cfg->pmer; ++i) {
+    u32 sym = rd_sym(w, p, i, size);
+    w.ctx_letters = (w.ctx_letters << 4) + sym;
+    if (sym == 4) { sym = 3; was_N = true; w.N_run++; } else w.N_run = 0;
+    insert_all(w, sym);
+  }
+  sm_encode(w, sb + SM_OFF_NS, SM_NS_N, 1u << 12, was_N ? 1u : 0u);
+  u64 psf = ((ws->ctx_ps_flags << 1) + (was_N ? 1u : 0u)) & 0xffff;
+  u64 flag;
+  const u64 cur_idx = km_aligned_dir(w.pm);
+  if (w.pm.dir == ws->pmer_prev_dir) flag = 4;
+  else { flag = siv_test(cfg, cur_idx); w.st[ST_SIV_WORDS] += 1; }
+  sm_encode(w, sb + SM_OFF_PSF + psf * (SM_PSF_N + 1), SM_PSF_N, 1u << 12, (u32)flag);
+  psf = ((psf << 3) + flag) & 0xffff;
+  ws->ctx_ps_flags = psf;
+  if (flag < 4) {
+    u64 prev_idx = ws->pmer_prev_cur ? ws->pmer_prev_dir >> (64 - 2 * ws->pmer_prev_cur) : 0;
+    u64 dif = siv_count_equal(w, prev_idx, cur_idx, flag);
+    u32 nb = 1;
+    for (u64 x = dif >> 8; x; x >>= 8) ++nb;  // no_bytes, utils.h:164-174
+    sm_encode(w, sb + SM_OFF_PSNB + psf * 6u, cfg->ps_nobytes_n, 1u << 12, nb - 1);
+    if (nb == 1) {
+      u32 hi = (u32)(dif >> 4), lo = (u32)(dif & 0xf);
+      sm_encode(w, sb + SM_OFF_NIB + (u32)flag * (SM_NIB_N + 1), SM_NIB_N, 1u << 15, hi);
+      sm_encode(w, sb + SM_OFF_NIB + (4u + (u32)flag * 16u + hi) * (SM_NIB_N + 1), SM_NIB_N, 1u << 15, lo);
+    } else {
+      u32 hi_byte = (u32)(dif >> (nb * 8 - 8));
+      u32 e = (u32)flag * 4u + (nb - 2);
+      u8 *bi = cfg->byte_init + (u64)w.tid * SM_BYTE_ENTRIES;
+      sm_encode256(w, sb + SM_OFF_BYTE + (u64)e * (SM_BYTE_N + 1), bi + e, hi_byte);
+      for (u32 i = 0; i + 1 < nb; ++i) {
+        u32 e2 = 16u + ((e * 256u + hi_byte) * 4u + i);
+        sm_encode256(w, sb + SM_OFF_BYTE + (u64)e2 * (SM_BYTE_N + 1), bi + e2, (u32)(dif & 0xff));
+        dif >>= 8;
+      }
+    }
+  }
+  if (was_N)
+    for (u32 i = 0; i < cfg->pmer; ++i) {
+      u8 ch = p[i];
+      if (ch == 'T' || ch == 'N') sm_encode(w, sb + SM_OFF_NS + (i + 1) * (SM_NS_N + 1), SM_NS_N, 1u << 12, ch == 'N' ? 1u : 0u);
+    }
+  ws->pmer_prev_dir = w.pm.dir;
+  ws->pmer_prev_cur = w.pm.cur;
+  push_p_both(w);
+}
+
+FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {  // compress_suffix, dna.cpp:674-877
+  const DevCfg *cfg = w.cfg;
+  C4 counts;
+  c4_zero(counts);
+  u64 ctx_r_sym = 0;
+  for (u32 i = original_order ? cfg->prefix : cfg->pmer; i < size; ++i) {
+    if (w.err) return;
+    u32 sym = rd_sym(w, p, i, size);
+    u64 sym_k = sym == 4 ? 0 : sym;
+    km_insert_zero(w.pm, cfg->gp); km_insert_zero(w.sm_, cfg->gs); km_insert_zero(w.bm, cfg->gb);
+    km_insert_zero(w.pm_u, cfg->gp); km_insert_zero(w.sm_u, cfg->gs); km_insert_zero(w.bm_u, cfg->gb);
+    u32 level = find_counts(w, counts);
+    if (level == LV_BMER_UNC) {
+      w.bm = w.bm_u; w.sm_ = w.sm_u; w.pm = w.pm_u;
+      w.cor_pos = 0;
+      level = LV_BMER;
+    }
+    bool rough = false;
+    if (level == LV_NONE) {
+      if (km_full(w.bm, cfg->gb)) {
+        if (rough_kt(w, cfg->g_b, cfg->gb, w.bm, RNG_B, CINC_B, counts)) { level = LV_PMER; rough = true; }
+      } else if (km_full(w.sm_, cfg->gs)) {
+        if (rough_kt(w, cfg->g_s, cfg->gs, w.sm_, RNG_S, CINC_S, counts)) { level = LV_PMER; rough = true; }
+      } else if (km_full(w.pm, cfg->gp)) {
+        if (rough_p(w, counts)) { level = LV_PMER; rough = true; }
+      }
+    }
+    if (level != LV_NONE && w.N_run < 2) {
+      int cor_dist = level == LV_PMER ? (int)cfg->pmer : level == LV_SMER ? (int)cfg->smer : (int)cfg->bmer;
+      int d = (int)i - (int)w.cor_pos;
+      u32 cor_zone = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
+      if (rough) cor_zone = 3;
+      u64 lev[7];
+      ctx_codes(lev, cfg, counts, w.s_let, i, level, cor_zone, ctx_r_sym, size);
+      Slot4 s;
+      u32 idx = find_leveled(w, 1, lev, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
+      u32 r_sym = rank_sym(w, counts, sym);
+      if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
+      ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;  // update_ctx_r_sym, dna.cpp:664-671
+    } else {
+      code_letter(w, i, sym, size);
+      ctx_r_sym = (ctx_r_sym << 1) & 0xff;
+    }
+    w.ctx_letters = (w.ctx_letters << 4) + sym;
+    if (sym == 4) ++w.N_run; else w.N_run = 0;
+    km_replace_last(w.pm, sym_k); km_replace_last(w.sm_, sym_k); km_replace_last(w.bm, sym_k);
+    km_replace_last(w.pm_u, sym_k); km_replace_last(w.sm_u, sym_k); km_replace_last(w.bm_u, sym_k);
+    if (sym < 4) {
+      bool pmer_insert = true;
+      if (km_full(w.bm, cfg->gb)) {
+        push_b_local(w);
+        if ((level == LV_SMER || level == LV_BMER || level == LV_MIXED || level == LV_BMER_UNC) && c4_get(counts, sym) >= 3) pmer_insert = false;
+      }
+      if (km_full(w.sm_, cfg->gs)) {
+        u64 x = km_norm(w.sm_, cfg->gs);
+        mail_push(w, MAIL_S, sb_owner(cfg, x), x);
+        tab_insert_uniform(w, cfg->l_s, w.tid, x, RNG_LS, CINC_S);
+        w.st[ST_LINS] += 1;
+      }
+      if (km_full(w.pm, cfg->gp) && i - w.cor_pos >= cfg->pmer - 1) {
+        if (pmer_insert) push_p_both(w); else w.hidden += 2;
+      }
+    }
+    if (km_full(w.bm, cfg->gb)) {
+      bool rep = false;
+      if (level == LV_BMER || level == LV_MIXED || level == LV_BMER_UNC) rep = repair_existing(w, i, counts, sym);
+      else if (level == LV_NONE || level == LV_PMER) rep = repair_missing(w, i);
+      if (rep) push_b_local(w);
+    }
+  }
+}
+
+// CompressDirect / CompressSorted, dna.cpp:1517-1556,1716-1754.  `prev` is the previous read of
+// this worker inside the block (read_prev is cleared per block, application.cpp:624), or null.
+FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev_size) {
+  const DevCfg *cfg = w.cfg;
+  WgShared *sm = w.sm;
+  const bool orig = cfg->mode == 0;
+  // duplicate test + staging of the read's codes in LDS + letter histogram, all lane-parallel
+  bool diff = prev == nullptr || prev_size != size;
+  u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+  FQ_SYNC();
+  for (u32 i = FQ_LANE; i < size; i += FQ_WAVE) {
+    u8 ch = p[i];
+    if (!diff && prev[i] != ch) diff = true;
+    u32 c = dna_code(ch);
+    if (i < FQSX_RD_LDS) sm->rd[i] = (u8)c;
+    h0 += c == 0; h1 += c == 1; h2 += c == 2; h3 += c == 3;
+  }
+  FQ_SYNC();
+  bool same = !wave_any(diff);
+  if (prev == nullptr || prev_size != size) same = false;
+  {
+    u16 *m = small_base(w) + SM_OFF_FLAGS + w.ws->ctx_flags * (SM_FLAGS_N + 1);
+    sm_encode(w, m, SM_FLAGS_N, 1u << 12, same ? 1u : 0u);
+    w.ws->ctx_flags = ((w.ws->ctx_flags << 1) + (same ? 1u : 0u)) & 0xff;
+  }
+  if (same) return;
+  km_reset(w.pm); km_reset(w.sm_); km_reset(w.bm);
+  km_reset(w.pm_u); km_reset(w.sm_u); km_reset(w.bm_u);
+  w.cor_pos = 0;
+  w.N_run = 0;
+  if (orig) prefix_direct(w, p, size); else prefix_sorted(w, p, size);
+  suffix(w, p, size, orig);
+  // update_s_letters, dna.cpp:2047-2057 (both strands)
+  h0 = wave_sum32(h0); h1 = wave_sum32(h1); h2 = wave_sum32(h2); h3 = wave_sum32(h3);
+  w.s_let[0] += h0 + h3; w.s_let[3] += h0 + h3;
+  w.s_let[1] += h1 + h2; w.s_let[2] += h1 + h2;
+  w.st[ST_BASES] += size;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel bodies
+
+// worker `tid` codes its reads of segment `seg` (application.cpp:610-656)
+FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg) {
+  Wk w;
+  w.cfg = &cfg;
+  w.sm = sm;
+  w.tid = tid;
+  WState *ws = cfg.ws + tid;
+  w.ws = ws;
+  w.err = 0;
+  for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
+  const u64 T = cfg.T;
+  // PartitionForWorkers, reads_block.h:197-214
+  u64 first = (u64)tid * n_reads / T, last = ((u64)tid + 1) * n_reads / T;
+  if (tid) first &= ~1ull;
+  if (tid + 1 < T) last &= ~1ull;
+  if (seg == 0) {  // application.cpp:624-628
+    ws->cursor = (u32)first;
+    ws->rc_low = 0;
+    ws->rc_range = 0xff00000000000000ULL;
+    ws->out_len = 0;
+  }
+  u64 stop = seg < S ? ((u64)seg + 1) * (last - first) / ((u64)S + 1) + first + 1 : last;
+  if (stop > last) stop = last;
+  // load state
+  FQ_SYNC();
+  for (u32 g = 0; g < 4; ++g) {
+    for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) sm->mt[g][i] = ws->mt[g][i];
+    if (FQ_LANE == 0) sm->mt_idx[g] = ws->mt_idx[g];
+  }
+  for (u32 k = 0; k < 3; ++k) {
+    for (u32 i = FQ_LANE; i < 256; i += FQ_WAVE) { sm->mail_count[k][i] = 0; sm->mail_tail[k][i] = 0; }
+    if (FQ_LANE == 0) sm->mail_nchunks[k] = 0;
+  }
+  FQ_SYNC();
+  w.enc.low = ws->rc_low; w.enc.range = ws->rc_range; w.enc.len = ws->out_len;
+  w.enc.cap = cfg.out_cap; w.enc.out = cfg.out + (u64)tid * cfg.out_cap;
+  w.avg_code = ws->avg_code; w.avg_letters = ws->avg_letters;
+  for (u32 i = 0; i < 4; ++i) w.s_let[i] = ws->s_letters[i];
+  w.hidden = ws->hidden_updates;
+  w.ctx_letters = 0; w.cor_pos = 0; w.N_run = 0;
+  km_reset(w.pm); km_reset(w.sm_); km_reset(w.bm); km_reset(w.pm_u); km_reset(w.sm_u); km_reset(w.bm_u);
+
+  u64 cur = ws->cursor;
+  for (u64 i = cur; i < stop && !w.err; ++i) {
+    u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
+    const u8 *prev = nullptr;
+    u32 prev_size = 0;
+    if (i > first) {
+      u64 q0 = cfg.read_off[i - 1];
+      prev = cfg.bases + q0;
+      prev_size = (u32)(o0 - q0);
+    }
+    compress_read(w, cfg.bases + o0, (u32)(o1 - o0), prev, prev_size);
+  }
+  if (stop > cur) cur = stop;
+
+  // store state
+  ws->cursor = (u32)cur;
+  ws->rc_low = w.enc.low; ws->rc_range = w.enc.range; ws->out_len = w.enc.len;
+  ws->avg_code = w.avg_code; ws->avg_letters = w.avg_letters;
+  for (u32 i = 0; i < 4; ++i) ws->s_letters[i] = w.s_let[i];
+  ws->hidden_updates = w.hidden;
+  for (u32 i = 0; i < ST_N; ++i) ws->stat[i] += w.st[i];
+  FQ_SYNC();
+  for (u32 g = 0; g < 4; ++g) {
+    for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) ws->mt[g][i] = sm->mt[g][i];
+    ws->mt_idx[g] = sm->mt_idx[g];
+  }
+  for (u32 k = 0; k < 3; ++k)
+    for (u32 i = FQ_LANE; i < T; i += FQ_WAVE) cfg.mail[k].count[(u64)tid * T + i] = sm->mail_count[k][i];
+  if (w.err) *cfg.err = w.err;
+}
+
+// lane-parallel insert of one mailbox chunk (<= 64 keys, all owned by `tid`) into a global
+// sub-table, RNG draws assigned in key order (InsertKmersToHT, dna.cpp:2426-2446; insert(),
+// ht_kmer.h:420-438).  Falls back to a serial pass when two keys of the batch interact.
+FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 tid, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
+                         u64 &nslots, u32 &err) {
+  u64 *s = t.slots + (u64)tid * t.stride;
+  const u64 cm = (1ull << t.cbits) - 1ull;
+  const u32 lane = FQ_LANE;
+  u64 v = 0, pos = 0, item = 0;
+  bool act = lane < n, found = false;
+  if (act) {
+    v = keys[lane] >> (64 - 2 * t.k);
+    u64 p = tab_home(t, v);
+    for (u64 q = 0; q <= t.cap_mask; ++q) {
+      u64 it = s[p];
+      ++nslots;
+      if (!it) break;
+      if ((it >> t.cbits) == v) { found = true; item = it; break; }
+      p = (p + 1) & t.cap_mask;
+    }
+    pos = p;
+  }
+  // interaction test: two active lanes targeting the same slot (same key, or two new keys
+  // racing for one empty slot); a new key can also extend a cluster another lane scanned, but
+  // that lane then targets a different slot and stays correct
+  FQ_SYNC();
+  sm->bk_key[lane] = act ? pos : ~0ull;
+  FQ_SYNC();
+  bool clash = false;
+#if FQ_WAVE > 1
+  if (act)
+    for (u32 j = 0; j < n; ++j)
+      if (j != lane && sm->bk_key[j] == pos) clash = true;
+#endif
+  u32 filled = t.filled[tid];
+  u32 n_new = popc64(wave_ballot(act && !found));
+  if ((u64)(filled + n_new) * 10 >= (t.cap_mask + 1) * 9) { err = FQSX_ERR_GTAB_FULL; return; }
+  if (!wave_any(clash)) {
+    u32 cnt = (u32)(item & cm);
+    bool draw = act && found && cnt > ci.thr && cnt < ci.maxv;
+    u64 dm = wave_ballot(draw);
+    u32 my = popc64(dm & ((1ull << lane) - 1ull)), total = popc64(dm);
+    u32 idx = sm->mt_idx[rng];
+    u32 avail = idx >= 624 ? 0 : 624 - idx;
+    u32 r = 0;
+    if (draw && my < avail) r = mt_temper(sm->mt[rng][idx + my]);
+    if (total > avail) {
+      mt_twist(sm->mt[rng]);
+      if (draw && my >= avail) r = mt_temper(sm->mt[rng][my - avail]);
+      idx = total - avail;
+    } else
+      idx += total;
+    FQ_SYNC();
+    if (lane == 0) sm->mt_idx[rng] = idx;
+    FQ_SYNC();
+    if (act) {
+      if (!found) s[pos] = (v << t.cbits) | 1ull;
+      else if (cnt <= ci.thr) { if (cnt < (u32)cm) s[pos] = item + 1; }
+      else if (draw && (r % (ci.mult * (cnt - ci.thr)) == 0)) s[pos] = item + 1;
+    }
+    if (lane == 0) t.filled[tid] = filled + n_new;
+    FQ_SYNC();
+    return;
+  }
+  // serial fallback, in key order
+  FQ_SYNC();
+  for (u32 j = 0; j < n; ++j) {
+    u64 vj = keys[j] >> (64 - 2 * t.k);
+    u64 p = tab_home(t, vj);
+    for (u64 q = 0; q <= t.cap_mask; ++q) {
+      u64 it = s[p];
+      if (!it) {
+        s[p] = (vj << t.cbits) | 1ull;
+        t.filled[tid] = t.filled[tid] + 1;
+        break;
+      }
+      if ((it >> t.cbits) == vj) {
+        u32 cnt = (u32)(it & cm);
+        if (cnt < (u32)cm && cinc_inc1(sm, rng, ci, cnt) != cnt) s[p] = it + 1;
+        break;
+      }
+      p = (p + 1) & t.cap_mask;
+    }
+    FQ_SYNC();
+  }
+}
+
+// owner `tid` applies column `tid` of every mailbox (InsertKmersToHT, dna.cpp:2393-2472)
+FQ_DEV void insert_phase_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
+  WState *ws = cfg.ws + tid;
+  const u32 T = cfg.T;
+  u32 err = 0;
+  u64 n_words = 0, n_ins = 0, n_slots = 0;
+  FQ_SYNC();
+  for (u32 g = RNG_B; g <= RNG_S; ++g) {
+    for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) sm->mt[g][i] = ws->mt[g][i];
+    if (FQ_LANE == 0) sm->mt_idx[g] = ws->mt_idx[g];
+  }
+  FQ_SYNC();
+  // p-mers: saturating 2-bit increments; order-free, so lanes update concurrently with CAS
+  {
+    const Mail &m = cfg.mail[MAIL_P];
+    u64 nf = 0, nu = 0;
+    for (u32 src = 0; src < T; ++src) {
+      u32 cnt = m.count[(u64)src * T + tid];
+      u32 chunk = cnt ? m.head[(u64)src * T + tid] : FQSX_NIL;
+      for (u32 done = 0; done < cnt; done += FQSX_CHUNK) {
+        u32 n = cnt - done < FQSX_CHUNK ? cnt - done : FQSX_CHUNK;
+        const u64 *keys = m.pool + ((u64)src * m.pool_chunks + chunk) * FQSX_CHUNK;
+        for (u32 i = FQ_LANE; i < n; i += FQ_WAVE) {
+          u64 idx = keys[i];
+          u64 *wp = cfg.siv + (idx >> 5);
+          u32 sh = 2 * (u32)(idx & 31);
+          u64 old = *wp;
+          for (;;) {  // increment(), bit_vec.h:53-67
+            u64 f = (old >> sh) & 3;
+            if (f == 3) break;
+            u64 seen = atomic_cas64(wp, old, old + (1ull << sh));
+            if (seen == old) { nf += f == 0; break; }
+            old = seen;
+          }
+          ++nu;
+        }
+        n_words += n;
+        chunk = m.next[(u64)src * m.pool_chunks + chunk];
+      }
+    }
+    nf = wave_sum64(nf);
+    nu = wave_sum64(nu);
+    if (FQ_LANE == 0) {  // update_no_filled / update_no_updates, dna.cpp:2416-2418 (atomics, bit_vec.h:25-26)
+#ifndef FQSX_EMU
+      atomicAdd((unsigned long long *)&cfg.siv_stats[1], (unsigned long long)nf);
+      atomicAdd((unsigned long long *)&cfg.siv_stats[0], (unsigned long long)(nu + ws->hidden_updates));
+#else
+      cfg.siv_stats[1] += nf;
+      cfg.siv_stats[0] += nu + ws->hidden_updates;
+#endif
+    }
+    FQ_SYNC();
+    ws->hidden_updates = 0;
+  }
+  // s-mers then b-mers
+  for (u32 kind = MAIL_S; kind <= MAIL_B; ++kind) {
+    const Mail &m = cfg.mail[kind];
+    const KTab &t = kind == MAIL_S ? cfg.g_s : cfg.g_b;
+    const u32 rng = kind == MAIL_S ? RNG_S : RNG_B;
+    const Cinc ci = kind == MAIL_S ? CINC_S : CINC_B;
+    for (u32 src = 0; src < T && !err; ++src) {
+      u32 cnt = m.count[(u64)src * T + tid];
+      u32 chunk = cnt ? m.head[(u64)src * T + tid] : FQSX_NIL;
+      for (u32 done = 0; done < cnt && !err; done += FQSX_CHUNK) {
+        u32 n = cnt - done < FQSX_CHUNK ? cnt - done : FQSX_CHUNK;
+        const u64 *keys = m.pool + ((u64)src * m.pool_chunks + chunk) * FQSX_CHUNK;
+#if FQ_WAVE > 1
+        insert_batch(cfg, sm, t, tid, keys, n, rng, ci, n_slots, err);
+#else
+        for (u32 j = 0; j < n && !err; ++j) insert_batch(cfg, sm, t, tid, keys + j, 1, rng, ci, n_slots, err);
+#endif
+        n_ins += n;
+        chunk = m.next[(u64)src * m.pool_chunks + chunk];
+      }
+    }
+  }
+  FQ_SYNC();
+  for (u32 g = RNG_B; g <= RNG_S; ++g) {
+    for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) ws->mt[g][i] = sm->mt[g][i];
+    ws->mt_idx[g] = sm->mt_idx[g];
+  }
+  ws->stat[ST_GINS] += n_ins;
+  ws->stat[ST_GINS_SLOT] += wave_sum64(n_slots);
+  ws->stat[ST_SIV_WORDS] += n_words;
+  if (err) *cfg.err = err;
+}
+
+// End() of the block's range coder: 8 flush bytes (sub_rc.h:79-86, application.cpp:664-665)
+FQ_DEV void finish_block_body(const DevCfg &cfg, u32 tid) {
+  WState *ws = cfg.ws + tid;
+  u64 low = ws->rc_low, len = ws->out_len;
+  u8 *out = cfg.out + (u64)tid * cfg.out_cap;
+  for (int i = 0; i < 8; ++i) {
+    if (len < cfg.out_cap) out[len] = (u8)(low >> 56); else *cfg.err = FQSX_ERR_OUT_OVERFLOW;
+    ++len;
+    low <<= 8;
+  }
+  ws->rc_low = low;
+  ws->out_len = len;
+}

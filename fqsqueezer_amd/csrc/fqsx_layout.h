@@ -1,0 +1,138 @@
+// fqsx_layout.h -- HBM data layout of the FQSX DNA codec (shared by host and device code).
+//
+// All state is flat and pointer-free inside the slots so that it can be sharded by owner
+// worker across GPUs.  Reference structures each array replaces (paths relative to
+// /root/reference/fqs):
+//   siv            TSmallIntVector<2>                      bit_vec.h:17-231
+//   gs_slots/gb_*  CHT_kmer<uint32_t> ht_smer / ht_bmer     ht_kmer.h:29-554, application.cpp:86-89
+//   ls_/lb_slots   CHT_kmer<uint64_t> ht_*_local            dna.cpp:97-103
+//   ctx            CContextHM<...,5> m_ctx_rc_codes/letters context_hm.h:21-248
+//   small models   the six low-cardinality CContextHM maps  dna.h:49-56
+//   mail           *_to_add[src][dst] mailboxes             application.h:56-59
+#pragma once
+#include "fqsx_plat.h"
+
+#define FQSX_MAX_T 255
+#define FQSX_CHUNK 64u           // mailbox chunk = one wave batch (64 x u64 = 512 B)
+#define FQSX_NIL 0xffffffffu
+#define FQSX_RD_LDS 4096u        // reads up to this length are staged in LDS
+
+// geometry of one rolling k-mer (kmer.h:279-298)
+struct KGeom {
+  u32 k, shift;
+  u64 mask, kernel_mask;
+};
+
+// One open-addressed table of normalised k-mers: slot = (kmer_right_aligned << cbits) | count,
+// 0 = empty.  Home position = murmur64(kernel) & cap_mask where kernel = symbols 2..k-3, so
+// the 4 (direct) or 4 (rc) sibling k-mers of a look-up sit in one probe cluster
+// (cf. ht_kmer.h:115-130,143-156).  `stride` separates the per-owner sub-tables.
+struct KTab {
+  u64 *slots;
+  u64 cap_mask;   // capacity-1 of every sub-table
+  u64 stride;     // slots between consecutive sub-tables (>= capacity)
+  u32 *filled;    // [n_sub] occupied slots
+  u32 k, cbits;
+};
+
+// Context slot (32 B): adaptive 5-symbol model + visit counter, keyed by (tag,key).
+// tag 0 = empty, 1 = rank-code contexts (m_ctx_rc_codes), 2 = letter contexts (m_ctx_rc_letters)
+struct CtxSlot {
+  u64 key;
+  u32 counter;
+  u16 tag;
+  u16 total;
+  u16 st[5];
+  u16 pad[3];
+};
+
+// Mailbox of one kind (p-, s- or b-mers): per source worker a pool of 64-entry chunks,
+// chained per destination owner in push order.
+struct Mail {
+  u64 *pool;        // [T][pool_chunks*64]
+  u32 *next;        // [T][pool_chunks]   chunk -> next chunk of the same (src,dst) chain
+  u32 *head;        // [T src][T dst]     first chunk or NIL
+  u32 *count;       // [T src][T dst]     entries pushed
+  u32 pool_chunks;  // per source
+};
+enum { MAIL_P = 0, MAIL_S = 1, MAIL_B = 2 };
+
+// offsets (in u16 units) of the small direct-indexed models inside a worker's model block
+// every model = N stats followed by its total
+#define SM_FLAGS_N 2u       /* m_ctx_rc_flags: key = 8-bit duplicate-flag history */
+#define SM_NS_N 2u          /* m_ctx_rc_prefix_Ns: key = 0 or position+1 */
+#define SM_PSF_N 5u         /* m_ctx_rc_prefix_sorted_flags: key = 16-bit history */
+#define SM_NIB_N 16u
+#define SM_BYTE_N 256u
+#define SM_OFF_FLAGS 0u
+#define SM_OFF_NS (SM_OFF_FLAGS + 256u * (SM_FLAGS_N + 1u))
+#define SM_OFF_PSF (SM_OFF_NS + 32u * (SM_NS_N + 1u))
+#define SM_OFF_PSNB (SM_OFF_PSF + 65536u * (SM_PSF_N + 1u))
+#define SM_OFF_NIB (SM_OFF_PSNB + 65536u * (5u + 1u))
+#define SM_OFF_BYTE (SM_OFF_NIB + 68u * (SM_NIB_N + 1u))
+#define SM_BYTE_ENTRIES (16u + 16384u)
+#define SM_TOTAL_U16 (SM_OFF_BYTE + SM_BYTE_ENTRIES * (SM_BYTE_N + 1u))
+
+// per-worker persistent state (dna.cpp:148-171 and the encoder objects of application.cpp:580-584)
+struct WState {
+  double avg_code, avg_letters;        // dna.h:34,37
+  u64 ctx_flags, ctx_ps_flags;         // dna.h:84,87
+  u64 s_letters[4];                    // dna.h:119
+  u64 pmer_prev_dir;                   // pmer_can_prev (dna.h:166); cur is 0 or pmer_len
+  u32 pmer_prev_cur;
+  u32 cursor;                          // next read of the block this worker codes
+  u64 hidden_updates;                  // no_pmer_hidden_updates, dna.h:43
+  u64 rc_low, rc_range;                // CRangeEncoder, sub_rc.h:44-45
+  u64 out_len;
+  u32 mt_idx[4];                       // cinc_b, cinc_s, cinc_lb, cinc_ls (dna.h:113-116)
+  u32 mt[4][624];
+  u64 stat[16];                        // probe/byte accounting, see ST_*
+};
+enum { RNG_B = 0, RNG_S = 1, RNG_LB = 2, RNG_LS = 3 };
+enum {
+  ST_GPROBE = 0,   // global table cluster scans
+  ST_GSLOT,        // slots read by them
+  ST_LPROBE,       // local table scans
+  ST_LSLOT,
+  ST_GINS,         // global inserts
+  ST_GINS_SLOT,
+  ST_SIV_WORDS,    // siv 64-bit words read or updated
+  ST_CTX,          // context slots read
+  ST_CODED,        // symbols range-coded
+  ST_LINS,         // local inserts
+  ST_MAIL,         // mailbox entries pushed
+  ST_BASES,        // input bases consumed
+  ST_N
+};
+
+struct DevCfg {
+  u32 T, mode;                 // mode 0 = original order, 1 = sorted (params.h:18)
+  u32 prefix, pmer, smer, bmer;
+  KGeom gp, gs, gb;
+  u32 pmer_mod_shift;          // dna.cpp:2381
+  u32 ps_nobytes_n;            // alphabet of prefix_sorted_no_bytes, dna.cpp:130
+  u64 *siv;                    // 4^pmer 2-bit counters
+  u64 *siv_stats;              // [0] no_updates [1] no_filled (bit_vec.h:25-26)
+  KTab g_s, g_b;               // owner-sharded global tables (T sub-tables)
+  KTab l_s, l_b;               // per-worker local tables (T sub-tables)
+  CtxSlot *ctx;                // [T][ctx_cap]
+  u64 ctx_cap_mask;
+  u32 *ctx_filled;             // [T]
+  u16 *small;                  // [T][SM_TOTAL_U16]
+  u8 *byte_init;               // [T][SM_BYTE_ENTRIES] lazy-init flags of the 256-symbol models
+  WState *ws;                  // [T]
+  Mail mail[3];
+  const u8 *bases;             // block input: concatenated ASCII reads
+  const u64 *read_off;         // n_reads+1
+  u8 *out;                     // [T][out_cap] DNA streams of the block
+  u64 out_cap;
+  u32 *err;                    // device error word (0 = ok)
+};
+
+enum {
+  FQSX_ERR_OUT_OVERFLOW = 1,
+  FQSX_ERR_GTAB_FULL = 2,
+  FQSX_ERR_LTAB_FULL = 3,
+  FQSX_ERR_CTX_FULL = 4,
+  FQSX_ERR_MAIL_FULL = 5,
+};

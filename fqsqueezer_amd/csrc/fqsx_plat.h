@@ -1,0 +1,96 @@
+// fqsx_plat.h -- wavefront primitives used by the FQSX device code.
+//
+// The device code is written "wave-uniform": one 64-lane wavefront (= one workgroup) is
+// one logical FQSqueezer worker.  Control flow and the coder state are identical in all
+// lanes; the lanes diverge only inside batch primitives (k-mer probe batches, p-mer
+// vector sweeps, 256-symbol model sums, mailbox insert batches), which are written as
+// strided loops `for (i = lane; i < n; i += WAVE)` followed by a wave reduction.
+//
+// FQSX_EMU builds the same sources for a 1-lane "wave" on the host.  That build exists
+// only so the kernels can be debugged in the GPU-less development container
+// (tests/emu); it is never part of the product library, which has no CPU path.
+#pragma once
+#include <stdint.h>
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+typedef int32_t i32;
+
+#ifndef FQSX_EMU
+#include <hip/hip_runtime.h>
+#define FQ_DEV __device__ __forceinline__
+#define FQ_DEVN __device__ __noinline__
+#define FQ_KERNEL extern "C" __global__
+#define FQ_KERNEL64 extern "C" __global__ __launch_bounds__(64)
+#define FQ_WAVE 64
+#define FQ_LANE ((u32)(threadIdx.x & 63u))
+#define FQ_BLOCK ((u32)blockIdx.x)
+#define FQ_NBLOCKS ((u32)gridDim.x)
+#define FQ_SHARED __shared__
+// single-wave workgroups: a workgroup barrier orders LDS/global traffic between lanes
+#define FQ_SYNC() __syncthreads()
+
+FQ_DEV u32 wave_sum32(u32 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+FQ_DEV u64 wave_sum64(u64 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+FQ_DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
+FQ_DEV bool wave_all(bool p) { return __ballot(p) == __ballot(true); }
+FQ_DEV u64 wave_ballot(bool p) { return __ballot(p); }
+FQ_DEV u32 wave_bcast32(u32 v, u32 lane) { return __shfl(v, (int)lane, 64); }
+FQ_DEV u64 wave_bcast64(u64 v, u32 lane) { return __shfl(v, (int)lane, 64); }
+FQ_DEV u32 uniform32(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+FQ_DEV u64 uniform64(u64 v) {
+  u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+  return ((u64)hi << 32) | lo;
+}
+FQ_DEV u32 popc64(u64 v) { return (u32)__popcll(v); }
+FQ_DEV u64 atomic_cas64(u64 *p, u64 expect, u64 desired) {
+  return (u64)atomicCAS((unsigned long long *)p, (unsigned long long)expect, (unsigned long long)desired);
+}
+// IEEE double multiply/add with no FMA contraction (reference dna.h:100-102 is built
+// without -mfma): avg = 0.999*avg + (1-0.999)*level
+FQ_DEV double ema_update(double avg, double level) { return __dadd_rn(__dmul_rn(0.999, avg), __dmul_rn(1.0 - 0.999, level)); }
+
+#else  // ---------------------------------------------------------------- host emulation
+#include <string.h>
+#define FQ_DEV static inline
+#define FQ_DEVN static
+#define FQ_KERNEL static
+#define FQ_KERNEL64 static
+#define FQ_WAVE 1
+#define FQ_LANE 0u
+#define FQ_BLOCK (fq_emu_block)
+#define FQ_NBLOCKS (fq_emu_nblocks)
+#define FQ_SHARED static thread_local
+#define FQ_SYNC() ((void)0)
+static thread_local u32 fq_emu_block = 0, fq_emu_nblocks = 1;
+FQ_DEV u32 wave_sum32(u32 v) { return v; }
+FQ_DEV u64 wave_sum64(u64 v) { return v; }
+FQ_DEV bool wave_any(bool p) { return p; }
+FQ_DEV bool wave_all(bool p) { return p; }
+FQ_DEV u64 wave_ballot(bool p) { return p ? 1ull : 0ull; }
+FQ_DEV u32 wave_bcast32(u32 v, u32) { return v; }
+FQ_DEV u64 wave_bcast64(u64 v, u32) { return v; }
+FQ_DEV u32 uniform32(u32 v) { return v; }
+FQ_DEV u64 uniform64(u64 v) { return v; }
+FQ_DEV u32 popc64(u64 v) { return (u32)__builtin_popcountll(v); }
+FQ_DEV u64 atomic_cas64(u64 *p, u64 expect, u64 desired) {
+  u64 old = *p;
+  if (old == expect) *p = desired;
+  return old;
+}
+FQ_DEV double ema_update(double avg, double level) {
+  volatile double a = 0.999 * avg;
+  volatile double b = (1.0 - 0.999) * level;
+  return a + b;
+}
+#endif

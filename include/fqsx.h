@@ -1,0 +1,84 @@
+/* fqsx.h -- C ABI of the MI355X-native FQSqueezer DNA path (libfqsx.so).
+ *
+ * The reference (refresh-bio/fqsqueezer v1.1) has no plugin/FFI surface; the narrowest
+ * seam its DNA hot path sits behind is the public interface of CDNACompressor as driven by
+ * the worker lambda of CApplication::compress_se_files.  This ABI replaces that seam at
+ * *reads-block* granularity:
+ *
+ *   fqsx_dna_create        <- CDNACompressor::SetParams/SetCoder/Init/SetKmerDS for all T
+ *                             workers + CApplication::AdjustToParams
+ *                             (fqs/compressor.h:42-43, fqs/dna.h:263-269,
+ *                              fqs/application.cpp:77-108, :578-608)
+ *   fqsx_dna_encode_block  <- one iteration of the worker loop for all T workers:
+ *                             ResetReadPrev, Start, CompressDirect|CompressSorted per read,
+ *                             the barrier-synchronised InsertKmersToHT/ClearKmersToHT
+ *                             phases, End  (fqs/application.cpp:610-669, fqs/dna.h:271-285)
+ *   fqsx_dna_destroy       <- ~CDNACompressor / ~CApplication
+ *
+ * The library is HIP-only: it fails with FQSX_E_NO_DEVICE when no gfx950 GPU is present.
+ * There is no CPU code path behind this ABI.
+ *
+ * Threading: one fqsx_dna per output file, calls serialised by the caller, blocks in file
+ * order (models persist across blocks exactly like the reference's per-thread compressors).
+ */
+#ifndef FQSX_H
+#define FQSX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fqsx_dna fqsx_dna;
+
+enum {
+  FQSX_OK = 0,
+  FQSX_E_ARG = -1,        /* bad argument / malformed header / unsupported dna_mode */
+  FQSX_E_NO_DEVICE = -2,  /* no HIP device (the library has no CPU fallback) */
+  FQSX_E_HIP = -3,        /* HIP runtime error, see fqsx_last_error() */
+  FQSX_E_NOMEM = -4,      /* device allocation failed */
+  FQSX_E_DEVICE = -5      /* device-side error word set (table/stream overflow) */
+};
+
+/* header17: the 17 parameter bytes of the .fqs file being written
+ * ('K','C','S','D', no_threads T, dna_mode, quality_mode, id_mode, quality_thr,
+ *  duplicates_check, prefix_len, pmer_len, smer_len, bmer_len, imer_len, hmer_len,
+ *  ht_prefix_len; fqs/params.h:80-100).  T is the number of logical workers and is part of
+ * the bitstream.  dna_mode 0 (se_original) and 1 (se_sorted) are implemented.
+ * device: HIP device ordinal. */
+int fqsx_dna_create(const uint8_t *header17, int device, fqsx_dna **out);
+void fqsx_dna_destroy(fqsx_dna *);
+
+/* Encode one reads block.  bases = concatenated ASCII sequences (ACGTN) of the block's
+ * reads in block order, read_off = n_reads+1 byte offsets into bases (host memory).
+ * generation = index of the block within the file (drives the synchronisation schedule,
+ * fqs/application.h:85-92).  On return streams[w]/lens[w] (w < T) describe worker w's
+ * complete DNA range-coder stream for this block in host memory owned by the codec and
+ * valid until the next call on the same codec. */
+int fqsx_dna_encode_block(fqsx_dna *, const uint8_t *bases, const uint64_t *read_off, uint32_t n_reads,
+                          uint32_t generation, const uint8_t **streams, uint64_t *lens);
+
+/* Same with the block already resident in device memory (HBM): d_bases / d_read_off are
+ * device pointers; h_read_off is the host copy of the offsets (needed for sizing). */
+int fqsx_dna_encode_block_dev(fqsx_dna *, const uint8_t *d_bases, const uint64_t *d_read_off,
+                              const uint64_t *h_read_off, uint32_t n_reads, uint32_t generation,
+                              const uint8_t **streams, uint64_t *lens);
+
+/* Accounting counters summed over workers since creation:
+ * [0] global probes [1] global slots read [2] local probes [3] local slots read
+ * [4] global inserts [5] slots read by them [6] siv words touched [7] context slots read
+ * [8] symbols range-coded [9] local inserts [10] mailbox entries [11] input bases */
+int fqsx_dna_stats(fqsx_dna *, uint64_t out[16]);
+
+/* Kernel timing: when enabled every launch is bracketed by HIP events on the codec's stream.
+ * out[0..2] = accumulated milliseconds of the encode-segment, insert-phase and all other
+ * kernels; out[3..5] = their launch counts. */
+int fqsx_dna_set_profiling(fqsx_dna *, int enable);
+int fqsx_dna_kernel_times(fqsx_dna *, double out[6]);
+
+const char *fqsx_last_error(void);
+const char *fqsx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
