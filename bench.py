@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the FQSX DNA hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 1 M x 100 bp synthetic single-end reads, 20x coverage of a
+5 Mbp random genome (seed 2), `-om s` (sorted), `-gs 5`, T logical workers (default 64 =
+the reference CLI's maximum; T is part of the .fqs bitstream).  One *step* = one pass of the
+DNA path over the whole file: fresh codec state, every reads block encoded in file order, the
+per-worker range-coder streams copied back to the host.  Inputs (base bytes + read offsets of
+every block) are resident in HBM before the timed region starts.
+
+N > 1 (torch.distributed.run): every rank compresses its own independent file (seed 2+rank)
+on its own GPU -- weak scaling, no data-path collective (see DESIGN.md "Multi-GPU").
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def algorithmic_bytes(st: dict) -> float:
+    """B = sum_probes(24+4*slots) + sum_global_inserts(24+4*slots+4) + 8*siv_words
+    + 24*ctx_slots + 2*40*models_updated   (reference structure sizes; data-dependent counters)."""
+    probes = st["gprobe"] + st["lprobe"]
+    slots = st["gslot"] + st["lslot"]
+    return (24.0 * probes + 4.0 * slots + 28.0 * st["gins"] + 4.0 * st["gins_slot"] + 8.0 * st["siv_words"]
+            + 24.0 * st["ctx_slots"] + 80.0 * st["coded"])
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=1_000_000)
+    ap.add_argument("--len", type=int, default=100)
+    ap.add_argument("--genome", type=int, default=5_000_000)
+    ap.add_argument("--gs", type=int, default=5)
+    ap.add_argument("--threads", type=int, default=64, help="logical workers T (header byte, <=255)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.codec import DnaCodec
+    from fqsqueezer_amd.synth import read_id, synth_quals, synth_reads
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the FQSX DNA path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic input, host preparation (not timed): binning + sort + block formation
+    seed = 2 + rank
+    reads = synth_reads(a.reads, a.len, a.genome, seed)
+    rec = hp.Records([read_id(i) for i in range(a.reads)], reads, synth_quals(a.reads, a.len, seed))
+    header = hp.make_header(a.threads, "se_sorted", a.gs)
+    blocks = hp.form_blocks(rec, "se_sorted")
+    dev_blocks = []
+    for idx in blocks:
+        bases, off = hp.block_arrays(rec, idx)
+        d_b = torch.from_numpy(np.ascontiguousarray(bases)).cuda()
+        d_o = torch.from_numpy(off.view(np.int64)).cuda()
+        dev_blocks.append((d_b, d_o, off))
+    n_bases = int(a.reads) * int(a.len)
+    torch.cuda.synchronize()
+
+    def one_step(profile: bool = False):
+        codec = DnaCodec(header, device=local_rank)
+        if profile:
+            codec.set_profiling(True)
+        out_bytes = 0
+        for g, (d_b, d_o, off) in enumerate(dev_blocks):
+            out_bytes += codec.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g, collect=False)
+        res = (out_bytes, codec.stats() if profile else None, codec.kernel_times() if profile else None)
+        codec.close()
+        return res
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    dna_bytes = 0
+    for _ in range(a.steps):
+        dna_bytes, _, _ = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = world * n_bases * a.steps / elapsed / 1e6
+
+    # ---- kernel-level measurement pass (HIP events around every launch on the codec's stream; untimed)
+    _, st, kt = one_step(profile=True)
+    alg = algorithmic_bytes(st)
+    enc_s, ins_s = kt["encode_ms"] / 1e3, kt["insert_ms"] / 1e3
+    dominant = "k_encode_segment" if enc_s >= ins_s else "k_insert_phase"
+    dom_s = max(enc_s, ins_s)
+    dom_launches = kt["encode_launches"] if enc_s >= ins_s else kt["insert_launches"]
+    # bytes attributable to the dominant kernel
+    ins_bytes = 28.0 * st["gins"] + 4.0 * st["gins_slot"]
+    dom_bytes = alg - ins_bytes if dominant == "k_encode_segment" else ins_bytes
+    achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 6), "traffic": None, "kernel": dominant,
+                "launches": dom_launches, "avg_launch_ms": round(dom_s * 1e3 / max(1, dom_launches), 4),
+                "algorithmic_bytes_per_launch": round(dom_bytes / max(1, dom_launches), 1),
+                "encode_kernel_s": round(enc_s, 4), "insert_kernel_s": round(ins_s, 4),
+                "probes_per_s": round((st["gprobe"] + st["lprobe"]) / max(enc_s, 1e-9), 1)}
+
+    # ---- CPU baseline on a bounded sample of the same workload (rank 0, N=1 only)
+    cpu = None
+    if not a.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(a, hp, reads, rec)
+
+    line = {
+        "metric": "Mbases/s compressed (DNA stream, SE sorted)", "value": round(value, 4), "unit": "Mbases/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2+rank), -om s -gs {a.gs} -qm n -im n",
+                   "workers_T": a.threads, "blocks": len(blocks), "per_gpu": "one independent file per GPU"},
+        "bits_per_base": round(8.0 * dna_bytes / n_bases, 5),
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, hp, reads, rec):
+    """Times the unmodified reference (oracle/_ref/fqs-1.1, built by oracle/Makefile) on the first
+    `cpu_sample_reads` reads of the same synthetic file; falls back to the oracle restatement."""
+    from fqsqueezer_amd.synth import write_fastq
+    n = min(a.cpu_sample_reads, a.reads)
+    ref = os.path.join(ROOT, "oracle", "_ref", "fqs-1.1")
+    cores = os.cpu_count() or 1
+    if os.path.exists(ref):
+        t = max(1, min(64, cores))
+        with tempfile.TemporaryDirectory(prefix="fqsx_bench_") as td:
+            fq = os.path.join(td, "s.fq")
+            write_fastq(fq, reads[:n], rec.qual[:n])
+            cmd = [ref, "e", "-s", "-om", "s", "-t", str(t), "-gs", str(a.gs), "-qm", "n", "-im", "n", "-v", "0",
+                   "-tmp", os.path.join(td, "tmp_"), "-out", os.path.join(td, "o.fqs"), fq]
+            t0 = time.perf_counter()
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+        return {"value": round(n * a.len / dt / 1e6, 4), "unit": "Mbases/s", "cores": t, "kind": "reference",
+                "sample": f"first {n} reads of the workload file, `fqs-1.1 e -s -om s -t {t} -gs {a.gs} -qm n -im n`, "
+                          f"whole-process wall {dt:.1f}s (includes its binning/sort pre-pass); host has {cores} logical CPUs"}
+    from oracle.pyoracle import OracleCodec
+    sub = hp.Records(rec.ids[:n], reads[:n], rec.qual[:n])
+    oc = OracleCodec(hp.make_header(a.threads, "se_sorted", a.gs))
+    t0 = time.perf_counter()
+    for g, idx in enumerate(hp.form_blocks(sub, "se_sorted")):
+        bases, off = hp.block_arrays(sub, idx)
+        oc.encode_block(bases, off, g)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * a.len / dt / 1e6, 4), "unit": "Mbases/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} reads, oracle restatement single-threaded, {dt:.1f}s"}
+
+
+if __name__ == "__main__":
+    main()

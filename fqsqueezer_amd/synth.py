@@ -82,3 +82,31 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     write_fastq(a.out, synth_reads(a.reads, a.len, a.genome, a.seed), seed=a.seed)
+
+
+def synth_ragged(n_reads: int, genome_len: int, seed: int, min_len: int = 30, max_len: int = 160,
+                 n_rate: float = 0.02, dup_rate: float = 0.05):
+    """Variable-length reads with N runs and exact duplicates (edge cases of the DNA path).
+    Returns (ids, seqs, quals) as lists of bytes."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    genome = _ACGT[rng.integers(0, 4, size=genome_len, dtype=np.uint8)]
+    seqs = []
+    for i in range(n_reads):
+        if seqs and rng.random() < dup_rate:
+            seqs.append(seqs[int(rng.integers(0, len(seqs)))])
+            continue
+        L = int(rng.integers(min_len, max_len + 1))
+        pos = int(rng.integers(0, genome_len - L + 1))
+        r = genome[pos:pos + L].copy()
+        if rng.random() < 0.5:
+            r = _COMP[r[::-1]]
+        u = rng.random(L)
+        r[u < 0.01] = _ACGT[rng.integers(0, 4, size=int((u < 0.01).sum()), dtype=np.uint8)]
+        if rng.random() < 0.3:                      # an N run somewhere (possibly in the prefix)
+            a = int(rng.integers(0, L))
+            r[a:a + int(rng.integers(1, 6))] = ord("N")
+        r[(u > 1.0 - n_rate)] = ord("N")
+        seqs.append(r.tobytes())
+    ids = [b"@rag.%d" % (i + 1) for i in range(n_reads)]
+    quals = [bytes([33 + int(x) for x in rng.integers(2, 41, size=len(s))]) for s in seqs]
+    return ids, seqs, quals

@@ -1,0 +1,99 @@
+import hashlib
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libfqsx_emu.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of CPU time; enabled with FQSX_SLOW=1")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("FQSX_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="set FQSX_SLOW=1 to run")
+    for it in items:
+        if "slow" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def built():
+    import __graft_entry__ as g
+    g.build_emu()
+    g.build_oracle_restate() if hasattr(g, "build_oracle_restate") else None
+    return g
+
+
+# ---- shared helpers ---------------------------------------------------------------------
+def c1_records():
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.synth import read_id, synth_quals, synth_reads
+    reads = synth_reads(10000, 100, 200000, 1)
+    return hp.Records([read_id(i) for i in range(10000)], reads, synth_quals(10000, 100, 1))
+
+
+def c4_records():
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.synth import synth_ragged
+    ids, seqs, quals = synth_ragged(3000, 60000, 4)
+    return hp.Records(ids, seqs, quals)
+
+
+def digest_records(meta):
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.synth import read_id, synth_quals, synth_reads
+    n, L = meta["reads"], meta["len"]
+    reads = synth_reads(n, L, meta["genome"], meta["seed"])
+    return hp.Records([read_id(i) for i in range(n)], reads, synth_quals(n, L, meta["seed"]))
+
+
+def check_against_fqs(make_codec, rec, fqs_name):
+    """Encode `rec` block by block and compare every worker's DNA stream with the reference .fqs."""
+    from fqsqueezer_amd import hostpipe as hp
+    header, blocks = hp.parse_fqs(open(os.path.join(GOLD, fqs_name), "rb").read())
+    mode = {0: "se_original", 1: "se_sorted"}[header[5]]
+    blks = hp.form_blocks(rec, mode)
+    assert len(blks) == len(blocks)
+    codec = make_codec(header)
+    for g, (idx, ref) in enumerate(zip(blks, blocks)):
+        assert len(idx) == ref.n_reads
+        bases, off = hp.block_arrays(rec, idx)
+        streams = codec.encode_block(bases, off, g)
+        for w, s in enumerate(streams):
+            assert s == ref.streams[w][hp.STREAM_DNA], f"{fqs_name}: block {g} worker {w} differs from the reference"
+    return codec
+
+
+def check_against_digest(make_codec, json_name, max_blocks=None):
+    from fqsqueezer_amd import hostpipe as hp
+    d = json.load(open(os.path.join(GOLD, json_name)))
+    rec = digest_records(d)
+    header = bytes.fromhex(d["header"])
+    blks = hp.form_blocks(rec, "se_sorted" if header[5] == 1 else "se_original")
+    assert len(blks) == d["n_blocks"]
+    codec = make_codec(header)
+    total = 0
+    for g, (idx, ref) in enumerate(zip(blks, d["blocks"])):
+        if max_blocks is not None and g >= max_blocks:
+            break
+        assert len(idx) == ref["n_reads"]
+        bases, off = hp.block_arrays(rec, idx)
+        streams = codec.encode_block(bases, off, g)
+        h = hashlib.sha256()
+        for s in streams:
+            h.update(s)
+        total += sum(len(s) for s in streams)
+        assert sum(len(s) for s in streams) == ref["bytes"], f"{json_name}: block {g} size differs"
+        assert h.hexdigest() == ref["sha256"], f"{json_name}: block {g} differs from the reference"
+    if max_blocks is None:
+        assert total == d["dna_bytes"]
+    return codec

@@ -1,0 +1,53 @@
+"""The product library: builds, exports every symbol include/fqsx.h declares, and has no CPU path."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    import __graft_entry__ as g
+    return g.build_hip()
+
+
+def test_exports_every_declared_symbol(libpath):
+    hdr = open(os.path.join(ROOT, "include", "fqsx.h")).read()
+    declared = set(re.findall(r"\b(fqsx_[a-z_]+)\s*\(", hdr))
+    assert {"fqsx_dna_create", "fqsx_dna_encode_block", "fqsx_dna_encode_block_dev", "fqsx_dna_destroy",
+            "fqsx_last_error"} <= declared
+    lib = C.CDLL(libpath)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/fqsx.h but not exported"
+
+
+def test_contains_gfx950_code_object(libpath):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-S", libpath], capture_output=True, text=True).stdout
+    assert ".hip_fatbin" in out
+    blob = open(libpath, "rb").read()
+    assert b"gfx950" in blob and b"k_encode_segment" in blob
+
+
+def test_fails_loudly_without_gpu(libpath):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from fqsqueezer_amd import hostpipe as hp
+    lib = C.CDLL(libpath)
+    lib.fqsx_last_error.restype = C.c_char_p
+    h = C.c_void_p()
+    rc = lib.fqsx_dna_create(hp.make_header(2, "se_sorted", 1), 0, C.byref(h))
+    assert rc == -2 and not h.value                       # FQSX_E_NO_DEVICE
+    assert b"no CPU path" in lib.fqsx_last_error()
+
+
+def test_package_never_selects_emulation():
+    src = open(os.path.join(ROOT, "fqsqueezer_amd", "codec.py")).read()
+    assert "libfqsx_emu" not in src.replace("host-emulation", "")
+    for f in os.listdir(os.path.join(ROOT, "fqsqueezer_amd")):
+        if f.endswith(".py"):
+            assert "oracle" not in open(os.path.join(ROOT, "fqsqueezer_amd", f)).read().replace("# oracle", "")

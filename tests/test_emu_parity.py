@@ -1,0 +1,54 @@
+"""The HIP kernels compiled for a 1-lane host wave (tests/emu) against the reference goldens and
+the oracle.  This exercises the kernel *logic* (state layout, schedule, mailboxes, table growth)
+in the GPU-less container; the 64-lane paths are covered by tests/test_gpu_parity.py on the GPU."""
+import numpy as np
+import pytest
+
+from conftest import EMU_LIB, c1_records, c4_records, check_against_digest, check_against_fqs
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.codec import DnaCodec
+from oracle.pyoracle import OracleCodec
+
+
+def emu(header):
+    return DnaCodec(header, lib_path=EMU_LIB)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build(built):
+    yield
+
+
+@pytest.mark.parametrize("name", ["c1_10k_o_t1.fqs", "c1_10k_o_t4.fqs", "c1_10k_s_t1.fqs", "c1_10k_s_t4.fqs"])
+def test_emu_matches_reference_10k(name):
+    codec = check_against_fqs(emu, c1_records(), name)
+    st = codec.stats()
+    assert st["bases"] > 0 and st["coded"] > 0 and st["gprobe"] > 0
+
+
+@pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
+def test_emu_matches_reference_ragged(name):
+    check_against_fqs(emu, c4_records(), name)
+
+
+def test_emu_matches_reference_150bp():
+    check_against_digest(emu, "c3_50k150_s_t8.json")
+
+
+def test_emu_matches_oracle_many_workers_and_tiny_blocks():
+    rec = c4_records()
+    for T, mode in [(7, "se_sorted"), (16, "se_original")]:
+        header = hp.make_header(T, mode, 1)
+        a, b = emu(header), OracleCodec(header)
+        blks = hp.form_blocks(rec, mode)[:12] if mode == "se_sorted" else [np.arange(0, 700), np.arange(700, 731), np.arange(731, 733)]
+        for g, idx in enumerate(blks):
+            bases, off = hp.block_arrays(rec, np.asarray(idx))
+            assert a.encode_block(bases, off, g) == b.encode_block(bases, off, g)
+
+
+def test_abi_rejects_bad_headers():
+    from fqsqueezer_amd.codec import FqsxError
+    good = hp.make_header(2, "se_sorted", 1)
+    for bad in [b"XCSD" + good[4:], good[:4] + bytes([0]) + good[5:], good[:5] + bytes([3]) + good[6:]]:
+        with pytest.raises(FqsxError):
+            emu(bad)

@@ -1,0 +1,79 @@
+"""Parity tests proper: the HIP path (through the C ABI) on a real MI355X against the reference
+goldens, the oracle, and size-independent properties at the benchmark's full size."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, c1_records, c4_records, check_against_digest, check_against_fqs
+from fqsqueezer_amd import hostpipe as hp
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu(header):
+    from fqsqueezer_amd.codec import DnaCodec
+    return DnaCodec(header, device=0)
+
+
+@pytest.mark.parametrize("name", ["c1_10k_o_t1.fqs", "c1_10k_o_t4.fqs", "c1_10k_s_t1.fqs", "c1_10k_s_t4.fqs"])
+def test_hip_matches_reference_10k(name):
+    check_against_fqs(gpu, c1_records(), name)
+
+
+@pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
+def test_hip_matches_reference_ragged(name):
+    check_against_fqs(gpu, c4_records(), name)
+
+
+def test_hip_matches_reference_150bp():
+    check_against_digest(gpu, "c3_50k150_s_t8.json")
+
+
+def test_hip_matches_reference_1M_t64_bit_exact():
+    """BASELINE configs[1] at full size: every block's DNA streams hash-identical to `fqs-1.1 e -t 64`."""
+    codec = check_against_digest(gpu, "c2_1M_s_t64.json")
+    st = codec.stats()
+    assert st["bases"] <= 100_000_000 and st["coded"] > 80_000_000
+
+
+def test_hip_matches_oracle_many_workers_and_tiny_blocks():
+    from oracle.pyoracle import OracleCodec
+    rec = c4_records()
+    for T, mode in [(7, "se_sorted"), (16, "se_original"), (64, "se_original")]:
+        header = hp.make_header(T, mode, 1)
+        a, b = gpu(header), OracleCodec(header)
+        blks = hp.form_blocks(rec, mode)[:12] if mode == "se_sorted" else [np.arange(0, 700), np.arange(700, 731), np.arange(731, 733)]
+        for g, idx in enumerate(blks):
+            bases, off = hp.block_arrays(rec, np.asarray(idx))
+            assert a.encode_block(bases, off, g) == b.encode_block(bases, off, g)
+
+
+def test_device_and_host_entry_points_agree():
+    import torch
+    rec = c1_records()
+    header = hp.make_header(4, "se_sorted", 1)
+    a, b = gpu(header), gpu(header)
+    for g, idx in enumerate(hp.form_blocks(rec, "se_sorted")[:20]):
+        bases, off = hp.block_arrays(rec, idx)
+        d_b = torch.from_numpy(np.ascontiguousarray(bases)).cuda()
+        d_o = torch.from_numpy(off.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        assert a.encode_block(bases, off, g) == b.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g)
+
+
+def test_determinism_and_stream_framing():
+    rec = c1_records()
+    header = hp.make_header(8, "se_sorted", 1)
+    runs = []
+    for _ in range(2):
+        c = gpu(header)
+        out = []
+        for g, idx in enumerate(hp.form_blocks(rec, "se_sorted")[:30]):
+            bases, off = hp.block_arrays(rec, idx)
+            out.append(c.encode_block(bases, off, g))
+        runs.append(out)
+    assert runs[0] == runs[1]
+    assert all(len(s) >= 8 for blk in runs[0] for s in blk)      # every stream ends with 8 flush bytes

@@ -1,0 +1,46 @@
+"""N>1 path of bench.py (one independent file per rank, barrier, max-over-ranks timing) with
+world_size 2 on the gloo backend; the ranks run the emulated kernels."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+WORKER = r'''
+import os, sys, time
+sys.path.insert(0, os.environ["FQSX_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.codec import DnaCodec
+from fqsqueezer_amd.synth import synth_reads
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+reads = synth_reads(600, 80, 20000, 2 + rank)
+rec = hp.Records([b"@r%d" % i for i in range(600)], reads, reads)
+codec = DnaCodec(hp.make_header(3, "se_sorted", 1), lib_path=os.environ["FQSX_EMU_LIB"])
+dist.barrier(); t0 = time.perf_counter(); n = 0
+for g, idx in enumerate(hp.form_blocks(rec, "se_sorted")[:10]):
+    bases, off = hp.block_arrays(rec, idx)
+    n += sum(len(s) for s in codec.encode_block(bases, off, g))
+dist.barrier()
+t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+tot = torch.tensor([n], dtype=torch.int64); dist.all_reduce(tot)
+lst = [None] * world; dist.all_gather_object(lst, n)
+if rank == 0:
+    assert lst[0] != lst[1], "ranks must compress different files"
+    assert int(tot.item()) == sum(lst) and t.item() > 0
+    print("MULTIRANK_OK", lst)
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_gloo(tmp_path, built):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, FQSX_ROOT=ROOT, FQSX_EMU_LIB=os.path.join(ROOT, "tests", "emu", "libfqsx_emu.so"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "MULTIRANK_OK" in r.stdout

@@ -1,0 +1,97 @@
+"""Pins the oracle (CPU restatement, oracle/fqs_oracle.cpp) to outputs of the unmodified reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import c1_records, c4_records, check_against_digest, check_against_fqs
+from oracle.pyoracle import OracleCodec, lib
+
+
+@pytest.mark.parametrize("name", ["c1_10k_o_t1.fqs", "c1_10k_o_t4.fqs", "c1_10k_s_t1.fqs", "c1_10k_s_t4.fqs"])
+def test_oracle_matches_reference_10k(name):
+    check_against_fqs(OracleCodec, c1_records(), name)
+
+
+@pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
+def test_oracle_matches_reference_ragged(name):
+    check_against_fqs(OracleCodec, c4_records(), name)
+
+
+def test_oracle_matches_reference_150bp():
+    check_against_digest(OracleCodec, "c3_50k150_s_t8.json")
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("t", [1, 8, 64])
+def test_oracle_matches_reference_1M(t):
+    check_against_digest(OracleCodec, f"c2_1M_s_t{t}.json")
+
+
+def test_mt19937_known_answer():
+    out = np.zeros(10000, dtype=np.uint32)
+    lib().fqo_kat_mt19937(5489, 10000, out.ctypes.data)
+    assert int(out[9999]) == 4123659995            # ISO C++ [rand.predef]: 10000th value of default mt19937
+    rs = np.random.RandomState(5481)               # init_genrand seeding, same as std::mt19937(5481)
+    ref = rs.randint(0, 2**32, size=2000, dtype=np.uint64).astype(np.uint32)
+    lib().fqo_kat_mt19937(5481, 2000, out.ctypes.data)
+    assert (out[:2000] == ref).all()
+
+
+def _py_decode(data, script):
+    """Independent Python decoder of the carry-less range coder (sub_rc.h:93-158)."""
+    TOP, M64, MASK = 0x00ffffffffffff, 0xFF << 56, (1 << 64) - 1   # TopValue is 2^48-1 (14 hex digits, sub_rc.h:38)
+    pos = 8
+    buf = int.from_bytes(data[:8], "big")
+    low, rng = 0, M64
+    out = []
+    for tot, cums in script:
+        rng //= tot
+        c = buf // rng
+        sym = max(i for i, x in enumerate(cums[:-1]) if x <= c)
+        out.append(sym)
+        r = cums[sym] * rng
+        buf -= r
+        low = (low + r) & MASK
+        rng *= cums[sym + 1] - cums[sym]
+        while rng <= TOP:
+            if (low ^ (low + rng)) & M64:
+                rng = ((low | TOP) - low) & MASK
+            buf = ((buf << 8) + data[pos]) & MASK
+            pos += 1
+            low = (low << 8) & MASK
+            rng = (rng << 8) & MASK
+    return out
+
+
+def test_range_coder_roundtrip():
+    rs = np.random.RandomState(3)
+    n = 5000
+    script, syms = [], []
+    for _ in range(n):
+        k = int(rs.randint(2, 6))
+        f = rs.randint(1, 2000, size=k)
+        cums = [0] + np.cumsum(f).tolist()
+        script.append((cums[-1], cums))
+        syms.append(int(rs.choice(k, p=f / f.sum())))
+    freq = np.array([s[1][x + 1] - s[1][x] for s, x in zip(script, syms)], dtype=np.uint32)
+    cum = np.array([s[1][x] for s, x in zip(script, syms)], dtype=np.uint32)
+    tot = np.array([s[0] for s in script], dtype=np.uint32)
+    out = np.zeros(4 * n + 64, dtype=np.uint8)
+    ln = lib().fqo_kat_rc(n, freq.ctypes.data, cum.ctypes.data, tot.ctypes.data, out.ctypes.data, len(out))
+    data = out[:ln].tobytes() + b"\0" * 16
+    assert _py_decode(data, script) == syms
+
+
+def test_counter_incrementer_properties():
+    # Increment(c) below the threshold is exact; merges below the threshold are exact sums
+    a = np.arange(0, 8, dtype=np.uint32)
+    b = np.full(8, 0xFFFFFFFF, dtype=np.uint32)
+    out = np.zeros(8, dtype=np.uint32)
+    lib().fqo_kat_cinc(7, 2, 63, 8, a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    assert out.tolist() == [1, 2, 3, 4, 5, 6, 7, 8]
+    a = np.array([0, 3, 7, 63, 63], dtype=np.uint32)
+    b = np.array([5, 4, 0, 63, 0], dtype=np.uint32)
+    out = np.zeros(5, dtype=np.uint32)
+    lib().fqo_kat_cinc(7, 2, 63, 5, a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    assert out.tolist()[:3] == [5, 7, 7] and out[3] == 63 and out[4] == 63

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the UNMODIFIED reference binary
+(oracle/_ref/fqs-1.1, built by `make -C oracle ref` from /root/reference).
+
+Fixtures (data only -- inputs are re-generated deterministically by fqsqueezer_amd.synth):
+  c1_10k_{o,s}_t{1,4}.fqs   complete reference outputs, 10k x 100bp, G=200kbp, seed 1, -gs 1
+  c2_1M_s_t{1,8,64}.json    per-block SHA-256 + sizes of the reference DNA streams,
+                            1M x 100bp, G=5Mbp, seed 2, -om s -gs 5   (BASELINE configs[1])
+  c4_ragged_{o,s}_t3.fqs   3000 ragged reads (30-160 bp, N runs, duplicates), G=60kbp, seed 4, -gs 1
+  c3_50k150_s_t8.json       50k x 150bp, G=250kbp, seed 3, -om s -gs 8 (150 bp metric shape)
+Usage: python tools/make_golden.py [--work /tmp/w] [--only c1|c2|c3]
+"""
+import argparse, hashlib, json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.synth import synth_reads, write_fastq
+
+REF = os.path.join(ROOT, "oracle", "_ref", "fqs-1.1")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def run_ref(fq, out, om, t, gs, work):
+    if not os.path.exists(out):
+        subprocess.check_call([REF, "e", "-s", "-om", om, "-t", str(t), "-gs", str(gs), "-qm", "n", "-im", "n", "-v", "0",
+                               "-tmp", os.path.join(work, "tmp_%d_" % os.getpid()), "-out", out, fq], stdout=subprocess.DEVNULL)
+
+
+def digest(fqs_path, meta):
+    header, blocks = hp.parse_fqs(open(fqs_path, "rb").read())
+    d = dict(meta, header=header.hex(), n_blocks=len(blocks), blocks=[])
+    total = 0
+    for b in blocks:
+        h = hashlib.sha256()
+        sizes = []
+        for st in b.streams:
+            h.update(st[hp.STREAM_DNA])
+            sizes.append(len(st[hp.STREAM_DNA]))
+        total += sum(sizes)
+        d["blocks"].append({"n_reads": b.n_reads, "sha256": h.hexdigest(), "bytes": sum(sizes)})
+    d["dna_bytes"] = total
+    return d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--work", default="/tmp/w")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(a.work, exist_ok=True)
+    if a.only in ("", "c1"):
+        fq = os.path.join(a.work, "c1.fq")
+        if not os.path.exists(fq):
+            write_fastq(fq, synth_reads(10000, 100, 200000, 1), seed=1)
+        for om in "os":
+            for t in (1, 4):
+                run_ref(fq, os.path.join(GOLD, f"c1_10k_{om}_t{t}.fqs"), om, t, 1, a.work)
+    if a.only in ("", "c2"):
+        fq = os.path.join(a.work, "c2.fq")
+        if not os.path.exists(fq):
+            write_fastq(fq, synth_reads(1000000, 100, 5000000, 2), seed=2)
+        for t in (1, 8, 64):
+            out = os.path.join(a.work, f"c2_s_t{t}.fqs")
+            run_ref(fq, out, "s", t, 5, a.work)
+            meta = {"reads": 1000000, "len": 100, "genome": 5000000, "seed": 2, "gs": 5, "om": "s", "threads": t}
+            json.dump(digest(out, meta), open(os.path.join(GOLD, f"c2_1M_s_t{t}.json"), "w"))
+    if a.only in ("", "c4"):
+        ids, seqs, quals = ragged()
+        fq = os.path.join(a.work, "c4.fq")
+        with open(fq, "wb") as f:
+            for i, sq, q in zip(ids, seqs, quals):
+                f.write(i + b"\n" + sq + b"\n+\n" + q + b"\n")
+        for om in "os":
+            run_ref(fq, os.path.join(GOLD, f"c4_ragged_{om}_t3.fqs"), om, 3, 1, a.work)
+    if a.only in ("", "c3"):
+        fq = os.path.join(a.work, "c3.fq")
+        if not os.path.exists(fq):
+            write_fastq(fq, synth_reads(50000, 150, 250000, 3), seed=3)
+        out = os.path.join(a.work, "c3_s_t8.fqs")
+        run_ref(fq, out, "s", 8, 8, a.work)
+        meta = {"reads": 50000, "len": 150, "genome": 250000, "seed": 3, "gs": 8, "om": "s", "threads": 8}
+        json.dump(digest(out, meta), open(os.path.join(GOLD, "c3_50k150_s_t8.json"), "w"))
+
+
+def ragged():
+    """c4: ragged reads with N runs and duplicates, both orders, T=3 (complete reference outputs)."""
+    from fqsqueezer_amd.synth import synth_ragged
+    ids, seqs, quals = synth_ragged(3000, 60000, 4)
+    return ids, seqs, quals
+
+
+if __name__ == "__main__":
+    main()
