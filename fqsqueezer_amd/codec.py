@@ -28,6 +28,10 @@ def _load(path: str):
     if not os.path.exists(path):
         raise FqsxError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    try:  # PyTorch ships its own ROCm runtime: load it first so the process has ONE HIP runtime
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.fqsx_dna_create.restype = C.c_int
     lib.fqsx_dna_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
@@ -98,11 +102,13 @@ class DnaCodec:
         return sum(self._lens[w] for w in range(self.T))
 
     def stats(self) -> dict:
-        a = (C.c_uint64 * 16)()
+        a = (C.c_uint64 * 24)()
         rc = self._lib.fqsx_dna_stats(self._h, a)
         if rc:
             raise FqsxError(f"fqsx_dna_stats: {rc}: {self._lib.fqsx_last_error().decode()}")
-        return dict(zip(STAT_NAMES, list(a)))
+        d = dict(zip(STAT_NAMES, list(a)))
+        d["timers"] = list(a)[16:24]
+        return d
 
     def set_profiling(self, on: bool) -> None:
         self._lib.fqsx_dna_set_profiling(self._h, int(on))

@@ -18,6 +18,15 @@ struct WgShared {
   u64 bk_key[256];             // probe batch: normalised k-mers
   u32 bk_res[256][4];          // probe batch: counts
   u8 bk_dir[256];              // probe batch: orientation
+  // speculation chunk: results of the lane-parallel b-mer probe + context-key stage
+  u64 sp_dir[FQSX_SPEC];       // corrected b-mer (dir word, last symbol open) the entry was computed for
+  u64 sp_key[FQSX_SPEC][7];    // context keys of the 7 levels (r_sym field left 0)
+  u32 sp_cnt[FQSX_SPEC];       // 4 x 8-bit counts
+  u8 sp_flag[FQSX_SPEC];       // 0 none, 1 b-mer hit (fast path), 2 hit but >1 saturated counter, 3 known miss
+  u8 sp_rsym[FQSX_SPEC];       // rank of the read's symbol under those counts
+  // deferred inserts into the worker-private local tables (flushed in order before any local look-up)
+  u64 lq_key[2][64];
+  u32 lq_n[2];
 };
 
 struct C4 { u32 c[4]; };
@@ -38,8 +47,16 @@ struct Wk {
   double avg_code, avg_letters;
   u64 hidden;
   u64 st[ST_N];
+  u64 tm[8];
   u32 err;
 };
+#ifdef FQSX_TIMING
+#define TM_BEGIN(v) u64 v = fq_clock()
+#define TM_END(w, slot, v) (w).tm[slot] += fq_clock() - (v)
+#else
+#define TM_BEGIN(v) ((void)0)
+#define TM_END(w, slot, v) ((void)0)
+#endif
 
 #define CINC_B (Cinc{7u, 2u, 63u})            /* dna.cpp:162,164 */
 #define CINC_S (Cinc{2047u, 1u, 4095u})       /* dna.cpp:163,165 */
@@ -177,8 +194,12 @@ FQ_DEV bool km_almost_full(const Kmer &k, const KGeom &g, u32 margin) { return k
 
 // ---------------------------------------------------------------------------------------
 // k-mer tables
-FQ_DEV u32 sb_owner(const DevCfg *cfg, u64 kmer_norm) { return (u32)(((kmer_norm >> 46) & 0x3fffull) % cfg->T); }  // dna.cpp:825
-FQ_DEV u32 p_owner(const DevCfg *cfg, u64 idx) { return (u32)((idx >> cfg->pmer_mod_shift) % cfg->T); }           // dna.cpp:658
+FQ_DEV u32 mod_T(const DevCfg *cfg, u32 x) {  // x % T for x < 2^14, T <= 255 (exact: x*T < 2^32)
+  u32 q = (u32)(((u64)x * cfg->T_magic) >> 32);
+  return x - q * cfg->T;
+}
+FQ_DEV u32 sb_owner(const DevCfg *cfg, u64 kmer_norm) { return mod_T(cfg, (u32)((kmer_norm >> 46) & 0x3fffull)); }  // dna.cpp:825
+FQ_DEV u32 p_owner(const DevCfg *cfg, u64 idx) { return mod_T(cfg, (u32)(idx >> cfg->pmer_mod_shift)); }           // dna.cpp:658
 
 FQ_DEV u64 tab_home(const KTab &t, u64 v) {
   u64 kern = (v >> 4) & ((1ull << (2 * t.k - 8)) - 1ull);
@@ -275,6 +296,48 @@ FQ_DEV void batch_count(Wk &w, const KTab &t, u32 n) {  // exact counts of the b
   FQ_SYNC();
   w.st[ST_GPROBE] += n;
   w.st[ST_GSLOT] += wave_sum64(ns);
+}
+
+// lane-parallel in-order insert of <= 64 keys into sub-table `sub` (defined below)
+FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 sub, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
+                         u64 &nslots, u32 &err);
+FQ_DEV void insert_keys(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 sub, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
+                        u64 &nslots, u32 &err) {
+#if FQ_WAVE > 1
+  for (u32 o = 0; o < n && !err; o += FQ_WAVE) insert_batch(cfg, sm, t, sub, keys + o, n - o < FQ_WAVE ? n - o : FQ_WAVE, rng, ci, nslots, err);
+#else
+  for (u32 j = 0; j < n && !err; ++j) insert_batch(cfg, sm, t, sub, keys + j, 1, rng, ci, nslots, err);
+#endif
+}
+// Deferred local-table inserts (ht_*_local->insert, dna.cpp:826,839,861,872): queued in LDS in program
+// order and applied as one lane-parallel batch before the next local look-up, so the tables always
+// hold exactly what the sequential algorithm would have inserted by then.
+FQ_DEV void lq_flush(Wk &w, u32 which) {
+  WgShared *sm = w.sm;
+  u32 n = sm->lq_n[which];
+  if (!n) return;
+  TM_BEGIN(t_lq);
+  u64 ns = 0;
+  u32 err = 0;
+  insert_keys(*w.cfg, sm, which ? w.cfg->l_s : w.cfg->l_b, w.tid, sm->lq_key[which], n, which ? RNG_LS : RNG_LB,
+              which ? CINC_S : CINC_B, ns, err);
+  FQ_SYNC();
+  if (FQ_LANE == 0) sm->lq_n[which] = 0;
+  FQ_SYNC();
+  if (err) w.err = FQSX_ERR_LTAB_FULL;
+  TM_END(w, TM_LQ, t_lq);
+}
+FQ_DEV void lq_push(Wk &w, u32 which, u64 key) {
+  WgShared *sm = w.sm;
+  u32 n = sm->lq_n[which];
+  FQ_SYNC();
+  if (FQ_LANE == 0) {
+    sm->lq_key[which][n] = key;
+    sm->lq_n[which] = n + 1;
+  }
+  FQ_SYNC();
+  w.st[ST_LINS] += 1;
+  if (n + 1 == 64) lq_flush(w, which);
 }
 
 // find / find_full / find_partial (ht_kmer.h:189-203,266-327,504-510)
@@ -374,9 +437,21 @@ FQ_DEV void rc_put(Wk &w, u8 b) {
   if (w.enc.len < w.enc.cap) w.enc.out[w.enc.len] = b; else w.err = FQSX_ERR_OUT_OVERFLOW;
   ++w.enc.len;
 }
+// exact range / tot for tot < 2^16 without the 64-bit software divide: high word by 32-bit
+// division, the remaining < 2^48 dividend in fp64 with a +-1 fix-up (sub_rc.h:63)
+FQ_DEV u64 div_u64_small(u64 x, u32 d) {
+  u32 hi = (u32)(x >> 32), lo = (u32)x;
+  u32 qh = hi / d;
+  u64 rem = ((u64)(hi - qh * d) << 32) | lo;
+  u64 q = (u64)((double)rem / (double)d);
+  u64 prod = q * d;
+  if (prod > rem) --q;
+  else if (rem - prod >= d) ++q;
+  return ((u64)qh << 32) + q;
+}
 FQ_DEV void rc_encode(Wk &w, u32 freq, u32 cum, u32 tot) {
   const u64 Top = 0x00ffffffffffffULL, M = 0xff00000000000000ULL;
-  u64 range = w.enc.range / tot, low = w.enc.low;
+  u64 range = div_u64_small(w.enc.range, tot), low = w.enc.low;
   low += range * cum;
   range *= freq;
   while (range <= Top) {
@@ -414,11 +489,11 @@ FQ_DEV void sm_encode(Wk &w, u16 *m, u32 n, u32 max_total, u32 x) {
 // 256-symbol model (prefix_sorted_bytes): cumulative sum and rescale are lane-parallel
 FQ_DEV void sm_encode256(Wk &w, u16 *m, u8 *init_flag, u32 x) {
   if (!*init_flag) {
-    FQ_SYNC();
+    FQ_SYNC_MEM();
     for (u32 i = FQ_LANE; i < 256; i += FQ_WAVE) m[i] = 1;
     m[256] = 256;
     *init_flag = 1;
-    FQ_SYNC();
+    FQ_SYNC_MEM();
   }
   u32 part = 0;
   for (u32 i = FQ_LANE; i < x; i += FQ_WAVE) part += m[i];
@@ -426,9 +501,9 @@ FQ_DEV void sm_encode256(Wk &w, u16 *m, u8 *init_flag, u32 x) {
   u32 f = m[x], tot = m[256];
   rc_encode(w, f, cum, tot);
   tot += 4;
-  FQ_SYNC();
+  FQ_SYNC_MEM();
   m[x] = (u16)(f + 4);
-  FQ_SYNC();
+  FQ_SYNC_MEM();
   while (tot >= (1u << 15)) {
     u32 p = 0;
     for (u32 i = FQ_LANE; i < 256; i += FQ_WAVE) {
@@ -437,7 +512,7 @@ FQ_DEV void sm_encode256(Wk &w, u16 *m, u8 *init_flag, u32 x) {
       p += v;
     }
     tot = wave_sum32(p);
-    FQ_SYNC();
+    FQ_SYNC_MEM();
   }
   m[256] = (u16)tot;
 }
@@ -455,13 +530,13 @@ FQ_DEV u32 ctx_find(Wk &w, u32 tag, u64 key, Slot4 &s) {
   const u64 *b = ctx_base(w);
   u64 h = ctx_hash(w, tag, key);
   for (u64 n = 0; n <= w.cfg->ctx_cap_mask; ++n) {
-    const u64 *p = b + 4 * h;
-    u64 q0 = p[0], q1 = p[1];
+    const u64 *p = (const u64 *)__builtin_assume_aligned(b + 4 * h, 32);
+    u64 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];  // one 32-byte slot, fetched in one round trip
     w.st[ST_CTX] += 1;
     u32 tg = slot_tag(q1);
     if (!tg) return FQSX_NIL;
     if (tg == tag && q0 == key) {
-      s.q0 = q0; s.q1 = q1; s.q2 = p[2]; s.q3 = p[3];
+      s.q0 = q0; s.q1 = q1; s.q2 = q2; s.q3 = q3;
       return (u32)h;
     }
     h = (h + 1) & w.cfg->ctx_cap_mask;
@@ -865,13 +940,15 @@ FQ_DEV bool rough_kt(Wk &w, const KTab &t, const KGeom &g, const Kmer &can, u32 
   return c4_any(counts);
 }
 
-FQ_DEV u32 find_counts(Wk &w, C4 &counts) {  // find_counts, dna.cpp:457-502
+// find_counts, dna.cpp:457-502.  b_miss_known: the speculation stage already probed the global
+// b-mer table for exactly this (full) b-mer and found nothing.
+FQ_DEV u32 find_counts(Wk &w, C4 &counts, bool b_miss_known) {
   const DevCfg *cfg = w.cfg;
   c4_zero(counts);
   u32 bmargin = cfg->bmer - cfg->smer - 1;
   u32 smargin = cfg->smer - cfg->pmer + 1;
   if (km_almost_full(w.bm, cfg->gb, bmargin)) {
-    if (kt_find(w, cfg->g_b, true, cfg->gb, w.bm, RNG_B, CINC_B, counts)) {
+    if (!b_miss_known && kt_find(w, cfg->g_b, true, cfg->gb, w.bm, RNG_B, CINC_B, counts)) {
       u32 sat = (counts.c[0] == 63) + (counts.c[1] == 63) + (counts.c[2] == 63) + (counts.c[3] == 63);
       if (sat > 1) {
         C4 c2;
@@ -881,12 +958,14 @@ FQ_DEV u32 find_counts(Wk &w, C4 &counts) {  // find_counts, dna.cpp:457-502
       }
       return LV_BMER;
     } else {
+      lq_flush(w, 0);
       if (kt_find(w, cfg->l_b, false, cfg->gb, w.bm, RNG_LB, CINC_B, counts)) return LV_BMER;
       if (w.bm.dir != w.bm_u.dir && kt_find(w, cfg->g_b, true, cfg->gb, w.bm_u, RNG_B, CINC_B, counts)) return LV_BMER_UNC;
     }
   }
   if (km_almost_full(w.sm_, cfg->gs, smargin)) {
     if (kt_find(w, cfg->g_s, true, cfg->gs, w.sm_, RNG_S, CINC_S, counts)) return LV_SMER;
+    lq_flush(w, 1);
     if (kt_find(w, cfg->l_s, false, cfg->gs, w.sm_, RNG_LS, CINC_S, counts)) return LV_SMER;
   } else if (find_counts_p(w, counts))
     return LV_PMER;
@@ -960,8 +1039,7 @@ FQ_DEV void push_p_both(Wk &w) {
 FQ_DEV void push_b_local(Wk &w) {
   u64 x = km_norm(w.bm, w.cfg->gb);
   mail_push(w, MAIL_B, sb_owner(w.cfg, x), x);
-  tab_insert_uniform(w, w.cfg->l_b, w.tid, x, RNG_LB, CINC_B);
-  w.st[ST_LINS] += 1;
+  lq_push(w, 0, x);
 }
 
 FQ_DEV void insert_all(Wk &w, u64 sym) {
@@ -1036,74 +1114,163 @@ FQ_DEV void prefix_sorted(Wk &w, const u8 *p, u32 size) {  // compress_prefix_so
   push_p_both(w);
 }
 
+// Speculation stage of one chunk of <= 64 suffix positions (one per lane): assuming no k-mer
+// correction happens inside the chunk, lane j rolls the corrected b-mer forward to position i0+j,
+// probes the global b-mer table and -- on a plain hit -- derives everything that depends only on
+// (counts, position, symbol): the 7 context keys and the symbol's rank.  The commit loop uses an
+// entry only if the b-mer it was computed for equals the actual one, so a wrong guess is a cache
+// miss, never a wrong result.
+FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n) {
+  const DevCfg *cfg = w.cfg;
+  WgShared *sm = w.sm;
+  u64 ns = 0;
+  u32 np = 0;
+  FQ_SYNC();
+  for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
+    Kmer b = w.bm;
+    for (u32 s = 0; s < j; ++s) {
+      u32 c = rd_sym(w, p, i0 + s, size);
+      km_insert(b, cfg->gb, c == 4 ? 0 : c);
+    }
+    km_insert_zero(b, cfg->gb);
+    u32 flag = 0;
+    if (b.cur == cfg->gb.k) {
+      bool nd = km_norm_dir(b, cfg->gb);
+      u64 key = nd ? b.dir : b.rc;
+      C4 c;
+      c4_zero(c);
+      tab_scan(cfg->g_b, sb_owner(cfg, key), key, nd, c, ns);
+      ++np;
+      sm->sp_dir[j] = b.dir;
+      if (c4_any(c)) {
+        u32 sat = (c.c[0] == 63) + (c.c[1] == 63) + (c.c[2] == 63) + (c.c[3] == 63);
+        if (sat > 1) flag = 2;
+        else {
+          flag = 1;
+          u32 i = i0 + j, sym = rd_sym(w, p, i, size);
+          int cor_dist = (int)cfg->bmer, d = (int)i - (int)w.cor_pos;
+          u32 cz = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
+          u64 lev[7];
+          ctx_codes(lev, cfg, c, w.s_let, i, LV_BMER, cz, 0, size);
+          for (u32 l = 0; l < 7; ++l) sm->sp_key[j][l] = lev[l];
+          sm->sp_cnt[j] = c.c[0] | (c.c[1] << 8) | (c.c[2] << 16) | (c.c[3] << 24);
+          sm->sp_rsym[j] = (u8)rank_sym(w, c, sym);
+        }
+      } else
+        flag = 3;
+    }
+    sm->sp_flag[j] = (u8)flag;
+  }
+  FQ_SYNC();
+  w.st[ST_GPROBE] += wave_sum32(np);
+  w.st[ST_GSLOT] += wave_sum64(ns);
+}
+
 FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {  // compress_suffix, dna.cpp:674-877
   const DevCfg *cfg = w.cfg;
+  WgShared *sm = w.sm;
   C4 counts;
   c4_zero(counts);
   u64 ctx_r_sym = 0;
-  for (u32 i = original_order ? cfg->prefix : cfg->pmer; i < size; ++i) {
-    if (w.err) return;
-    u32 sym = rd_sym(w, p, i, size);
-    u64 sym_k = sym == 4 ? 0 : sym;
-    km_insert_zero(w.pm, cfg->gp); km_insert_zero(w.sm_, cfg->gs); km_insert_zero(w.bm, cfg->gb);
-    km_insert_zero(w.pm_u, cfg->gp); km_insert_zero(w.sm_u, cfg->gs); km_insert_zero(w.bm_u, cfg->gb);
-    u32 level = find_counts(w, counts);
-    if (level == LV_BMER_UNC) {
-      w.bm = w.bm_u; w.sm_ = w.sm_u; w.pm = w.pm_u;
-      w.cor_pos = 0;
-      level = LV_BMER;
-    }
-    bool rough = false;
-    if (level == LV_NONE) {
+  u32 i = original_order ? cfg->prefix : cfg->pmer;
+  while (i < size) {
+    const u32 n = size - i < FQSX_SPEC ? size - i : FQSX_SPEC;
+    TM_BEGIN(t_sp);
+    speculate(w, p, size, i, n);
+    TM_END(w, TM_SPEC, t_sp);
+    bool dirty = false;  // corrected k-mers were modified: the rest of the chunk's speculation is stale
+    for (u32 j = 0; j < n && !dirty; ++j, ++i) {
+      if (w.err) return;
+      u32 sym = rd_sym(w, p, i, size);
+      u64 sym_k = sym == 4 ? 0 : sym;
+      km_insert_zero(w.pm, cfg->gp); km_insert_zero(w.sm_, cfg->gs); km_insert_zero(w.bm, cfg->gb);
+      km_insert_zero(w.pm_u, cfg->gp); km_insert_zero(w.sm_u, cfg->gs); km_insert_zero(w.bm_u, cfg->gb);
+      const u32 flag = sm->sp_flag[j];
+      const bool spec_ok = flag != 0 && w.bm.cur == cfg->gb.k && w.bm.dir == sm->sp_dir[j];
+      u32 level;
+      TM_BEGIN(t_code);
+      const bool fast = spec_ok && flag == 1 && w.N_run < 2;
+      if (fast) {
+        // fast path: level bmer, everything but the adaptive state was computed in parallel
+        u32 pc = sm->sp_cnt[j];
+        counts.c[0] = pc & 0xff; counts.c[1] = (pc >> 8) & 0xff; counts.c[2] = (pc >> 16) & 0xff; counts.c[3] = pc >> 24;
+        level = LV_BMER;
+        u64 lev[7];
+        const u64 rs = (u64)popc64(ctx_r_sym) << SH_RSYM;
+        lev[0] = sm->sp_key[j][0];
+        lev[1] = sm->sp_key[j][1];
+        for (u32 l = 2; l < 7; ++l) lev[l] = sm->sp_key[j][l] + rs;
+        Slot4 s;
+        u32 idx = find_leveled(w, 1, lev, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
+        u32 r_sym = sm->sp_rsym[j];
+        if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
+        ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;
+      } else {
+        level = find_counts(w, counts, spec_ok && flag == 3);
+        if (level == LV_BMER_UNC) {
+          w.bm = w.bm_u; w.sm_ = w.sm_u; w.pm = w.pm_u;
+          w.cor_pos = 0;
+          level = LV_BMER;
+          dirty = true;
+        }
+        bool rough = false;
+        if (level == LV_NONE) {
+          if (km_full(w.bm, cfg->gb)) {
+            if (rough_kt(w, cfg->g_b, cfg->gb, w.bm, RNG_B, CINC_B, counts)) { level = LV_PMER; rough = true; }
+          } else if (km_full(w.sm_, cfg->gs)) {
+            if (rough_kt(w, cfg->g_s, cfg->gs, w.sm_, RNG_S, CINC_S, counts)) { level = LV_PMER; rough = true; }
+          } else if (km_full(w.pm, cfg->gp)) {
+            if (rough_p(w, counts)) { level = LV_PMER; rough = true; }
+          }
+        }
+        if (level != LV_NONE && w.N_run < 2) {
+          int cor_dist = level == LV_PMER ? (int)cfg->pmer : level == LV_SMER ? (int)cfg->smer : (int)cfg->bmer;
+          int d = (int)i - (int)w.cor_pos;
+          u32 cor_zone = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
+          if (rough) cor_zone = 3;
+          u64 lev[7];
+          ctx_codes(lev, cfg, counts, w.s_let, i, level, cor_zone, ctx_r_sym, size);
+          Slot4 s;
+          u32 idx = find_leveled(w, 1, lev, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
+          u32 r_sym = rank_sym(w, counts, sym);
+          if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
+          ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;  // update_ctx_r_sym, dna.cpp:664-671
+        } else {
+          code_letter(w, i, sym, size);
+          ctx_r_sym = (ctx_r_sym << 1) & 0xff;
+        }
+      }
+      TM_END(w, fast ? TM_FAST : TM_SLOW, t_code);
+      TM_BEGIN(t_post);
+      w.ctx_letters = (w.ctx_letters << 4) + sym;
+      if (sym == 4) ++w.N_run; else w.N_run = 0;
+      km_replace_last(w.pm, sym_k); km_replace_last(w.sm_, sym_k); km_replace_last(w.bm, sym_k);
+      km_replace_last(w.pm_u, sym_k); km_replace_last(w.sm_u, sym_k); km_replace_last(w.bm_u, sym_k);
+      if (sym < 4) {
+        bool pmer_insert = true;
+        if (km_full(w.bm, cfg->gb)) {
+          push_b_local(w);
+          if ((level == LV_SMER || level == LV_BMER || level == LV_MIXED || level == LV_BMER_UNC) && c4_get(counts, sym) >= 3) pmer_insert = false;
+        }
+        if (km_full(w.sm_, cfg->gs)) {
+          u64 x = km_norm(w.sm_, cfg->gs);
+          mail_push(w, MAIL_S, sb_owner(cfg, x), x);
+          lq_push(w, 1, x);
+        }
+        if (km_full(w.pm, cfg->gp) && i - w.cor_pos >= cfg->pmer - 1) {
+          if (pmer_insert) push_p_both(w); else w.hidden += 2;
+        }
+      }
       if (km_full(w.bm, cfg->gb)) {
-        if (rough_kt(w, cfg->g_b, cfg->gb, w.bm, RNG_B, CINC_B, counts)) { level = LV_PMER; rough = true; }
-      } else if (km_full(w.sm_, cfg->gs)) {
-        if (rough_kt(w, cfg->g_s, cfg->gs, w.sm_, RNG_S, CINC_S, counts)) { level = LV_PMER; rough = true; }
-      } else if (km_full(w.pm, cfg->gp)) {
-        if (rough_p(w, counts)) { level = LV_PMER; rough = true; }
+        bool rep = false;
+        if (level == LV_BMER || level == LV_MIXED || level == LV_BMER_UNC) rep = repair_existing(w, i, counts, sym);
+        else if (level == LV_NONE || level == LV_PMER) rep = repair_missing(w, i);
+        if (rep) {
+          push_b_local(w);
+          dirty = true;
+        }
       }
-    }
-    if (level != LV_NONE && w.N_run < 2) {
-      int cor_dist = level == LV_PMER ? (int)cfg->pmer : level == LV_SMER ? (int)cfg->smer : (int)cfg->bmer;
-      int d = (int)i - (int)w.cor_pos;
-      u32 cor_zone = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
-      if (rough) cor_zone = 3;
-      u64 lev[7];
-      ctx_codes(lev, cfg, counts, w.s_let, i, level, cor_zone, ctx_r_sym, size);
-      Slot4 s;
-      u32 idx = find_leveled(w, 1, lev, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
-      u32 r_sym = rank_sym(w, counts, sym);
-      if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
-      ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;  // update_ctx_r_sym, dna.cpp:664-671
-    } else {
-      code_letter(w, i, sym, size);
-      ctx_r_sym = (ctx_r_sym << 1) & 0xff;
-    }
-    w.ctx_letters = (w.ctx_letters << 4) + sym;
-    if (sym == 4) ++w.N_run; else w.N_run = 0;
-    km_replace_last(w.pm, sym_k); km_replace_last(w.sm_, sym_k); km_replace_last(w.bm, sym_k);
-    km_replace_last(w.pm_u, sym_k); km_replace_last(w.sm_u, sym_k); km_replace_last(w.bm_u, sym_k);
-    if (sym < 4) {
-      bool pmer_insert = true;
-      if (km_full(w.bm, cfg->gb)) {
-        push_b_local(w);
-        if ((level == LV_SMER || level == LV_BMER || level == LV_MIXED || level == LV_BMER_UNC) && c4_get(counts, sym) >= 3) pmer_insert = false;
-      }
-      if (km_full(w.sm_, cfg->gs)) {
-        u64 x = km_norm(w.sm_, cfg->gs);
-        mail_push(w, MAIL_S, sb_owner(cfg, x), x);
-        tab_insert_uniform(w, cfg->l_s, w.tid, x, RNG_LS, CINC_S);
-        w.st[ST_LINS] += 1;
-      }
-      if (km_full(w.pm, cfg->gp) && i - w.cor_pos >= cfg->pmer - 1) {
-        if (pmer_insert) push_p_both(w); else w.hidden += 2;
-      }
-    }
-    if (km_full(w.bm, cfg->gb)) {
-      bool rep = false;
-      if (level == LV_BMER || level == LV_MIXED || level == LV_BMER_UNC) rep = repair_existing(w, i, counts, sym);
-      else if (level == LV_NONE || level == LV_PMER) rep = repair_missing(w, i);
-      if (rep) push_b_local(w);
+      TM_END(w, TM_POST, t_post);
     }
   }
 }
@@ -1115,6 +1282,7 @@ FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev
   WgShared *sm = w.sm;
   const bool orig = cfg->mode == 0;
   // duplicate test + staging of the read's codes in LDS + letter histogram, all lane-parallel
+  TM_BEGIN(t_head);
   bool diff = prev == nullptr || prev_size != size;
   u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0;
   FQ_SYNC();
@@ -1139,6 +1307,7 @@ FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev
   w.cor_pos = 0;
   w.N_run = 0;
   if (orig) prefix_direct(w, p, size); else prefix_sorted(w, p, size);
+  TM_END(w, TM_READ_HEAD, t_head);
   suffix(w, p, size, orig);
   // update_s_letters, dna.cpp:2047-2057 (both strands)
   h0 = wave_sum32(h0); h1 = wave_sum32(h1); h2 = wave_sum32(h2); h3 = wave_sum32(h3);
@@ -1160,6 +1329,8 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.ws = ws;
   w.err = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
+  for (u32 i = 0; i < 8; ++i) w.tm[i] = 0;
+  TM_BEGIN(t_total);
   const u64 T = cfg.T;
   // PartitionForWorkers, reads_block.h:197-214
   u64 first = (u64)tid * n_reads / T, last = ((u64)tid + 1) * n_reads / T;
@@ -1183,6 +1354,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
     for (u32 i = FQ_LANE; i < 256; i += FQ_WAVE) { sm->mail_count[k][i] = 0; sm->mail_tail[k][i] = 0; }
     if (FQ_LANE == 0) sm->mail_nchunks[k] = 0;
   }
+  if (FQ_LANE == 0) sm->lq_n[0] = sm->lq_n[1] = 0;
   FQ_SYNC();
   w.enc.low = ws->rc_low; w.enc.range = ws->rc_range; w.enc.len = ws->out_len;
   w.enc.cap = cfg.out_cap; w.enc.out = cfg.out + (u64)tid * cfg.out_cap;
@@ -1205,6 +1377,8 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
     compress_read(w, cfg.bases + o0, (u32)(o1 - o0), prev, prev_size);
   }
   if (stop > cur) cur = stop;
+  lq_flush(w, 0);  // the insert phase clears the local tables; apply what is still queued first
+  lq_flush(w, 1);
 
   // store state
   ws->cursor = (u32)cur;
@@ -1212,7 +1386,9 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   ws->avg_code = w.avg_code; ws->avg_letters = w.avg_letters;
   for (u32 i = 0; i < 4; ++i) ws->s_letters[i] = w.s_let[i];
   ws->hidden_updates = w.hidden;
+  TM_END(w, TM_TOTAL, t_total);
   for (u32 i = 0; i < ST_N; ++i) ws->stat[i] += w.st[i];
+  for (u32 i = 0; i < 8; ++i) ws->stat[16 + i] += w.tm[i];
   FQ_SYNC();
   for (u32 g = 0; g < 4; ++g) {
     for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) ws->mt[g][i] = sm->mt[g][i];
@@ -1228,6 +1404,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
 // ht_kmer.h:420-438).  Falls back to a serial pass when two keys of the batch interact.
 FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 tid, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
                          u64 &nslots, u32 &err) {
+  (void)cfg;
   u64 *s = t.slots + (u64)tid * t.stride;
   const u64 cm = (1ull << t.cbits) - 1ull;
   const u32 lane = FQ_LANE;
@@ -1284,11 +1461,11 @@ FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 tid
       else if (draw && (r % (ci.mult * (cnt - ci.thr)) == 0)) s[pos] = item + 1;
     }
     if (lane == 0) t.filled[tid] = filled + n_new;
-    FQ_SYNC();
+    FQ_SYNC_MEM();  // later batches of this wave read these slots from other lanes
     return;
   }
   // serial fallback, in key order
-  FQ_SYNC();
+  FQ_SYNC_MEM();
   for (u32 j = 0; j < n; ++j) {
     u64 vj = keys[j] >> (64 - 2 * t.k);
     u64 p = tab_home(t, vj);
@@ -1306,8 +1483,8 @@ FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 tid
       }
       p = (p + 1) & t.cap_mask;
     }
-    FQ_SYNC();
   }
+  FQ_SYNC_MEM();
 }
 
 // owner `tid` applies column `tid` of every mailbox (InsertKmersToHT, dna.cpp:2393-2472)
@@ -1361,7 +1538,7 @@ FQ_DEV void insert_phase_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
       cfg.siv_stats[0] += nu + ws->hidden_updates;
 #endif
     }
-    FQ_SYNC();
+    FQ_SYNC_MEM();
     ws->hidden_updates = 0;
   }
   // s-mers then b-mers
@@ -1376,11 +1553,7 @@ FQ_DEV void insert_phase_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
       for (u32 done = 0; done < cnt && !err; done += FQSX_CHUNK) {
         u32 n = cnt - done < FQSX_CHUNK ? cnt - done : FQSX_CHUNK;
         const u64 *keys = m.pool + ((u64)src * m.pool_chunks + chunk) * FQSX_CHUNK;
-#if FQ_WAVE > 1
-        insert_batch(cfg, sm, t, tid, keys, n, rng, ci, n_slots, err);
-#else
-        for (u32 j = 0; j < n && !err; ++j) insert_batch(cfg, sm, t, tid, keys + j, 1, rng, ci, n_slots, err);
-#endif
+        insert_keys(cfg, sm, t, tid, keys, n, rng, ci, n_slots, err);
         n_ins += n;
         chunk = m.next[(u64)src * m.pool_chunks + chunk];
       }

@@ -16,6 +16,7 @@
 #define FQSX_CHUNK 64u           // mailbox chunk = one wave batch (64 x u64 = 512 B)
 #define FQSX_NIL 0xffffffffu
 #define FQSX_RD_LDS 4096u        // reads up to this length are staged in LDS
+#define FQSX_SPEC 64u            // positions speculated per chunk (one per lane)
 
 // geometry of one rolling k-mer (kmer.h:279-298)
 struct KGeom {
@@ -86,7 +87,7 @@ struct WState {
   u64 out_len;
   u32 mt_idx[4];                       // cinc_b, cinc_s, cinc_lb, cinc_ls (dna.h:113-116)
   u32 mt[4][624];
-  u64 stat[16];                        // probe/byte accounting, see ST_*
+  u64 stat[24];                        // probe/byte accounting, see ST_*; [16..23] in-kernel section times (10 ns ticks)
 };
 enum { RNG_B = 0, RNG_S = 1, RNG_LB = 2, RNG_LS = 3 };
 enum {
@@ -104,6 +105,8 @@ enum {
   ST_BASES,        // input bases consumed
   ST_N
 };
+// section timers (only maintained by -DFQSX_TIMING builds)
+enum { TM_TOTAL = 0, TM_SPEC, TM_FAST, TM_SLOW, TM_POST, TM_READ_HEAD, TM_LQ, TM_N };
 
 struct DevCfg {
   u32 T, mode;                 // mode 0 = original order, 1 = sorted (params.h:18)
@@ -111,6 +114,7 @@ struct DevCfg {
   KGeom gp, gs, gb;
   u32 pmer_mod_shift;          // dna.cpp:2381
   u32 ps_nobytes_n;            // alphabet of prefix_sorted_no_bytes, dna.cpp:130
+  u64 T_magic;                 // ceil(2^32 / T): x % T for x < 2^14 without a division
   u64 *siv;                    // 4^pmer 2-bit counters
   u64 *siv_stats;              // [0] no_updates [1] no_filled (bit_vec.h:25-26)
   KTab g_s, g_b;               // owner-sharded global tables (T sub-tables)

@@ -29,8 +29,12 @@ typedef int32_t i32;
 #define FQ_BLOCK ((u32)blockIdx.x)
 #define FQ_NBLOCKS ((u32)gridDim.x)
 #define FQ_SHARED __shared__
-// single-wave workgroups: a workgroup barrier orders LDS/global traffic between lanes
-#define FQ_SYNC() __syncthreads()
+// Cross-lane hand-off through LDS inside the single wavefront of a workgroup: the LDS queue of one
+// wave is in order, so draining it (and stopping compiler reordering) is all that is needed.  This
+// deliberately does NOT wait for outstanding global stores (a __syncthreads() would: vmcnt(0)).
+#define FQ_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// Full drain: lanes are about to read global memory other lanes of the wave have written.
+#define FQ_SYNC_MEM() __syncthreads()
 
 FQ_DEV u32 wave_sum32(u32 v) {
 #pragma unroll
@@ -53,6 +57,7 @@ FQ_DEV u64 uniform64(u64 v) {
   return ((u64)hi << 32) | lo;
 }
 FQ_DEV u32 popc64(u64 v) { return (u32)__popcll(v); }
+FQ_DEV u64 fq_clock() { return (u64)wall_clock64(); }  // 100 MHz constant clock (s_memrealtime)
 FQ_DEV u64 atomic_cas64(u64 *p, u64 expect, u64 desired) {
   return (u64)atomicCAS((unsigned long long *)p, (unsigned long long)expect, (unsigned long long)desired);
 }
@@ -72,6 +77,7 @@ FQ_DEV double ema_update(double avg, double level) { return __dadd_rn(__dmul_rn(
 #define FQ_NBLOCKS (fq_emu_nblocks)
 #define FQ_SHARED static thread_local
 #define FQ_SYNC() ((void)0)
+#define FQ_SYNC_MEM() ((void)0)
 static thread_local u32 fq_emu_block = 0, fq_emu_nblocks = 1;
 FQ_DEV u32 wave_sum32(u32 v) { return v; }
 FQ_DEV u64 wave_sum64(u64 v) { return v; }
@@ -83,6 +89,7 @@ FQ_DEV u64 wave_bcast64(u64 v, u32) { return v; }
 FQ_DEV u32 uniform32(u32 v) { return v; }
 FQ_DEV u64 uniform64(u64 v) { return v; }
 FQ_DEV u32 popc64(u64 v) { return (u32)__builtin_popcountll(v); }
+FQ_DEV u64 fq_clock() { return 0; }
 FQ_DEV u64 atomic_cas64(u64 *p, u64 expect, u64 desired) {
   u64 old = *p;
   if (old == expect) *p = desired;

@@ -1,0 +1,32 @@
+"""Diagnostic: run the -DFQSX_TIMING build over the first N reads of the bench workload and print
+the in-kernel section times summed over workers (10 ns ticks -> seconds)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.codec import DnaCodec
+from fqsqueezer_amd.synth import synth_reads, read_id
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "tools", "libfqsx_timing.so")
+reads = synth_reads(1000000, 100, 5000000, 2)[:n]
+rec = hp.Records([read_id(i) for i in range(n)], reads, reads)
+header = hp.make_header(T, "se_sorted", 5)
+blocks = hp.form_blocks(rec, "se_sorted")
+c = DnaCodec(header, lib_path=lib)
+c.set_profiling(True)
+t0 = time.time()
+for g, idx in enumerate(blocks):
+    bases, off = hp.block_arrays(rec, idx)
+    c.encode_block(bases, off, g)
+dt = time.time() - t0
+st = c.stats(); kt = c.kernel_times()
+names = ["total", "spec", "fast", "slow", "post", "read_head", "lq_flush", "-"]
+tm = [x * 1e-8 for x in st["timers"]]
+print(f"{n} reads T={T}: wall {dt:.2f}s  {n*100/dt/1e6:.2f} Mbases/s  kernels: {kt}")
+print("section seconds summed over workers:", {k: round(v, 3) for k, v in zip(names, tm)})
+tot = tm[0] or 1
+print("shares of worker time:", {k: round(v / tot, 3) for k, v in zip(names, tm)})
+print({k: v for k, v in st.items() if k != "timers"})
