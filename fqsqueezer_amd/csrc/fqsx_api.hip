@@ -49,27 +49,29 @@ FQ_KERNEL64 void k_finish_block(DevCfg cfg, u64 *lens /*[T+1]*/) {
 }
 // gathers the per-worker accounting counters: out[i] = sum over workers of stat[i]
 FQ_KERNEL64 void k_gather_stats(DevCfg cfg, u64 *out) {
-  for (u32 i = FQ_LANE; i < 24; i += FQ_WAVE) {
+  for (u32 i = FQ_LANE; i < 32; i += FQ_WAVE) {
     u64 s = 0;
     for (u32 t = 0; t < cfg.T; ++t) s += cfg.ws[t].stat[i];
     out[i] = s;
   }
 }
-// owner `blk` demand of the coming insert phase: entries addressed to it, per table
-FQ_KERNEL64 void k_phase_demand(DevCfg cfg, u32 *demand /*[2][T]*/) {
-  const u32 tid = FQ_BLOCK, T = cfg.T;
-  u32 s = 0, b = 0;
-  for (u32 src = FQ_LANE; src < T; src += FQ_WAVE) {
-    s += cfg.mail[MAIL_S].count[(u64)src * T + tid];
-    b += cfg.mail[MAIL_B].count[(u64)src * T + tid];
-  }
-  s = wave_sum32(s);
-  b = wave_sum32(b);
-  if (FQ_LANE == 0) {
-    demand[tid] = s;
-    demand[T + tid] = b;
-    if (tid == 0) demand[2 * T] = *cfg.err;
-  }
+// stable partition of the mailbox lists by owner (count -> scan -> group offsets -> scatter)
+FQ_KERNEL64 void k_part_count(DevCfg cfg, u32 kind) {
+  FQ_SHARED u32 hist[256];
+  part_count_body(cfg, kind, FQ_BLOCK, hist);
+}
+FQ_KERNEL64 void k_part_scan(DevCfg cfg, u32 kind) { part_scan_body(cfg, kind, FQ_BLOCK); }
+FQ_KERNEL64 void k_part_dstoff(DevCfg cfg, u32 *demand /*[2][T]+1*/) {
+  part_dstoff_body(cfg, FQ_BLOCK);
+  // per-owner demand of the coming insert phase (s- and b-mers) + the device error word
+  if (FQ_BLOCK != MAIL_P)
+    for (u32 d = FQ_LANE; d < cfg.T; d += FQ_WAVE) demand[(FQ_BLOCK == MAIL_S ? 0 : cfg.T) + d] = cfg.mail[FQ_BLOCK].dst_tot[d];
+  if (FQ_BLOCK == 0 && FQ_LANE == 0) demand[2 * cfg.T] = *cfg.err;
+}
+FQ_KERNEL64 void k_part_scatter(DevCfg cfg, u32 kind) {
+  FQ_SHARED u32 cursor[256];
+  FQ_SHARED u32 ld[64];
+  part_scatter_body(cfg, kind, FQ_BLOCK, cursor, ld);
 }
 // re-insert every occupied slot of `o` into the (empty, larger) table `n`; layout-free, so parallel
 FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub) {
@@ -145,7 +147,7 @@ struct fqsx_dna {
   u64 k_n[3];
   // capacities (host mirror)
   u64 gs_cap, gb_cap, ls_cap, lb_cap, ctx_cap, out_cap;
-  u32 pool_chunks[3];
+  u32 mail_cap[3];
   u64 dev_bases_cap, dev_off_cap;
   u8 *d_bases;
   u64 *d_off;
@@ -323,18 +325,22 @@ int grow_ctx(fqsx_dna *c, u64 new_cap) {
   return FQSX_OK;
 }
 
-int mail_alloc(fqsx_dna *c, u32 kind, u32 chunks) {
+int mail_alloc(fqsx_dna *c, u32 kind, u32 cap) {
   Mail &m = c->cfg.mail[kind];
-  if (m.pool) { dfree(c, m.pool); dfree(c, m.next); }
+  const u32 T = c->T;
+  if (m.list) { dfree(c, m.list); dfree(c, m.sorted); dfree(c, m.tile_hist); }
+  cap = (cap + FQSX_TILE - 1) / FQSX_TILE * FQSX_TILE;
   void *p = nullptr;
-  int rc = dalloc(c, &p, (u64)c->T * chunks * FQSX_CHUNK * sizeof(u64), false);
-  if (rc) return rc;
-  m.pool = (u64 *)p;
-  rc = dalloc(c, &p, (u64)c->T * chunks * sizeof(u32), false);
-  if (rc) return rc;
-  m.next = (u32 *)p;
-  m.pool_chunks = chunks;
-  c->pool_chunks[kind] = chunks;
+  int rc;
+  if ((rc = dalloc(c, &p, (u64)T * cap * sizeof(u64), false))) return rc;
+  m.list = (u64 *)p;
+  if ((rc = dalloc(c, &p, (u64)T * cap * sizeof(u64), false))) return rc;
+  m.sorted = (u64 *)p;
+  m.cap = cap;
+  m.n_tiles = cap / FQSX_TILE;
+  if ((rc = dalloc(c, &p, (u64)T * m.n_tiles * T * sizeof(u32), false))) return rc;
+  m.tile_hist = (u32 *)p;
+  c->mail_cap[kind] = cap;
   return FQSX_OK;
 }
 
@@ -380,8 +386,8 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
   }
   const u64 mail_entries[3] = {2 * max_seg_bases + 2 * max_seg_reads, max_seg_bases, 2 * max_seg_bases};
   for (u32 k = 0; k < 3; ++k) {
-    u64 chunks = mail_entries[k] / FQSX_CHUNK + T + 2;
-    if (chunks > c->pool_chunks[k] && (rc = mail_alloc(c, k, (u32)(chunks + chunks / 4)))) return rc;
+    u64 need = mail_entries[k] + 64;
+    if (need > c->mail_cap[k] && (rc = mail_alloc(c, k, (u32)(need + need / 4)))) return rc;
   }
   u64 need_lb = pow2_at_least(4 * max_seg_bases + 64), need_ls = pow2_at_least(2 * max_seg_bases + 64);
   if (need_lb > c->lb_cap) {
@@ -410,7 +416,9 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
   for (u32 seg = 0; seg <= (u32)S; ++seg) {
     LAUNCH(c, 0, k_encode_segment, T, 64, cfg, n_reads, (u32)S, seg);
     // size the global tables for this phase's inserts (exact per-owner demand)
-    LAUNCH(c, 2, k_phase_demand, T, 64, cfg, c->d_demand);
+    for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_count, T * cfg.mail[k].n_tiles, 64, cfg, k);
+    for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_scan, T, 64, cfg, k);
+    LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand);
     if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, (2 * T + 1) * sizeof(u32)))) return rc;
     if (c->h_demand[2 * T]) {
       g_err = "device error " + std::to_string(c->h_demand[2 * T]) + " in encode kernel";
@@ -424,6 +432,7 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
       for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_filled[o] + c->h_demand[which * T + o]);
       if (need * 2 > cap && (rc = grow_global(c, t, cap, pow2_at_least(need * 2 + 2)))) return rc;
     }
+    for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_scatter, T * cfg.mail[k].n_tiles, 64, cfg, k);
     LAUNCH(c, 1, k_insert_phase, T, 64, cfg);
     // ClearKmersToHT, dna.cpp:2475-2488 (mailbox counters are rewritten by the next encode launch)
     if ((rc = dzero(c, cfg.l_b.slots, need_lb * T * sizeof(u64)))) return rc;
@@ -538,21 +547,23 @@ int create_impl(fqsx_dna *c, const u8 *h) {
 #endif
   }
   for (u32 k = 0; k < 3; ++k) {
-    if ((rc = dalloc(c, &p, (u64)T * T * sizeof(u32), true))) return rc;
-    cfg.mail[k].head = (u32 *)p;
-    if ((rc = dalloc(c, &p, (u64)T * T * sizeof(u32), true))) return rc;
-    cfg.mail[k].count = (u32 *)p;
-    if ((rc = mail_alloc(c, k, T + 64))) return rc;
+    if ((rc = dalloc(c, &p, (u64)T * sizeof(u32), true))) return rc;
+    cfg.mail[k].n = (u32 *)p;
+    if ((rc = dalloc(c, &p, (u64)T * sizeof(u32), true))) return rc;
+    cfg.mail[k].dst_tot = (u32 *)p;
+    if ((rc = dalloc(c, &p, ((u64)T + 1) * sizeof(u32), true))) return rc;
+    cfg.mail[k].dst_off = (u32 *)p;
+    if ((rc = mail_alloc(c, k, FQSX_TILE))) return rc;
   }
   if ((rc = dalloc(c, &p, sizeof(u32) * 4, true))) return rc;
   cfg.err = (u32 *)p;
   if ((rc = dalloc(c, &p, (2 * (u64)T + 1) * sizeof(u32), true))) return rc;
   c->d_demand = (u32 *)p;
-  if ((rc = dalloc(c, &p, ((u64)T + 32) * sizeof(u64), true))) return rc;
+  if ((rc = dalloc(c, &p, ((u64)T + 48) * sizeof(u64), true))) return rc;
   c->d_lens = (u64 *)p;
   c->h_demand.assign(2 * T + 1, 0);
   c->h_filled.assign(T, 0);
-  c->h_lens.assign(T + 32, 0);
+  c->h_lens.assign(T + 48, 0);
 #ifndef FQSX_EMU
   HIPCHK(hipStreamSynchronize(c->stream));
 #endif
@@ -591,7 +602,7 @@ int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) {
   c->k_ms[0] = c->k_ms[1] = c->k_ms[2] = 0;
   c->k_n[0] = c->k_n[1] = c->k_n[2] = 0;
   c->out_cap = 0;
-  c->pool_chunks[0] = c->pool_chunks[1] = c->pool_chunks[2] = 0;
+  c->mail_cap[0] = c->mail_cap[1] = c->mail_cap[2] = 0;
   c->dev_bases_cap = c->dev_off_cap = 0;
   c->d_bases = nullptr;
   c->d_off = nullptr;
@@ -660,10 +671,10 @@ int fqsx_dna_encode_block(fqsx_dna *c, const uint8_t *bases, const uint64_t *off
   return encode_block_impl(c, c->d_bases, c->d_off, off, n_reads, generation, streams, lens);
 }
 
-int fqsx_dna_stats(fqsx_dna *c, uint64_t out[24]) {
+int fqsx_dna_stats(fqsx_dna *c, uint64_t out[32]) {
   if (!c || !out) return FQSX_E_ARG;
   LAUNCH(c, 2, k_gather_stats, 1, 64, c->cfg, c->d_lens + c->T);
-  return d2h_sync(c, out, c->d_lens + c->T, 24 * sizeof(u64));
+  return d2h_sync(c, out, c->d_lens + c->T, 32 * sizeof(u64));
 }
 
 int fqsx_dna_set_profiling(fqsx_dna *c, int enable) {

@@ -11,23 +11,27 @@
 struct WgShared {
   u32 mt[4][624];              // MT19937 states of cinc_b, cinc_s, cinc_lb, cinc_ls
   u32 mt_idx[4];
-  u32 mail_count[3][256];      // entries pushed per destination in this phase
-  u32 mail_tail[3][256];       // current chunk per destination
-  u32 mail_nchunks[3];
   u8 rd[FQSX_RD_LDS];          // 2-bit codes (0..4) of the current read
   u64 bk_key[256];             // probe batch: normalised k-mers
   u32 bk_res[256][4];          // probe batch: counts
   u8 bk_dir[256];              // probe batch: orientation
-  // speculation chunk: results of the lane-parallel b-mer probe + context-key stage
-  u64 sp_dir[FQSX_SPEC];       // corrected b-mer (dir word, last symbol open) the entry was computed for
+  // speculation chunk (stage P): everything about positions i0..i0+63 that does not depend on the
+  // adaptive models, computed one position per lane under the assumption "no k-mer correction
+  // inside the chunk" (a correction ends the chunk, so the assumption holds for what is used)
+  u64 sp_sdir[6][FQSX_SPEC];   // rolled k-mers after insert_zero: pm, sm, bm, pm_u, sm_u, bm_u
+  u64 sp_src[6][FQSX_SPEC];
+  u8 sp_scur[6][FQSX_SPEC];
   u64 sp_key[FQSX_SPEC][7];    // context keys of the 7 levels (r_sym field left 0)
   u32 sp_cnt[FQSX_SPEC];       // 4 x 8-bit counts
-  u8 sp_flag[FQSX_SPEC];       // 0 none, 1 b-mer hit (fast path), 2 hit but >1 saturated counter, 3 known miss
+  u8 sp_flag[FQSX_SPEC];       // 0 slow path, 1 b-mer hit (fast path), 3 slow path with known global b-mer miss
   u8 sp_rsym[FQSX_SPEC];       // rank of the read's symbol under those counts
-  // deferred inserts into the worker-private local tables (flushed in order before any local look-up)
-  u64 lq_key[2][64];
-  u32 lq_n[2];
+  u8 sp_rep[FQSX_SPEC];        // fast path: symbol repair_kmers_existing substitutes, or 0xff
+  u8 sp_nrun[FQSX_SPEC];       // N_run_len before the position
+  // mailbox entries of the chunk's positions (stage Q appends them lane-parallel)
+  u64 pv_b[FQSX_SPEC], pv_s[FQSX_SPEC], pv_pd[FQSX_SPEC], pv_pr[FQSX_SPEC];
+  u8 pv_flag[FQSX_SPEC];       // PV_* bits
 };
+enum { PV_B = 1, PV_S = 2, PV_P = 4, PV_PHID = 8, PV_PCAND = 16 };
 
 struct C4 { u32 c[4]; };
 struct Kmer { u64 dir, rc; u32 cur; };
@@ -46,16 +50,21 @@ struct Wk {
   u64 s_let[4];
   double avg_code, avg_letters;
   u64 hidden;
+  bool repm_gate;                       // siv avg_filling_factor() >= 7 (constant within a segment)
+  u32 mn[3];                            // entries appended to this worker's p/s/b mailbox lists
+  u32 la[3];                            // list entries already applied to the local tables (b, s)
   u64 st[ST_N];
-  u64 tm[8];
+  u64 tm[16];
   u32 err;
 };
 #ifdef FQSX_TIMING
 #define TM_BEGIN(v) u64 v = fq_clock()
 #define TM_END(w, slot, v) (w).tm[slot] += fq_clock() - (v)
+#define TM_COUNT(w, slot) (w).tm[slot] += 1
 #else
 #define TM_BEGIN(v) ((void)0)
 #define TM_END(w, slot, v) ((void)0)
+#define TM_COUNT(w, slot) ((void)0)
 #endif
 
 #define CINC_B (Cinc{7u, 2u, 63u})            /* dna.cpp:162,164 */
@@ -184,6 +193,26 @@ FQ_DEV void km_replace_last(Kmer &k, u64 sym) {  // kmer.h:163-169,181-185
   k.dir = (k.dir & ~(3ull << sh)) + (sym << sh);
   k.rc = ((k.rc << 2) >> 2) + ((3 - sym) << 62);
 }
+// k-mer `b` after inserting j further symbols (kmer.h:80-96 applied j times).  fw / rv hold the last
+// L = min(j,27) of them: fw packed oldest-first, rv = their complements packed newest-first.
+FQ_DEV Kmer km_roll(const Kmer &b, const KGeom &g, u32 j, u64 fw, u64 rv, u32 L) {
+  if (j == 0) return b;
+  Kmer r;
+  const u32 k = g.k;
+  u32 tot = b.cur + j;
+  r.cur = tot < k ? tot : k;
+  if (j >= k) {  // the k-mer consists of new symbols only (L >= k here)
+    r.dir = (fw & ((1ull << (2 * k)) - 1ull)) << g.shift;
+    r.rc = (rv >> (2 * (L - k))) << g.shift;   // newest k symbols sit at the top of rv
+  } else {       // L == j < k: old symbols survive
+    u64 old = b.cur ? b.dir >> (64 - 2 * b.cur) : 0;                    // right-aligned old symbols
+    u32 keep = r.cur - j;                                               // old symbols still inside
+    old &= (1ull << (2 * keep)) - 1ull;
+    r.dir = ((old << (2 * j)) | fw) << (64 - 2 * r.cur);
+    r.rc = ((rv << (64 - 2 * j)) | (b.rc >> (2 * j))) & g.mask;
+  }
+  return r;
+}
 FQ_DEV bool km_norm_dir(const Kmer &k, const KGeom &g) { return (k.dir & g.kernel_mask) < (k.rc & g.kernel_mask); }
 FQ_DEV u64 km_norm(const Kmer &k, const KGeom &g) { return km_norm_dir(k, g) ? k.dir : k.rc; }
 FQ_DEV u64 km_aligned_dir(const Kmer &k) { return k.cur ? k.dir >> (64 - 2 * k.cur) : 0; }  // kmer.h:398 (quirk 18)
@@ -285,6 +314,21 @@ FQ_DEV void batch_scan(Wk &w, const KTab &t, bool global, u32 n) {
   w.st[global ? ST_GPROBE : ST_LPROBE] += n;
   w.st[global ? ST_GSLOT : ST_LSLOT] += wave_sum64(ns);
 }
+// bit q of mask[q/64] = probe q of the batch returned a non-zero count
+FQ_DEV void batch_hit_mask(Wk &w, u32 n, u64 mask[4]) {
+  WgShared *sm = w.sm;
+  mask[0] = mask[1] = mask[2] = mask[3] = 0;
+#if FQ_WAVE > 1
+  for (u32 r = 0; r * 64 < n; ++r) {
+    u32 q = r * 64 + FQ_LANE;
+    bool hit = q < n && (sm->bk_res[q][0] | sm->bk_res[q][1] | sm->bk_res[q][2] | sm->bk_res[q][3]) != 0;
+    mask[r] = wave_ballot(hit);
+  }
+#else
+  for (u32 q = 0; q < n; ++q)
+    if (sm->bk_res[q][0] | sm->bk_res[q][1] | sm->bk_res[q][2] | sm->bk_res[q][3]) mask[q >> 6] |= 1ull << (q & 63);
+#endif
+}
 FQ_DEV void batch_count(Wk &w, const KTab &t, u32 n) {  // exact counts of the batch keys (global table)
   WgShared *sm = w.sm;
   u64 ns = 0;
@@ -309,35 +353,24 @@ FQ_DEV void insert_keys(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 sub,
   for (u32 j = 0; j < n && !err; ++j) insert_batch(cfg, sm, t, sub, keys + j, 1, rng, ci, nslots, err);
 #endif
 }
-// Deferred local-table inserts (ht_*_local->insert, dna.cpp:826,839,861,872): queued in LDS in program
-// order and applied as one lane-parallel batch before the next local look-up, so the tables always
-// hold exactly what the sequential algorithm would have inserted by then.
-FQ_DEV void lq_flush(Wk &w, u32 which) {
-  WgShared *sm = w.sm;
-  u32 n = sm->lq_n[which];
-  if (!n) return;
+// Local-table inserts (ht_*_local->insert, dna.cpp:826,839,861,872) are deferred: every b-/s-mer a
+// worker pushes to its mailbox list is also a local insert, so the not-yet-applied tail of the
+// list is the pending queue.  It is applied as lane-parallel batches, in order, before the next
+// local look-up, so the tables always hold exactly what the sequential algorithm would have.
+FQ_DEV void lq_flush(Wk &w, u32 kind) {
+  const Mail &m = w.cfg->mail[kind];
+  u32 a = w.la[kind], n = w.mn[kind];
+  if (a >= n) return;
   TM_BEGIN(t_lq);
   u64 ns = 0;
   u32 err = 0;
-  insert_keys(*w.cfg, sm, which ? w.cfg->l_s : w.cfg->l_b, w.tid, sm->lq_key[which], n, which ? RNG_LS : RNG_LB,
-              which ? CINC_S : CINC_B, ns, err);
-  FQ_SYNC();
-  if (FQ_LANE == 0) sm->lq_n[which] = 0;
-  FQ_SYNC();
+  FQ_SYNC_MEM();  // the list entries were written by other lanes
+  insert_keys(*w.cfg, w.sm, kind == MAIL_S ? w.cfg->l_s : w.cfg->l_b, w.tid, m.list + (u64)w.tid * m.cap + a, n - a,
+              kind == MAIL_S ? RNG_LS : RNG_LB, kind == MAIL_S ? CINC_S : CINC_B, ns, err);
+  w.la[kind] = n;
+  w.st[ST_LINS] += n - a;
   if (err) w.err = FQSX_ERR_LTAB_FULL;
   TM_END(w, TM_LQ, t_lq);
-}
-FQ_DEV void lq_push(Wk &w, u32 which, u64 key) {
-  WgShared *sm = w.sm;
-  u32 n = sm->lq_n[which];
-  FQ_SYNC();
-  if (FQ_LANE == 0) {
-    sm->lq_key[which][n] = key;
-    sm->lq_n[which] = n + 1;
-  }
-  FQ_SYNC();
-  w.st[ST_LINS] += 1;
-  if (n + 1 == 64) lq_flush(w, which);
 }
 
 // find / find_full / find_partial (ht_kmer.h:189-203,266-327,504-510)
@@ -373,10 +406,15 @@ FQ_DEV bool kt_find(Wk &w, const KTab &t, bool global, const KGeom &g, const Kme
       sm->bk_dir[i] = nd ? 1 : 0;
     }
     batch_scan(w, t, global, n);
-    for (u32 i = 0; i < n; ++i)
-      for (u32 s = 0; s < 4; ++s) {
-        u32 loc = sm->bk_res[i][s];
-        if (loc) out.c[s] = cinc_merge(sm, rng, ci, out.c[s], loc);  // ht_kmer.h:321-323
+    u64 hm[4];
+    batch_hit_mask(w, n, hm);
+    for (u32 r = 0; r < 4; ++r)
+      for (u64 mk = hm[r]; mk; mk &= mk - 1) {  // trials in order, only those that found something
+        u32 i = r * 64 + ctz64(mk);
+        for (u32 s = 0; s < 4; ++s) {
+          u32 loc = sm->bk_res[i][s];
+          if (loc) out.c[s] = cinc_merge(sm, rng, ci, out.c[s], loc);  // ht_kmer.h:321-323
+        }
       }
   }
   return c4_any(out);
@@ -830,29 +868,14 @@ FQ_DEV void ctx_letters_keys(u64 a[10], const DevCfg *cfg, u32 pos, u64 letters,
 #define TPL_LET_TOT 41u
 
 // ---------------------------------------------------------------------------------------
-// mailboxes (my_*_to_add push_back, dna.cpp:657-660,818-852)
-FQ_DEV void mail_push(Wk &w, u32 kind, u32 dst, u64 x) {
-  WgShared *sm = w.sm;
+// mailboxes (my_*_to_add push_back, dna.cpp:657-660,818-852): append in push order; the owner is
+// derived from the key by the partition kernels
+FQ_DEV void mail_push(Wk &w, u32 kind, u64 x) {
   const Mail &m = w.cfg->mail[kind];
-  u32 c = sm->mail_count[kind][dst];
-  u32 tail = sm->mail_tail[kind][dst];
-  u32 slot = c & (FQSX_CHUNK - 1);
-  FQ_SYNC();
-  if (slot == 0) {  // open a new chunk of this (src,dst) chain
-    u32 id = sm->mail_nchunks[kind];
-    if (id >= m.pool_chunks) { w.err = FQSX_ERR_MAIL_FULL; return; }
-    u64 pc = (u64)w.tid * m.pool_chunks;
-    m.next[pc + id] = FQSX_NIL;
-    if (c == 0) m.head[(u64)w.tid * w.cfg->T + dst] = id; else m.next[pc + tail] = id;
-    tail = id;
-    if (FQ_LANE == 0) {
-      sm->mail_nchunks[kind] = id + 1;
-      sm->mail_tail[kind][dst] = id;
-    }
-  }
-  m.pool[((u64)w.tid * m.pool_chunks + tail) * FQSX_CHUNK + slot] = x;
-  if (FQ_LANE == 0) sm->mail_count[kind][dst] = c + 1;
-  FQ_SYNC();
+  u32 c = w.mn[kind];
+  if (c >= m.cap) { w.err = FQSX_ERR_MAIL_FULL; return; }
+  m.list[(u64)w.tid * m.cap + c] = x;
+  w.mn[kind] = c + 1;
   w.st[ST_MAIL] += 1;
 }
 
@@ -928,15 +951,17 @@ FQ_DEV bool rough_kt(Wk &w, const KTab &t, const KGeom &g, const Kmer &can, u32 
     sm->bk_dir[q] = nd ? 1 : 0;
   }
   batch_scan(w, t, true, n);
-  for (u32 q = 0; q < n; ++q) {
-    u32 l0 = sm->bk_res[q][0], l1 = sm->bk_res[q][1], l2 = sm->bk_res[q][2], l3 = sm->bk_res[q][3];
-    if (l0 | l1 | l2 | l3) {  // merges all four counters, zeros included (dna.cpp:324-326)
-      counts.c[0] = cinc_merge(sm, rng, ci, counts.c[0], l0);
-      counts.c[1] = cinc_merge(sm, rng, ci, counts.c[1], l1);
-      counts.c[2] = cinc_merge(sm, rng, ci, counts.c[2], l2);
-      counts.c[3] = cinc_merge(sm, rng, ci, counts.c[3], l3);
+  u64 hm[4];
+  batch_hit_mask(w, n, hm);
+  for (u32 r = 0; r < 4; ++r)
+    for (u64 mk = hm[r]; mk; mk &= mk - 1) {  // probes in order, only those that found something
+      u32 q = r * 64 + ctz64(mk);
+      // merges all four counters, zeros included (dna.cpp:324-326)
+      counts.c[0] = cinc_merge(sm, rng, ci, counts.c[0], sm->bk_res[q][0]);
+      counts.c[1] = cinc_merge(sm, rng, ci, counts.c[1], sm->bk_res[q][1]);
+      counts.c[2] = cinc_merge(sm, rng, ci, counts.c[2], sm->bk_res[q][2]);
+      counts.c[3] = cinc_merge(sm, rng, ci, counts.c[3], sm->bk_res[q][3]);
     }
-  }
   return c4_any(counts);
 }
 
@@ -958,14 +983,14 @@ FQ_DEV u32 find_counts(Wk &w, C4 &counts, bool b_miss_known) {
       }
       return LV_BMER;
     } else {
-      lq_flush(w, 0);
+      lq_flush(w, MAIL_B);
       if (kt_find(w, cfg->l_b, false, cfg->gb, w.bm, RNG_LB, CINC_B, counts)) return LV_BMER;
       if (w.bm.dir != w.bm_u.dir && kt_find(w, cfg->g_b, true, cfg->gb, w.bm_u, RNG_B, CINC_B, counts)) return LV_BMER_UNC;
     }
   }
   if (km_almost_full(w.sm_, cfg->gs, smargin)) {
     if (kt_find(w, cfg->g_s, true, cfg->gs, w.sm_, RNG_S, CINC_S, counts)) return LV_SMER;
-    lq_flush(w, 1);
+    lq_flush(w, MAIL_S);
     if (kt_find(w, cfg->l_s, false, cfg->gs, w.sm_, RNG_LS, CINC_S, counts)) return LV_SMER;
   } else if (find_counts_p(w, counts))
     return LV_PMER;
@@ -988,9 +1013,7 @@ FQ_DEV bool repair_existing(Wk &w, u32 pos, const C4 &counts, u32 sym) {  // rep
 FQ_DEV bool repair_missing(Wk &w, u32 pos) {  // repair_kmers_missing, dna.cpp:374-454
   const DevCfg *cfg = w.cfg;
   WgShared *sm = w.sm;
-  u64 nu = cfg->siv_stats[0], nf = cfg->siv_stats[1];
-  double aff = nf ? (double)nu / (double)nf : 0.0;  // avg_filling_factor, bit_vec.h:204-210
-  if (aff < 7.0) return false;
+  if (!w.repm_gate) return false;  // siv_pmer->avg_filling_factor() < 7.0, dna.cpp:376
   // 5 positions x 4 symbols; the entries equal to the current symbol are skipped
   FQ_SYNC();
   for (u32 q = FQ_LANE; q < 20; q += FQ_WAVE) {
@@ -1031,15 +1054,12 @@ FQ_DEV void code_letter(Wk &w, u32 pos, u32 sym, u32 read_len) {  // dna.cpp:520
 FQ_DEV u16 *small_base(Wk &w) { return w.cfg->small + (u64)w.tid * SM_TOTAL_U16; }
 
 FQ_DEV void push_p_both(Wk &w) {
-  u64 x = km_aligned_dir(w.pm);
-  mail_push(w, MAIL_P, p_owner(w.cfg, x), x);
-  x = km_aligned_rc(w.pm);
-  mail_push(w, MAIL_P, p_owner(w.cfg, x), x);
+  mail_push(w, MAIL_P, km_aligned_dir(w.pm));
+  mail_push(w, MAIL_P, km_aligned_rc(w.pm));
 }
 FQ_DEV void push_b_local(Wk &w) {
   u64 x = km_norm(w.bm, w.cfg->gb);
-  mail_push(w, MAIL_B, sb_owner(w.cfg, x), x);
-  lq_push(w, 0, x);
+  mail_push(w, MAIL_B, x);
 }
 
 FQ_DEV void insert_all(Wk &w, u64 sym) {
@@ -1114,12 +1134,10 @@ FQ_DEV void prefix_sorted(Wk &w, const u8 *p, u32 size) {  // compress_prefix_so
   push_p_both(w);
 }
 
-// Speculation stage of one chunk of <= 64 suffix positions (one per lane): assuming no k-mer
-// correction happens inside the chunk, lane j rolls the corrected b-mer forward to position i0+j,
-// probes the global b-mer table and -- on a plain hit -- derives everything that depends only on
-// (counts, position, symbol): the 7 context keys and the symbol's rank.  The commit loop uses an
-// entry only if the b-mer it was computed for equals the actual one, so a wrong guess is a cache
-// miss, never a wrong result.
+// Stage P of one chunk of <= 64 suffix positions (one per lane).  Lane j rolls the six k-mers
+// forward to position i0+j, probes the global b-mer table and -- on a plain hit -- derives everything
+// that depends only on (counts, position, symbol): the 7 context keys, the symbol's rank, the
+// repair decision; it also prepares the position's mailbox entries.
 FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n) {
   const DevCfg *cfg = w.cfg;
   WgShared *sm = w.sm;
@@ -1127,27 +1145,47 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n) {
   u32 np = 0;
   FQ_SYNC();
   for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
-    Kmer b = w.bm;
-    for (u32 s = 0; s < j; ++s) {
-      u32 c = rd_sym(w, p, i0 + s, size);
-      km_insert(b, cfg->gb, c == 4 ? 0 : c);
+    // roll the six k-mers j symbols forward in closed form: only the last min(j, k) new symbols matter
+    u64 fw = 0, rv = 0;   // new symbols packed oldest-first (fw) and complemented newest-first (rv)
+    const u32 L = j < 27 ? j : 27;
+    for (u32 s = 0; s < L; ++s) {
+      u32 c = rd_sym(w, p, i0 + j - L + s, size);
+      u64 ck = c == 4 ? 0 : c;
+      fw = (fw << 2) | ck;
+      rv |= (3 - ck) << (2 * s);
     }
-    km_insert_zero(b, cfg->gb);
-    u32 flag = 0;
-    if (b.cur == cfg->gb.k) {
-      bool nd = km_norm_dir(b, cfg->gb);
-      u64 key = nd ? b.dir : b.rc;
-      C4 c;
-      c4_zero(c);
+    u32 nrun = 0;
+    {
+      u32 s = j;
+      while (s > 0 && rd_sym(w, p, i0 + s - 1, size) == 4) { --s; ++nrun; }
+      if (s == 0) nrun += w.N_run;
+    }
+    Kmer pm = km_roll(w.pm, cfg->gp, j, fw, rv, L), sk = km_roll(w.sm_, cfg->gs, j, fw, rv, L), bm = km_roll(w.bm, cfg->gb, j, fw, rv, L);
+    Kmer pu = km_roll(w.pm_u, cfg->gp, j, fw, rv, L), su = km_roll(w.sm_u, cfg->gs, j, fw, rv, L), bu = km_roll(w.bm_u, cfg->gb, j, fw, rv, L);
+    km_insert_zero(pm, cfg->gp); km_insert_zero(sk, cfg->gs); km_insert_zero(bm, cfg->gb);
+    km_insert_zero(pu, cfg->gp); km_insert_zero(su, cfg->gs); km_insert_zero(bu, cfg->gb);
+    sm->sp_sdir[0][j] = pm.dir; sm->sp_src[0][j] = pm.rc; sm->sp_scur[0][j] = (u8)pm.cur;
+    sm->sp_sdir[1][j] = sk.dir; sm->sp_src[1][j] = sk.rc; sm->sp_scur[1][j] = (u8)sk.cur;
+    sm->sp_sdir[2][j] = bm.dir; sm->sp_src[2][j] = bm.rc; sm->sp_scur[2][j] = (u8)bm.cur;
+    sm->sp_sdir[3][j] = pu.dir; sm->sp_src[3][j] = pu.rc; sm->sp_scur[3][j] = (u8)pu.cur;
+    sm->sp_sdir[4][j] = su.dir; sm->sp_src[4][j] = su.rc; sm->sp_scur[4][j] = (u8)su.cur;
+    sm->sp_sdir[5][j] = bu.dir; sm->sp_src[5][j] = bu.rc; sm->sp_scur[5][j] = (u8)bu.cur;
+    sm->sp_nrun[j] = (u8)(nrun > 255 ? 255 : nrun);
+    const u32 i = i0 + j, sym = rd_sym(w, p, i, size);
+    const u64 symk = sym == 4 ? 0 : sym;
+    u32 flag = 0, rep = 0xff;
+    C4 c;
+    c4_zero(c);
+    const bool b_full = bm.cur == cfg->gb.k;
+    if (b_full) {
+      bool nd = km_norm_dir(bm, cfg->gb);
+      u64 key = nd ? bm.dir : bm.rc;
       tab_scan(cfg->g_b, sb_owner(cfg, key), key, nd, c, ns);
       ++np;
-      sm->sp_dir[j] = b.dir;
       if (c4_any(c)) {
         u32 sat = (c.c[0] == 63) + (c.c[1] == 63) + (c.c[2] == 63) + (c.c[3] == 63);
-        if (sat > 1) flag = 2;
-        else {
+        if (sat <= 1 && nrun < 2) {
           flag = 1;
-          u32 i = i0 + j, sym = rd_sym(w, p, i, size);
           int cor_dist = (int)cfg->bmer, d = (int)i - (int)w.cor_pos;
           u32 cz = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
           u64 lev[7];
@@ -1155,46 +1193,115 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n) {
           for (u32 l = 0; l < 7; ++l) sm->sp_key[j][l] = lev[l];
           sm->sp_cnt[j] = c.c[0] | (c.c[1] << 8) | (c.c[2] << 16) | (c.c[3] << 24);
           sm->sp_rsym[j] = (u8)rank_sym(w, c, sym);
+          // repair_kmers_existing decision (dna.cpp:333-360)
+          u32 mx = let_max(c, w.s_let);
+          if (sym == 4 || (mx != sym && c4_get(c, sym) == 0 && c4_get(c, mx) > 3)) rep = mx;
         }
       } else
         flag = 3;
     }
     sm->sp_flag[j] = (u8)flag;
+    sm->sp_rep[j] = (u8)rep;
+    // mailbox entries of this position (dna.cpp:818-852), k-mers after replace_last(sym)
+    km_replace_last(pm, symk); km_replace_last(sk, symk); km_replace_last(bm, symk);
+    u32 pf = 0;
+    if (sym < 4) {
+      if (b_full) pf |= PV_B;
+      if (sk.cur == cfg->gs.k) pf |= PV_S;
+      if (pm.cur == cfg->gp.k && i - w.cor_pos >= cfg->pmer - 1) {
+        pf |= PV_PCAND;
+        if (flag == 1) pf |= (b_full && c4_get(c, sym) >= 3) ? PV_PHID : PV_P;
+      }
+    }
+    sm->pv_b[j] = km_norm(bm, cfg->gb);
+    sm->pv_s[j] = km_norm(sk, cfg->gs);
+    sm->pv_pd[j] = km_aligned_dir(pm);
+    sm->pv_pr[j] = km_aligned_rc(pm);
+    sm->pv_flag[j] = (u8)pf;
   }
   FQ_SYNC();
   w.st[ST_GPROBE] += wave_sum32(np);
   w.st[ST_GSLOT] += wave_sum64(ns);
 }
 
-FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {  // compress_suffix, dna.cpp:674-877
+// Stage Q: append the mailbox entries of chunk positions [a,b) to this worker's lists, lane-parallel,
+// in position order (b-mers, s-mers; two p-mer entries per position: direct then rc)
+FQ_DEV void flush_pushes(Wk &w, u32 a, u32 b) {
+  if (a >= b) return;
+  TM_BEGIN(t_q);
   const DevCfg *cfg = w.cfg;
   WgShared *sm = w.sm;
-  C4 counts;
-  c4_zero(counts);
+  const Mail &mb = cfg->mail[MAIL_B], &ms = cfg->mail[MAIL_S], &mp = cfg->mail[MAIL_P];
+  FQ_SYNC();
+  for (u32 base = a; base < b; base += FQ_WAVE) {
+    const u32 t = base + FQ_LANE;
+    const u32 f = t < b ? sm->pv_flag[t] : 0;
+    const u32 nb = f & PV_B ? 1u : 0u, nsm = f & PV_S ? 1u : 0u, npm = f & PV_P ? 2u : 0u, nh = f & PV_PHID ? 2u : 0u;
+    const u32 ob = wave_excl_scan32(nb), os = wave_excl_scan32(nsm), op = wave_excl_scan32(npm);
+    const u32 tb = wave_sum32(nb), ts = wave_sum32(nsm), tp = wave_sum32(npm);
+    if (w.mn[MAIL_B] + tb > mb.cap || w.mn[MAIL_S] + ts > ms.cap || w.mn[MAIL_P] + tp > mp.cap) { w.err = FQSX_ERR_MAIL_FULL; return; }
+    if (nb) mb.list[(u64)w.tid * mb.cap + w.mn[MAIL_B] + ob] = sm->pv_b[t];
+    if (nsm) ms.list[(u64)w.tid * ms.cap + w.mn[MAIL_S] + os] = sm->pv_s[t];
+    if (npm) {
+      u64 *dst = mp.list + (u64)w.tid * mp.cap + w.mn[MAIL_P] + op;
+      dst[0] = sm->pv_pd[t];
+      dst[1] = sm->pv_pr[t];
+    }
+    w.mn[MAIL_B] += tb; w.mn[MAIL_S] += ts; w.mn[MAIL_P] += tp;
+    w.hidden += wave_sum32(nh);
+    w.st[ST_MAIL] += tb + ts + tp;
+  }
+  TM_END(w, TM_POST, t_q);
+}
+
+// rolled k-mer state of chunk position j (after insert_zero)
+FQ_DEV void load_state(Wk &w, u32 j) {
+  WgShared *sm = w.sm;
+  w.pm.dir = sm->sp_sdir[0][j]; w.pm.rc = sm->sp_src[0][j]; w.pm.cur = sm->sp_scur[0][j];
+  w.sm_.dir = sm->sp_sdir[1][j]; w.sm_.rc = sm->sp_src[1][j]; w.sm_.cur = sm->sp_scur[1][j];
+  w.bm.dir = sm->sp_sdir[2][j]; w.bm.rc = sm->sp_src[2][j]; w.bm.cur = sm->sp_scur[2][j];
+  w.pm_u.dir = sm->sp_sdir[3][j]; w.pm_u.rc = sm->sp_src[3][j]; w.pm_u.cur = sm->sp_scur[3][j];
+  w.sm_u.dir = sm->sp_sdir[4][j]; w.sm_u.rc = sm->sp_src[4][j]; w.sm_u.cur = sm->sp_scur[4][j];
+  w.bm_u.dir = sm->sp_sdir[5][j]; w.bm_u.rc = sm->sp_src[5][j]; w.bm_u.cur = sm->sp_scur[5][j];
+  w.N_run = sm->sp_nrun[j];
+}
+FQ_DEV void replace_last_all(Wk &w, u64 symk) {
+  km_replace_last(w.pm, symk); km_replace_last(w.sm_, symk); km_replace_last(w.bm, symk);
+  km_replace_last(w.pm_u, symk); km_replace_last(w.sm_u, symk); km_replace_last(w.bm_u, symk);
+}
+// ctx_letters before position i: reset (all ones) followed by the symbols 0..i-1 (dna.cpp:108-110,803)
+FQ_DEV u64 letters_before(Wk &w, const u8 *p, u32 i, u32 size) {
+  u64 ctx = ~0ull;
+  for (u32 t = i > 16 ? i - 16 : 0; t < i; ++t) ctx = (ctx << 4) + rd_sym(w, p, t, size);
+  return ctx;
+}
+
+// compress_suffix, dna.cpp:674-877, as chunks of stage P (parallel) -> stage C (the serial loop below:
+// context look-up + range coding, plus the complete reference logic for positions P could not
+// settle) -> stage Q (parallel mailbox appends)
+FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {
+  const DevCfg *cfg = w.cfg;
+  WgShared *sm = w.sm;
   u64 ctx_r_sym = 0;
   u32 i = original_order ? cfg->prefix : cfg->pmer;
-  while (i < size) {
+  while (i < size && !w.err) {
     const u32 n = size - i < FQSX_SPEC ? size - i : FQSX_SPEC;
     TM_BEGIN(t_sp);
     speculate(w, p, size, i, n);
     TM_END(w, TM_SPEC, t_sp);
+    TM_COUNT(w, CN_CHUNK);
+    u32 q_done = 0;   // chunk positions whose mailbox entries are already in the lists
+    u32 w_pos = 0;    // w's k-mers = state before position w_pos of the chunk
+    u32 m = 0;        // committed positions
     bool dirty = false;  // corrected k-mers were modified: the rest of the chunk's speculation is stale
-    for (u32 j = 0; j < n && !dirty; ++j, ++i) {
-      if (w.err) return;
-      u32 sym = rd_sym(w, p, i, size);
-      u64 sym_k = sym == 4 ? 0 : sym;
-      km_insert_zero(w.pm, cfg->gp); km_insert_zero(w.sm_, cfg->gs); km_insert_zero(w.bm, cfg->gb);
-      km_insert_zero(w.pm_u, cfg->gp); km_insert_zero(w.sm_u, cfg->gs); km_insert_zero(w.bm_u, cfg->gb);
+    for (u32 j = 0; j < n && !dirty && !w.err; ++j) {
+      const u32 pos = i + j;
+      const u32 sym = rd_sym(w, p, pos, size);
+      const u64 sym_k = sym == 4 ? 0 : sym;
       const u32 flag = sm->sp_flag[j];
-      const bool spec_ok = flag != 0 && w.bm.cur == cfg->gb.k && w.bm.dir == sm->sp_dir[j];
-      u32 level;
       TM_BEGIN(t_code);
-      const bool fast = spec_ok && flag == 1 && w.N_run < 2;
-      if (fast) {
-        // fast path: level bmer, everything but the adaptive state was computed in parallel
-        u32 pc = sm->sp_cnt[j];
-        counts.c[0] = pc & 0xff; counts.c[1] = (pc >> 8) & 0xff; counts.c[2] = (pc >> 16) & 0xff; counts.c[3] = pc >> 24;
-        level = LV_BMER;
+      if (flag == 1) {
+        // fast path: level bmer; only the adaptive model and the range coder are serial
         u64 lev[7];
         const u64 rs = (u64)popc64(ctx_r_sym) << SH_RSYM;
         lev[0] = sm->sp_key[j][0];
@@ -1205,8 +1312,31 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {  // comp
         u32 r_sym = sm->sp_rsym[j];
         if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
         ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;
+        const u32 rep = sm->sp_rep[j];
+        TM_END(w, TM_FAST, t_code);
+        TM_COUNT(w, CN_FAST);
+        if (rep != 0xff) {  // repair_kmers_existing fires (dna.cpp:362-369,856-863)
+          load_state(w, j);
+          replace_last_all(w, sym_k);
+          flush_pushes(w, q_done, j + 1);
+          q_done = j + 1;
+          km_replace_last(w.pm, rep); km_replace_last(w.sm_, rep); km_replace_last(w.bm, rep);
+          w.cor_pos = pos;
+          w.N_run = sym == 4 ? w.N_run + 1 : 0;
+          push_b_local(w);
+          w_pos = j + 1;
+          dirty = true;
+        }
       } else {
-        level = find_counts(w, counts, spec_ok && flag == 3);
+        // complete reference logic on the exact k-mers of this position
+        flush_pushes(w, q_done, j);
+        q_done = j;
+        load_state(w, j);
+        C4 counts;
+        TM_COUNT(w, CN_SLOW);
+        TM_BEGIN(t_fc);
+        u32 level = find_counts(w, counts, flag == 3);
+        TM_END(w, TM_FINDC, t_fc);
         if (level == LV_BMER_UNC) {
           w.bm = w.bm_u; w.sm_ = w.sm_u; w.pm = w.pm_u;
           w.cor_pos = 0;
@@ -1215,6 +1345,8 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {  // comp
         }
         bool rough = false;
         if (level == LV_NONE) {
+          TM_BEGIN(t_r);
+          TM_COUNT(w, CN_ROUGH);
           if (km_full(w.bm, cfg->gb)) {
             if (rough_kt(w, cfg->g_b, cfg->gb, w.bm, RNG_B, CINC_B, counts)) { level = LV_PMER; rough = true; }
           } else if (km_full(w.sm_, cfg->gs)) {
@@ -1222,56 +1354,79 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {  // comp
           } else if (km_full(w.pm, cfg->gp)) {
             if (rough_p(w, counts)) { level = LV_PMER; rough = true; }
           }
+          TM_END(w, TM_ROUGH, t_r);
         }
         if (level != LV_NONE && w.N_run < 2) {
           int cor_dist = level == LV_PMER ? (int)cfg->pmer : level == LV_SMER ? (int)cfg->smer : (int)cfg->bmer;
-          int d = (int)i - (int)w.cor_pos;
+          int d = (int)pos - (int)w.cor_pos;
           u32 cor_zone = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
           if (rough) cor_zone = 3;
           u64 lev[7];
-          ctx_codes(lev, cfg, counts, w.s_let, i, level, cor_zone, ctx_r_sym, size);
+          ctx_codes(lev, cfg, counts, w.s_let, pos, level, cor_zone, ctx_r_sym, size);
           Slot4 s;
           u32 idx = find_leveled(w, 1, lev, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
           u32 r_sym = rank_sym(w, counts, sym);
           if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
           ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;  // update_ctx_r_sym, dna.cpp:664-671
         } else {
-          code_letter(w, i, sym, size);
+          w.ctx_letters = letters_before(w, p, pos, size);
+          code_letter(w, pos, sym, size);
           ctx_r_sym = (ctx_r_sym << 1) & 0xff;
         }
-      }
-      TM_END(w, fast ? TM_FAST : TM_SLOW, t_code);
-      TM_BEGIN(t_post);
-      w.ctx_letters = (w.ctx_letters << 4) + sym;
-      if (sym == 4) ++w.N_run; else w.N_run = 0;
-      km_replace_last(w.pm, sym_k); km_replace_last(w.sm_, sym_k); km_replace_last(w.bm, sym_k);
-      km_replace_last(w.pm_u, sym_k); km_replace_last(w.sm_u, sym_k); km_replace_last(w.bm_u, sym_k);
-      if (sym < 4) {
-        bool pmer_insert = true;
+        if (sym == 4) ++w.N_run; else w.N_run = 0;
+        replace_last_all(w, sym_k);
+        // this position's mailbox entries from the exact k-mers (dna.cpp:818-852)
+        u32 pf = 0;
+        if (sym < 4) {
+          bool pmer_insert = true;
+          if (km_full(w.bm, cfg->gb)) {
+            pf |= PV_B;
+            if ((level == LV_SMER || level == LV_BMER || level == LV_MIXED) && c4_get(counts, sym) >= 3) pmer_insert = false;
+          }
+          if (km_full(w.sm_, cfg->gs)) pf |= PV_S;
+          if (km_full(w.pm, cfg->gp) && pos - w.cor_pos >= cfg->pmer - 1) pf |= pmer_insert ? PV_P : PV_PHID;
+        }
+        FQ_SYNC();
+        if (FQ_LANE == 0) {
+          sm->pv_b[j] = km_norm(w.bm, cfg->gb);
+          sm->pv_s[j] = km_norm(w.sm_, cfg->gs);
+          sm->pv_pd[j] = km_aligned_dir(w.pm);
+          sm->pv_pr[j] = km_aligned_rc(w.pm);
+          sm->pv_flag[j] = (u8)pf;
+        }
+        FQ_SYNC();
+        w_pos = j + 1;
         if (km_full(w.bm, cfg->gb)) {
-          push_b_local(w);
-          if ((level == LV_SMER || level == LV_BMER || level == LV_MIXED || level == LV_BMER_UNC) && c4_get(counts, sym) >= 3) pmer_insert = false;
+          bool rep = false;
+          if (level == LV_BMER || level == LV_MIXED) rep = repair_existing(w, pos, counts, sym);
+          else if (level == LV_NONE || level == LV_PMER) {
+            flush_pushes(w, q_done, j + 1);  // repair_missing probes only the global table; keep list order anyway
+            q_done = j + 1;
+            TM_BEGIN(t_rm);
+            TM_COUNT(w, CN_REPM);
+            rep = repair_missing(w, pos);
+            TM_END(w, TM_REPM, t_rm);
+          }
+          if (rep) {
+            flush_pushes(w, q_done, j + 1);
+            q_done = j + 1;
+            push_b_local(w);
+            dirty = true;
+          }
         }
-        if (km_full(w.sm_, cfg->gs)) {
-          u64 x = km_norm(w.sm_, cfg->gs);
-          mail_push(w, MAIL_S, sb_owner(cfg, x), x);
-          lq_push(w, 1, x);
-        }
-        if (km_full(w.pm, cfg->gp) && i - w.cor_pos >= cfg->pmer - 1) {
-          if (pmer_insert) push_p_both(w); else w.hidden += 2;
-        }
+        TM_END(w, TM_SLOW, t_code);
       }
-      if (km_full(w.bm, cfg->gb)) {
-        bool rep = false;
-        if (level == LV_BMER || level == LV_MIXED || level == LV_BMER_UNC) rep = repair_existing(w, i, counts, sym);
-        else if (level == LV_NONE || level == LV_PMER) rep = repair_missing(w, i);
-        if (rep) {
-          push_b_local(w);
-          dirty = true;
-        }
-      }
-      TM_END(w, TM_POST, t_post);
+      m = j + 1;
     }
+    if (dirty) TM_COUNT(w, CN_DIRTY);
+    flush_pushes(w, q_done, m);
+    if (w_pos != m) {  // the last committed position went through the fast path: materialise its state
+      const u32 sym = rd_sym(w, p, i + m - 1, size);
+      load_state(w, m - 1);
+      replace_last_all(w, sym == 4 ? 0 : sym);
+      w.N_run = sym == 4 ? w.N_run + 1 : 0;
+    }
+    i += m;
   }
 }
 
@@ -1329,7 +1484,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.ws = ws;
   w.err = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
-  for (u32 i = 0; i < 8; ++i) w.tm[i] = 0;
+  for (u32 i = 0; i < 16; ++i) w.tm[i] = 0;
   TM_BEGIN(t_total);
   const u64 T = cfg.T;
   // PartitionForWorkers, reads_block.h:197-214
@@ -1350,11 +1505,12 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
     for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) sm->mt[g][i] = ws->mt[g][i];
     if (FQ_LANE == 0) sm->mt_idx[g] = ws->mt_idx[g];
   }
-  for (u32 k = 0; k < 3; ++k) {
-    for (u32 i = FQ_LANE; i < 256; i += FQ_WAVE) { sm->mail_count[k][i] = 0; sm->mail_tail[k][i] = 0; }
-    if (FQ_LANE == 0) sm->mail_nchunks[k] = 0;
+  w.mn[0] = w.mn[1] = w.mn[2] = 0;
+  {  // avg_filling_factor (bit_vec.h:204-210) only changes in insert phases (dna.cpp:2416-2418)
+    u64 nu = cfg.siv_stats[0], nf = cfg.siv_stats[1];
+    w.repm_gate = !((nf ? (double)nu / (double)nf : 0.0) < 7.0);
   }
-  if (FQ_LANE == 0) sm->lq_n[0] = sm->lq_n[1] = 0;
+  w.la[0] = w.la[1] = w.la[2] = 0;
   FQ_SYNC();
   w.enc.low = ws->rc_low; w.enc.range = ws->rc_range; w.enc.len = ws->out_len;
   w.enc.cap = cfg.out_cap; w.enc.out = cfg.out + (u64)tid * cfg.out_cap;
@@ -1377,8 +1533,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
     compress_read(w, cfg.bases + o0, (u32)(o1 - o0), prev, prev_size);
   }
   if (stop > cur) cur = stop;
-  lq_flush(w, 0);  // the insert phase clears the local tables; apply what is still queued first
-  lq_flush(w, 1);
+  // (entries still pending for the local tables need not be applied: ClearKmersToHT empties them next)
 
   // store state
   ws->cursor = (u32)cur;
@@ -1388,14 +1543,13 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   ws->hidden_updates = w.hidden;
   TM_END(w, TM_TOTAL, t_total);
   for (u32 i = 0; i < ST_N; ++i) ws->stat[i] += w.st[i];
-  for (u32 i = 0; i < 8; ++i) ws->stat[16 + i] += w.tm[i];
+  for (u32 i = 0; i < 16; ++i) ws->stat[16 + i] += w.tm[i];
   FQ_SYNC();
   for (u32 g = 0; g < 4; ++g) {
     for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) ws->mt[g][i] = sm->mt[g][i];
     ws->mt_idx[g] = sm->mt_idx[g];
   }
-  for (u32 k = 0; k < 3; ++k)
-    for (u32 i = FQ_LANE; i < T; i += FQ_WAVE) cfg.mail[k].count[(u64)tid * T + i] = sm->mail_count[k][i];
+  for (u32 k = 0; k < 3; ++k) cfg.mail[k].n[tid] = w.mn[k];
   if (w.err) *cfg.err = w.err;
 }
 
@@ -1487,10 +1641,79 @@ FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 tid
   FQ_SYNC_MEM();
 }
 
-// owner `tid` applies column `tid` of every mailbox (InsertKmersToHT, dna.cpp:2393-2472)
+// ---- stable partition of the mailbox lists by owner -----------------------------------------
+FQ_DEV u32 mail_owner(const DevCfg &cfg, u32 kind, u64 x) { return kind == MAIL_P ? p_owner(&cfg, x) : sb_owner(&cfg, x); }
+
+// tile `blk` = (source, tile): histogram of owners
+FQ_DEV void part_count_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *hist /*LDS[256]*/) {
+  const Mail &m = cfg.mail[kind];
+  const u32 T = cfg.T, s = blk / m.n_tiles, t = blk % m.n_tiles;
+  const u32 n = m.n[s], lo = t * FQSX_TILE, hi = n < lo + FQSX_TILE ? n : lo + FQSX_TILE;
+  for (u32 d = FQ_LANE; d < 256; d += FQ_WAVE) hist[d] = 0;
+  FQ_SYNC();
+  for (u32 e = lo + FQ_LANE; e < hi; e += FQ_WAVE) lds_inc32(&hist[mail_owner(cfg, kind, m.list[(u64)s * m.cap + e])]);
+  FQ_SYNC();
+  for (u32 d = FQ_LANE; d < T; d += FQ_WAVE) m.tile_hist[(u64)blk * T + d] = hist[d];
+}
+// owner `d`: exclusive scan of its column over all (source, tile) in order
+FQ_DEV void part_scan_body(const DevCfg &cfg, u32 kind, u32 d) {
+  const Mail &m = cfg.mail[kind];
+  const u32 T = cfg.T, tiles = T * m.n_tiles;
+  u32 run = 0;
+  for (u32 base = 0; base < tiles; base += FQ_WAVE) {
+    u32 i = base + FQ_LANE;
+    u32 v = i < tiles ? m.tile_hist[(u64)i * T + d] : 0;
+    u32 ex = wave_excl_scan32(v) + run;
+    if (i < tiles) m.tile_hist[(u64)i * T + d] = ex;
+    run += wave_sum32(v);
+  }
+  if (FQ_LANE == 0) m.dst_tot[d] = run;
+}
+FQ_DEV void part_dstoff_body(const DevCfg &cfg, u32 kind) {
+  const Mail &m = cfg.mail[kind];
+  if (FQ_LANE == 0) {
+    u32 run = 0;
+    for (u32 d = 0; d < cfg.T; ++d) { m.dst_off[d] = run; run += m.dst_tot[d]; }
+    m.dst_off[cfg.T] = run;
+  }
+}
+// tile `blk`: stable scatter into the owners' groups
+FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor /*LDS[256]*/, u32 *ld /*LDS[64]*/) {
+  const Mail &m = cfg.mail[kind];
+  const u32 T = cfg.T, s = blk / m.n_tiles, t = blk % m.n_tiles;
+  const u32 n = m.n[s], lo = t * FQSX_TILE, hi = n < lo + FQSX_TILE ? n : lo + FQSX_TILE;
+  if (lo >= hi) return;
+  for (u32 d = FQ_LANE; d < T; d += FQ_WAVE) cursor[d] = m.dst_off[d] + m.tile_hist[(u64)blk * T + d];
+  FQ_SYNC();
+  for (u32 base = lo; base < hi; base += FQ_WAVE) {
+    const u32 e = base + FQ_LANE, cnt = hi - base < FQ_WAVE ? hi - base : FQ_WAVE;
+    u64 x = 0;
+    u32 d = 0xffffffffu;
+    if (e < hi) {
+      x = m.list[(u64)s * m.cap + e];
+      d = mail_owner(cfg, kind, x);
+    }
+    ld[FQ_LANE] = d;
+    FQ_SYNC();
+    u32 rank = 0, later = 0;
+    for (u32 q = 0; q < cnt; ++q) {
+      u32 dq = ld[q];
+      rank += (q < FQ_LANE && dq == d) ? 1u : 0u;
+      later += (q > FQ_LANE && dq == d) ? 1u : 0u;
+    }
+    u32 cur = e < hi ? cursor[d] : 0;
+    FQ_SYNC();
+    if (e < hi) {
+      m.sorted[cur + rank] = x;
+      if (later == 0) cursor[d] = cur + rank + 1;  // last entry of this owner in the round advances the cursor
+    }
+    FQ_SYNC();
+  }
+}
+
+// owner `tid` applies its group of every mailbox (InsertKmersToHT, dna.cpp:2393-2472)
 FQ_DEV void insert_phase_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
   WState *ws = cfg.ws + tid;
-  const u32 T = cfg.T;
   u32 err = 0;
   u64 n_words = 0, n_ins = 0, n_slots = 0;
   FQ_SYNC();
@@ -1502,31 +1725,23 @@ FQ_DEV void insert_phase_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
   // p-mers: saturating 2-bit increments; order-free, so lanes update concurrently with CAS
   {
     const Mail &m = cfg.mail[MAIL_P];
+    const u32 lo = m.dst_off[tid], hi = m.dst_off[tid + 1];
     u64 nf = 0, nu = 0;
-    for (u32 src = 0; src < T; ++src) {
-      u32 cnt = m.count[(u64)src * T + tid];
-      u32 chunk = cnt ? m.head[(u64)src * T + tid] : FQSX_NIL;
-      for (u32 done = 0; done < cnt; done += FQSX_CHUNK) {
-        u32 n = cnt - done < FQSX_CHUNK ? cnt - done : FQSX_CHUNK;
-        const u64 *keys = m.pool + ((u64)src * m.pool_chunks + chunk) * FQSX_CHUNK;
-        for (u32 i = FQ_LANE; i < n; i += FQ_WAVE) {
-          u64 idx = keys[i];
-          u64 *wp = cfg.siv + (idx >> 5);
-          u32 sh = 2 * (u32)(idx & 31);
-          u64 old = *wp;
-          for (;;) {  // increment(), bit_vec.h:53-67
-            u64 f = (old >> sh) & 3;
-            if (f == 3) break;
-            u64 seen = atomic_cas64(wp, old, old + (1ull << sh));
-            if (seen == old) { nf += f == 0; break; }
-            old = seen;
-          }
-          ++nu;
-        }
-        n_words += n;
-        chunk = m.next[(u64)src * m.pool_chunks + chunk];
+    for (u32 e = lo + FQ_LANE; e < hi; e += FQ_WAVE) {
+      u64 idx = m.sorted[e];
+      u64 *wp = cfg.siv + (idx >> 5);
+      u32 sh = 2 * (u32)(idx & 31);
+      u64 old = *wp;
+      for (;;) {  // increment(), bit_vec.h:53-67
+        u64 f = (old >> sh) & 3;
+        if (f == 3) break;
+        u64 seen = atomic_cas64(wp, old, old + (1ull << sh));
+        if (seen == old) { nf += f == 0; break; }
+        old = seen;
       }
+      ++nu;
     }
+    n_words += hi - lo;
     nf = wave_sum64(nf);
     nu = wave_sum64(nu);
     if (FQ_LANE == 0) {  // update_no_filled / update_no_updates, dna.cpp:2416-2418 (atomics, bit_vec.h:25-26)
@@ -1547,17 +1762,9 @@ FQ_DEV void insert_phase_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
     const KTab &t = kind == MAIL_S ? cfg.g_s : cfg.g_b;
     const u32 rng = kind == MAIL_S ? RNG_S : RNG_B;
     const Cinc ci = kind == MAIL_S ? CINC_S : CINC_B;
-    for (u32 src = 0; src < T && !err; ++src) {
-      u32 cnt = m.count[(u64)src * T + tid];
-      u32 chunk = cnt ? m.head[(u64)src * T + tid] : FQSX_NIL;
-      for (u32 done = 0; done < cnt && !err; done += FQSX_CHUNK) {
-        u32 n = cnt - done < FQSX_CHUNK ? cnt - done : FQSX_CHUNK;
-        const u64 *keys = m.pool + ((u64)src * m.pool_chunks + chunk) * FQSX_CHUNK;
-        insert_keys(cfg, sm, t, tid, keys, n, rng, ci, n_slots, err);
-        n_ins += n;
-        chunk = m.next[(u64)src * m.pool_chunks + chunk];
-      }
-    }
+    const u32 lo = m.dst_off[tid], hi = m.dst_off[tid + 1];
+    insert_keys(cfg, sm, t, tid, m.sorted + lo, hi - lo, rng, ci, n_slots, err);
+    n_ins += hi - lo;
   }
   FQ_SYNC();
   for (u32 g = RNG_B; g <= RNG_S; ++g) {

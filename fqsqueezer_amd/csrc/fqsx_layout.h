@@ -13,7 +13,6 @@
 #include "fqsx_plat.h"
 
 #define FQSX_MAX_T 255
-#define FQSX_CHUNK 64u           // mailbox chunk = one wave batch (64 x u64 = 512 B)
 #define FQSX_NIL 0xffffffffu
 #define FQSX_RD_LDS 4096u        // reads up to this length are staged in LDS
 #define FQSX_SPEC 64u            // positions speculated per chunk (one per lane)
@@ -47,14 +46,19 @@ struct CtxSlot {
   u16 pad[3];
 };
 
-// Mailbox of one kind (p-, s- or b-mers): per source worker a pool of 64-entry chunks,
-// chained per destination owner in push order.
+// Mailbox of one kind (p-, s- or b-mers).  Sources append to a flat per-source list in push
+// order; a GPU-wide stable partition (k_part_*) then groups the entries by owner, keeping
+// (source, push) order inside each group -- the order InsertKmersToHT drains its column in.
+#define FQSX_TILE 2048u
 struct Mail {
-  u64 *pool;        // [T][pool_chunks*64]
-  u32 *next;        // [T][pool_chunks]   chunk -> next chunk of the same (src,dst) chain
-  u32 *head;        // [T src][T dst]     first chunk or NIL
-  u32 *count;       // [T src][T dst]     entries pushed
-  u32 pool_chunks;  // per source
+  u64 *list;       // [T][cap]     entries in push order per source
+  u32 *n;          // [T]          entries per source (written at the end of an encode launch)
+  u64 *sorted;     // [T*cap]      entries grouped by owner
+  u32 *tile_hist;  // [T*n_tiles][T] per-tile owner histogram, exclusive offsets after the scan
+  u32 *dst_tot;    // [T]          entries per owner
+  u32 *dst_off;    // [T+1]        start of each owner's group in `sorted`
+  u32 cap;         // per source
+  u32 n_tiles;     // ceil(cap / FQSX_TILE)
 };
 enum { MAIL_P = 0, MAIL_S = 1, MAIL_B = 2 };
 
@@ -87,7 +91,7 @@ struct WState {
   u64 out_len;
   u32 mt_idx[4];                       // cinc_b, cinc_s, cinc_lb, cinc_ls (dna.h:113-116)
   u32 mt[4][624];
-  u64 stat[24];                        // probe/byte accounting, see ST_*; [16..23] in-kernel section times (10 ns ticks)
+  u64 stat[32];                        // probe/byte accounting, see ST_*; [16..23] in-kernel section times (10 ns ticks)
 };
 enum { RNG_B = 0, RNG_S = 1, RNG_LB = 2, RNG_LS = 3 };
 enum {
@@ -106,7 +110,8 @@ enum {
   ST_N
 };
 // section timers (only maintained by -DFQSX_TIMING builds)
-enum { TM_TOTAL = 0, TM_SPEC, TM_FAST, TM_SLOW, TM_POST, TM_READ_HEAD, TM_LQ, TM_N };
+enum { TM_TOTAL = 0, TM_SPEC, TM_FAST, TM_SLOW, TM_POST, TM_READ_HEAD, TM_LQ, TM_ROUGH, TM_REPM, TM_FINDC,
+       CN_FAST, CN_SLOW, CN_CHUNK, CN_DIRTY, CN_ROUGH, CN_REPM, TM_N };
 
 struct DevCfg {
   u32 T, mode;                 // mode 0 = original order, 1 = sorted (params.h:18)

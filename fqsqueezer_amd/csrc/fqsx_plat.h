@@ -46,6 +46,17 @@ FQ_DEV u64 wave_sum64(u64 v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// exclusive prefix sum over the lanes of the wave
+FQ_DEV u32 wave_excl_scan32(u32 v) {
+  u32 x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    u32 y = __shfl_up(x, o, 64);
+    if ((int)(threadIdx.x & 63u) >= o) x += y;
+  }
+  return x - v;
+}
+FQ_DEV void lds_inc32(u32 *p) { atomicAdd(p, 1u); }
 FQ_DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
 FQ_DEV bool wave_all(bool p) { return __ballot(p) == __ballot(true); }
 FQ_DEV u64 wave_ballot(bool p) { return __ballot(p); }
@@ -57,6 +68,7 @@ FQ_DEV u64 uniform64(u64 v) {
   return ((u64)hi << 32) | lo;
 }
 FQ_DEV u32 popc64(u64 v) { return (u32)__popcll(v); }
+FQ_DEV u32 ctz64(u64 v) { return (u32)__ffsll((long long)v) - 1u; }
 FQ_DEV u64 fq_clock() { return (u64)wall_clock64(); }  // 100 MHz constant clock (s_memrealtime)
 FQ_DEV u64 atomic_cas64(u64 *p, u64 expect, u64 desired) {
   return (u64)atomicCAS((unsigned long long *)p, (unsigned long long)expect, (unsigned long long)desired);
@@ -81,6 +93,8 @@ FQ_DEV double ema_update(double avg, double level) { return __dadd_rn(__dmul_rn(
 static thread_local u32 fq_emu_block = 0, fq_emu_nblocks = 1;
 FQ_DEV u32 wave_sum32(u32 v) { return v; }
 FQ_DEV u64 wave_sum64(u64 v) { return v; }
+FQ_DEV u32 wave_excl_scan32(u32) { return 0; }
+FQ_DEV void lds_inc32(u32 *p) { ++*p; }
 FQ_DEV bool wave_any(bool p) { return p; }
 FQ_DEV bool wave_all(bool p) { return p; }
 FQ_DEV u64 wave_ballot(bool p) { return p ? 1ull : 0ull; }
@@ -89,6 +103,7 @@ FQ_DEV u64 wave_bcast64(u64 v, u32) { return v; }
 FQ_DEV u32 uniform32(u32 v) { return v; }
 FQ_DEV u64 uniform64(u64 v) { return v; }
 FQ_DEV u32 popc64(u64 v) { return (u32)__builtin_popcountll(v); }
+FQ_DEV u32 ctz64(u64 v) { return (u32)__builtin_ctzll(v); }
 FQ_DEV u64 fq_clock() { return 0; }
 FQ_DEV u64 atomic_cas64(u64 *p, u64 expect, u64 desired) {
   u64 old = *p;

@@ -23,10 +23,12 @@ for g, idx in enumerate(blocks):
     c.encode_block(bases, off, g)
 dt = time.time() - t0
 st = c.stats(); kt = c.kernel_times()
-names = ["total", "spec", "fast", "slow", "post", "read_head", "lq_flush", "-"]
-tm = [x * 1e-8 for x in st["timers"]]
+names = ["total", "spec", "fast", "slow", "post_q", "read_head", "lq_flush", "rough", "repair_missing", "find_counts"]
+cn = dict(zip(["n_fast", "n_slow", "n_chunk", "n_dirty", "n_rough", "n_repm"], st["timers"][10:16]))
+tm = [x * 1e-8 for x in st["timers"][:10]]
 print(f"{n} reads T={T}: wall {dt:.2f}s  {n*100/dt/1e6:.2f} Mbases/s  kernels: {kt}")
 print("section seconds summed over workers:", {k: round(v, 3) for k, v in zip(names, tm)})
 tot = tm[0] or 1
 print("shares of worker time:", {k: round(v / tot, 3) for k, v in zip(names, tm)})
+print("events:", cn)
 print({k: v for k, v in st.items() if k != "timers"})
