@@ -109,7 +109,7 @@ FQ_KERNEL void k_rehash_ctx(const u64 *o, u64 ocap_mask, u64 *n, u64 ncap_mask, 
     if (!tag) continue;
     u64 key = src[0];
     u64 *b = n + 4 * (u64)w * (ncap_mask + 1);
-    u64 h = murmur64(key ^ ((u64)tag * 0x9E3779B97F4A7C15ULL)) & ncap_mask;
+    u64 h = (u64)ctx_mix(tag, key) & ncap_mask;
     for (;;) {
       u64 *p = b + 4 * h;
       if (p[1] == 0 && atomic_cas64(&p[1], 0, q1) == 0) {

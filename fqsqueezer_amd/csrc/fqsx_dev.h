@@ -30,6 +30,7 @@ struct WgShared {
   // mailbox entries of the chunk's positions (stage Q appends them lane-parallel)
   u64 pv_b[FQSX_SPEC], pv_s[FQSX_SPEC], pv_pd[FQSX_SPEC], pv_pr[FQSX_SPEC];
   u8 pv_flag[FQSX_SPEC];       // PV_* bits
+  u64 lev_tmp[10];             // level keys of a position coded outside the fast path
 };
 enum { PV_B = 1, PV_S = 2, PV_P = 4, PV_PHID = 8, PV_PCAND = 16 };
 
@@ -478,10 +479,13 @@ FQ_DEV void rc_put(Wk &w, u8 b) {
 // exact range / tot for tot < 2^16 without the 64-bit software divide: high word by 32-bit
 // division, the remaining < 2^48 dividend in fp64 with a +-1 fix-up (sub_rc.h:63)
 FQ_DEV u64 div_u64_small(u64 x, u32 d) {
+  const double rd = 1.0 / (double)d;
   u32 hi = (u32)(x >> 32), lo = (u32)x;
-  u32 qh = hi / d;
-  u64 rem = ((u64)(hi - qh * d) << 32) | lo;
-  u64 q = (u64)((double)rem / (double)d);
+  u32 qh = (u32)((double)hi * rd);
+  u32 ph = qh * d;
+  if (ph > hi) { --qh; ph -= d; } else if (hi - ph >= d) { ++qh; ph += d; }
+  u64 rem = ((u64)(hi - ph) << 32) | lo;   // < d * 2^32 <= 2^48
+  u64 q = (u64)((double)rem * rd);
   u64 prod = q * d;
   if (prod > rem) --q;
   else if (rem - prod >= d) ++q;
@@ -561,7 +565,15 @@ FQ_DEV void sm_encode256(Wk &w, u16 *m, u8 *init_flag, u32 x) {
 // later duplicate in the reference's linear probe)
 struct Slot4 { u64 q0, q1, q2, q3; };  // key | counter,tag,total | st0..3 | st4
 FQ_DEV u64 *ctx_base(Wk &w) { return (u64 *)(w.cfg->ctx + (u64)w.tid * (w.cfg->ctx_cap_mask + 1)); }
-FQ_DEV u64 ctx_hash(Wk &w, u32 tag, u64 key) { return murmur64(key ^ ((u64)tag * 0x9E3779B97F4A7C15ULL)) & w.cfg->ctx_cap_mask; }
+// slot hash of the context table (our layout, so any good mixer will do: 32-bit finaliser)
+FQ_DEV u32 ctx_mix(u32 tag, u64 key) {
+  u32 x = (u32)key ^ ((u32)(key >> 32) * 0x9E3779B1u) ^ (tag * 0x85EBCA6Bu);
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+FQ_DEV u64 ctx_hash(Wk &w, u32 tag, u64 key) { return (u64)ctx_mix(tag, key) & w.cfg->ctx_cap_mask; }
 FQ_DEV u32 slot_counter(const Slot4 &s) { return (u32)s.q1; }
 FQ_DEV u32 slot_tag(u64 q1) { return (u32)(q1 >> 32) & 0xffffu; }
 FQ_DEV u32 ctx_find(Wk &w, u32 tag, u64 key, Slot4 &s) {
@@ -615,23 +627,22 @@ FQ_DEV void ctx_store_counter(Wk &w, u32 idx, Slot4 &s, u32 counter) {
 }
 
 // level thresholds (dna.h:33,36)
-FQ_DEV u32 code_thr(u32 i) {
-  const u32 t[12] = {1, 32, 64, 64, 128, 512, 1024, 32, 128, 256, 2048, 4};
-  return t[i];
-}
-FQ_DEV u32 letters_thr(u32 i) {
-  const u32 t[12] = {1, 32, 64, 128, 256, 512, 2048, 4096, 8192, 16384, 16384, 4};
-  return t[i];
-}
+// {1,32,64,64,128,512,1024,32,128,256,2048,4} and {1,32,64,128,256,512,2048,4096,8192,16384,16384,4}: powers of
+// two, kept as packed exponents
+FQ_DEV u32 code_thr(u32 i) { return 1u << ((0x2B875A976650ULL >> (4 * i)) & 15); }
+FQ_DEV u32 letters_thr(u32 i) { return 1u << ((0x2EEDCB987650ULL >> (4 * i)) & 15); }
 
 // find_rc_code_context / find_rc_letters_context (dna.cpp:2107-2286): hierarchical level
 // search with lazy clone-on-threshold; returns slot index (model + already incremented counter in s)
-FQ_DEV u32 find_leveled(Wk &w, u32 tag, const u64 *lev, int n_levels, double &avg, u64 tpl_q2, u64 tpl_q3, u32 tpl_total, Slot4 &s) {
+// `lev` points to the level keys in LDS; `rs` is added to the keys of levels >= 2 (the r_sym field the
+// speculation stage left open)
+#define LEVKEY(l) (lev[l] + ((l) >= 2 ? rs : 0))
+FQ_DEV u32 find_leveled(Wk &w, u32 tag, const u64 *lev, u64 rs, int n_levels, double &avg, u64 tpl_q2, u64 tpl_q3, u32 tpl_total, Slot4 &s) {
   int i;
   Slot4 q;
   const bool letters = tag == 2;
   int start = (int)(avg + 0.49);
-  u32 p = ctx_find(w, tag, lev[start], s);
+  u32 p = ctx_find(w, tag, LEVKEY(start), s);
   if (p != FQSX_NIL && slot_counter(s) < (letters ? letters_thr(start) : code_thr(start))) {
     ctx_store_counter(w, p, s, slot_counter(s) + 1);
     avg = ema_update(avg, (double)start);
@@ -639,12 +650,12 @@ FQ_DEV u32 find_leveled(Wk &w, u32 tag, const u64 *lev, int n_levels, double &av
   }
   if (p == FQSX_NIL) {
     for (i = start - 1; i >= 0; --i) {
-      p = ctx_find(w, tag, lev[i], s);
+      p = ctx_find(w, tag, LEVKEY(i), s);
       if (p != FQSX_NIL) break;
     }
   } else {
     for (i = start + 1; i < n_levels; ++i) {
-      u32 qi = ctx_find(w, tag, lev[i], q);
+      u32 qi = ctx_find(w, tag, LEVKEY(i), q);
       if (qi == FQSX_NIL) break;
       if (slot_counter(q) < code_thr(i)) {  // both routines use the *code* thresholds here (quirk, dna.cpp:2244)
         avg = ema_update(avg, (double)i);
@@ -658,7 +669,7 @@ FQ_DEV u32 find_leveled(Wk &w, u32 tag, const u64 *lev, int n_levels, double &av
     --i;
   }
   if (p == FQSX_NIL) {  // nothing known: create level 0 from the template
-    p = ctx_insert(w, tag, lev[0], tpl_q2, tpl_q3, tpl_total, s);
+    p = ctx_insert(w, tag, LEVKEY(0), tpl_q2, tpl_q3, tpl_total, s);
     if (p == FQSX_NIL) return p;
     ctx_store_counter(w, p, s, slot_counter(s) + 1);
     i = 0;
@@ -666,7 +677,7 @@ FQ_DEV u32 find_leveled(Wk &w, u32 tag, const u64 *lev, int n_levels, double &av
   if (slot_counter(s) >= code_thr(i) && i + 1 < n_levels) {  // clone into the next level (dna.cpp:2177-2184)
     u32 total = (u32)(s.q1 >> 48);
     Slot4 c;
-    u32 ci = ctx_insert(w, tag, lev[i + 1], s.q2, s.q3, total, c);
+    u32 ci = ctx_insert(w, tag, LEVKEY(i + 1), s.q2, s.q3, total, c);
     if (ci == FQSX_NIL) return ci;
     ctx_store_counter(w, ci, c, slot_counter(c) + 1);
     s = c;
@@ -678,29 +689,27 @@ FQ_DEV u32 find_leveled(Wk &w, u32 tag, const u64 *lev, int n_levels, double &av
 }
 
 // Encode with a context slot's 5-symbol model (CSimpleModelFixedSize<5>, rc.h:178-338,478-488)
+FQ_DEV u32 hsum4x16(u64 v) { return (u32)((v * 0x0001000100010001ULL) >> 48); }  // sum of four 16-bit fields (< 2^16)
 FQ_DEV void slot_encode(Wk &w, u32 idx, Slot4 &s, u32 x) {
-  u32 st[5];
-  st[0] = (u32)(s.q2 & 0xffff); st[1] = (u32)((s.q2 >> 16) & 0xffff);
-  st[2] = (u32)((s.q2 >> 32) & 0xffff); st[3] = (u32)(s.q2 >> 48);
-  st[4] = (u32)(s.q3 & 0xffff);
   u32 tot = (u32)(s.q1 >> 48);
-  u32 cum = 0, f = 0;
-  for (u32 i = 0; i < 5; ++i) {
-    cum += i < x ? st[i] : 0;
-    f = i == x ? st[i] : f;
-  }
+  const u32 sh = 16 * (x & 3);
+  u32 cum = hsum4x16(x >= 4 ? s.q2 : s.q2 & ((1ull << sh) - 1ull));
+  u32 f = x >= 4 ? (u32)(s.q3 & 0xffff) : (u32)((s.q2 >> sh) & 0xffff);
   rc_encode(w, f, cum, tot);
-  for (u32 i = 0; i < 5; ++i) st[i] += i == x ? 4u : 0u;
+  if (x >= 4) s.q3 += 4; else s.q2 += 4ull << sh;   // fields stay < 2^16: total < 2^15 + 4
   tot += 4;
-  while (tot >= (1u << 15)) {
-    tot = 0;
-    for (u32 i = 0; i < 5; ++i) {
-      st[i] = (st[i] + 1) / 2;
-      tot += st[i];
+  if (tot >= (1u << 15)) {  // rescale, rc.h:186-197
+    u32 st[5] = {(u32)(s.q2 & 0xffff), (u32)((s.q2 >> 16) & 0xffff), (u32)((s.q2 >> 32) & 0xffff), (u32)(s.q2 >> 48), (u32)(s.q3 & 0xffff)};
+    while (tot >= (1u << 15)) {
+      tot = 0;
+      for (u32 i = 0; i < 5; ++i) {
+        st[i] = (st[i] + 1) / 2;
+        tot += st[i];
+      }
     }
+    s.q2 = (u64)st[0] | ((u64)st[1] << 16) | ((u64)st[2] << 32) | ((u64)st[3] << 48);
+    s.q3 = (s.q3 & ~0xffffULL) | st[4];
   }
-  s.q2 = (u64)st[0] | ((u64)st[1] << 16) | ((u64)st[2] << 32) | ((u64)st[3] << 48);
-  s.q3 = (s.q3 & ~0xffffULL) | st[4];
   s.q1 = (s.q1 & 0x0000ffffffffffffULL) | ((u64)tot << 48);
   u64 *p = ctx_base(w) + 4 * (u64)idx;
   p[1] = s.q1; p[2] = s.q2; p[3] = s.q3;
@@ -1046,8 +1055,11 @@ FQ_DEV bool repair_missing(Wk &w, u32 pos) {  // repair_kmers_missing, dna.cpp:3
 FQ_DEV void code_letter(Wk &w, u32 pos, u32 sym, u32 read_len) {  // dna.cpp:520-528,776-785
   u64 lev[10];
   ctx_letters_keys(lev, w.cfg, pos, w.ctx_letters, read_len);
+  FQ_SYNC();
+  for (u32 l = 0; l < 10; ++l) w.sm->lev_tmp[l] = lev[l];
+  FQ_SYNC();
   Slot4 s;
-  u32 idx = find_leveled(w, 2, lev, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
+  u32 idx = find_leveled(w, 2, w.sm->lev_tmp, 0, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
   if (idx != FQSX_NIL) slot_encode(w, idx, s, sym);
 }
 
@@ -1302,13 +1314,9 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {
       TM_BEGIN(t_code);
       if (flag == 1) {
         // fast path: level bmer; only the adaptive model and the range coder are serial
-        u64 lev[7];
         const u64 rs = (u64)popc64(ctx_r_sym) << SH_RSYM;
-        lev[0] = sm->sp_key[j][0];
-        lev[1] = sm->sp_key[j][1];
-        for (u32 l = 2; l < 7; ++l) lev[l] = sm->sp_key[j][l] + rs;
         Slot4 s;
-        u32 idx = find_leveled(w, 1, lev, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
+        u32 idx = find_leveled(w, 1, sm->sp_key[j], rs, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
         u32 r_sym = sm->sp_rsym[j];
         if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
         ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;
@@ -1363,8 +1371,11 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {
           if (rough) cor_zone = 3;
           u64 lev[7];
           ctx_codes(lev, cfg, counts, w.s_let, pos, level, cor_zone, ctx_r_sym, size);
+          FQ_SYNC();
+          for (u32 l = 0; l < 7; ++l) sm->lev_tmp[l] = lev[l];
+          FQ_SYNC();
           Slot4 s;
-          u32 idx = find_leveled(w, 1, lev, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
+          u32 idx = find_leveled(w, 1, sm->lev_tmp, 0, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
           u32 r_sym = rank_sym(w, counts, sym);
           if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
           ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;  // update_ctx_r_sym, dna.cpp:664-671
