@@ -50,6 +50,7 @@ def main() -> None:
     ap.add_argument("--threads", type=int, default=64, help="logical workers T (header byte, <=255)")
     ap.add_argument("--cpu-sample-reads", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the extra host-buffer (PCIe-inclusive) pass")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,6 +140,29 @@ def main() -> None:
                 "encode_kernel_s": round(enc_s, 4), "insert_kernel_s": round(ins_s, 4),
                 "probes_per_s": round((st["gprobe"] + st["lprobe"]) / max(enc_s, 1e-9), 1)}
 
+    # ---- PCIe-inclusive rate: the same pass through the host-buffer entry point (H2D copy per block; untimed run)
+    pcie = None
+    if world == 1 and not a.no_pcie:
+        host_blocks = [hp.block_arrays(rec, idx) for idx in blocks]
+        codec = DnaCodec(header, device=local_rank)
+        t1 = time.perf_counter()
+        for g, (bases, off) in enumerate(host_blocks):
+            codec.encode_block(bases, off, g)
+        pcie = round(n_bases / (time.perf_counter() - t1) / 1e6, 4)
+        codec.close()
+
+    # HBM traffic of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/traffic.json), if recorded
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            tj = json.load(open(tf))
+            if tj.get("workers_T") == a.threads and tj.get("reads") == a.reads and tj.get("len") == a.len:
+                traffic = tj.get("bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline["traffic"] = traffic
+
     # ---- CPU baseline on a bounded sample of the same workload (rank 0, N=1 only)
     cpu = None
     if not a.no_cpu_baseline and world == 1:
@@ -150,7 +174,7 @@ def main() -> None:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2+rank), -om s -gs {a.gs} -qm n -im n",
                    "workers_T": a.threads, "blocks": len(blocks), "per_gpu": "one independent file per GPU"},
-        "bits_per_base": round(8.0 * dna_bytes / n_bases, 5),
+        "bits_per_base": round(8.0 * dna_bytes / n_bases, 5), "pcie_inclusive_mbases_s": pcie,
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)

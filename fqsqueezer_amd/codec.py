@@ -46,6 +46,9 @@ def _load(path: str):
     lib.fqsx_dna_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.fqsx_dna_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.fqsx_dna_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.fqsx_meta_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.fqsx_meta_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.fqsx_meta_destroy.argtypes = [C.c_void_p]
     lib.fqsx_last_error.restype = C.c_char_p
     lib.fqsx_version.restype = C.c_char_p
     return lib
@@ -122,6 +125,36 @@ class DnaCodec:
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._lib.fqsx_dna_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MetaCodec:
+    """Host-side read-length stream of the container (fqsx_meta_*)."""
+
+    def __init__(self, threads: int, lib_path: Optional[str] = None):
+        self._lib = load_library(lib_path)
+        self.T = threads
+        self._h = C.c_void_p()
+        if self._lib.fqsx_meta_create(threads, C.byref(self._h)):
+            raise FqsxError("fqsx_meta_create failed")
+        self._streams = (C.c_void_p * threads)()
+        self._lens = (C.c_uint64 * threads)()
+
+    def encode_block(self, read_len: np.ndarray) -> List[bytes]:
+        read_len = np.ascontiguousarray(read_len, dtype=np.uint32)
+        if self._lib.fqsx_meta_encode_block(self._h, read_len.ctypes.data, len(read_len), self._streams, self._lens):
+            raise FqsxError("fqsx_meta_encode_block failed")
+        return [C.string_at(self._streams[w], self._lens[w]) for w in range(self.T)]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.fqsx_meta_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -31,6 +31,7 @@ struct WgShared {
   u64 pv_b[FQSX_SPEC], pv_s[FQSX_SPEC], pv_pd[FQSX_SPEC], pv_pr[FQSX_SPEC];
   u8 pv_flag[FQSX_SPEC];       // PV_* bits
   u64 lev_tmp[10];             // level keys of a position coded outside the fast path
+  u64 pq_key[2][64];           // LDS mirror of the list entries not yet applied to the local tables (b, s)
 };
 enum { PV_B = 1, PV_S = 2, PV_P = 4, PV_PHID = 8, PV_PCAND = 16 };
 
@@ -54,6 +55,7 @@ struct Wk {
   bool repm_gate;                       // siv avg_filling_factor() >= 7 (constant within a segment)
   u32 mn[3];                            // entries appended to this worker's p/s/b mailbox lists
   u32 la[3];                            // list entries already applied to the local tables (b, s)
+  u32 pq_n[2];                          // valid entries of the LDS mirror (b, s); ~0u = mirror overflowed
   u64 st[ST_N];
   u64 tm[16];
   u32 err;
@@ -244,17 +246,27 @@ FQ_DEV void tab_scan(const KTab &t, u32 sub, u64 kmer_norm, bool is_dir, C4 &c, 
   const u64 cm = (1ull << t.cbits) - 1ull;
   const u64 lowmask = (1ull << (k2 - 2)) - 1ull;
   const u64 grp = is_dir ? (v >> 2) : (v & lowmask);
-  for (u64 n = 0; n <= t.cap_mask; ++n) {
-    u64 it = s[p];
+  for (u64 n = 0; n <= t.cap_mask; n += 2) {
+    // two consecutive slots per round trip (independent loads); most clusters end within them
+    const u64 p1 = (p + 1) & t.cap_mask;
+    const u64 it0 = s[p], it1 = s[p1];
     ++nslots;
-    if (!it) break;
-    u64 iv = it >> t.cbits;
+    if (!it0) break;
+    u64 iv = it0 >> t.cbits;
     if (is_dir) {
-      if ((iv >> 2) == grp) c4_add(c, (u32)(iv & 3), (u32)(it & cm));
+      if ((iv >> 2) == grp) c4_add(c, (u32)(iv & 3), (u32)(it0 & cm));
     } else {
-      if ((iv & lowmask) == grp) c4_add(c, 3u - (u32)(iv >> (k2 - 2)), (u32)(it & cm));
+      if ((iv & lowmask) == grp) c4_add(c, 3u - (u32)(iv >> (k2 - 2)), (u32)(it0 & cm));
     }
-    p = (p + 1) & t.cap_mask;
+    ++nslots;
+    if (!it1) break;
+    iv = it1 >> t.cbits;
+    if (is_dir) {
+      if ((iv >> 2) == grp) c4_add(c, (u32)(iv & 3), (u32)(it1 & cm));
+    } else {
+      if ((iv & lowmask) == grp) c4_add(c, 3u - (u32)(iv >> (k2 - 2)), (u32)(it1 & cm));
+    }
+    p = (p1 + 1) & t.cap_mask;
   }
 }
 // exact look-up (count(), ht_kmer.h:330-362,441-453)
@@ -361,7 +373,7 @@ FQ_DEV void insert_keys(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 sub,
 FQ_DEV void lq_flush(Wk &w, u32 kind) {
   const Mail &m = w.cfg->mail[kind];
   u32 a = w.la[kind], n = w.mn[kind];
-  if (a >= n) return;
+  if (a >= n) { w.pq_n[kind == MAIL_S ? 1 : 0] = 0; return; }
   TM_BEGIN(t_lq);
   u64 ns = 0;
   u32 err = 0;
@@ -369,9 +381,34 @@ FQ_DEV void lq_flush(Wk &w, u32 kind) {
   insert_keys(*w.cfg, w.sm, kind == MAIL_S ? w.cfg->l_s : w.cfg->l_b, w.tid, m.list + (u64)w.tid * m.cap + a, n - a,
               kind == MAIL_S ? RNG_LS : RNG_LB, kind == MAIL_S ? CINC_S : CINC_B, ns, err);
   w.la[kind] = n;
+  w.pq_n[kind == MAIL_S ? 1 : 0] = 0;
   w.st[ST_LINS] += n - a;
   if (err) w.err = FQSX_ERR_LTAB_FULL;
   TM_END(w, TM_LQ, t_lq);
+}
+
+// Before a local look-up: apply the pending inserts only if one of them could change the answer
+// (same sibling group as the looked-up full k-mer), the mirror overflowed, or the k-mer is partial.
+FQ_DEV void lq_sync_for(Wk &w, u32 kind, const KGeom &g, const Kmer &km) {
+  const u32 qi = kind == MAIL_S ? 1 : 0;
+  const u32 pn = w.pq_n[qi];
+  if (w.la[kind] >= w.mn[kind]) return;
+  bool need = pn == ~0u || km.cur != g.k;
+  if (!need) {
+    const u32 k2 = 2 * g.k;
+    const bool nd = km_norm_dir(km, g);
+    const u64 v = (nd ? km.dir : km.rc) >> (64 - k2);
+    const u64 lowmask = (1ull << (k2 - 2)) - 1ull;
+    const u64 grp = nd ? (v >> 2) : (v & lowmask);
+    bool hit = false;
+    FQ_SYNC();
+    for (u32 t = FQ_LANE; t < pn; t += FQ_WAVE) {
+      u64 pv = w.sm->pq_key[qi][t] >> (64 - k2);
+      hit |= nd ? ((pv >> 2) == grp) : ((pv & lowmask) == grp);
+    }
+    need = wave_any(hit);
+  }
+  if (need) lq_flush(w, kind);
 }
 
 // find / find_full / find_partial (ht_kmer.h:189-203,266-327,504-510)
@@ -886,6 +923,11 @@ FQ_DEV void mail_push(Wk &w, u32 kind, u64 x) {
   m.list[(u64)w.tid * m.cap + c] = x;
   w.mn[kind] = c + 1;
   w.st[ST_MAIL] += 1;
+  if (kind != MAIL_P) {
+    const u32 qi = kind == MAIL_S ? 1 : 0;
+    u32 pn = w.pq_n[qi];
+    if (pn < 64) { w.sm->pq_key[qi][pn] = x; w.pq_n[qi] = pn + 1; } else w.pq_n[qi] = ~0u;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -992,14 +1034,14 @@ FQ_DEV u32 find_counts(Wk &w, C4 &counts, bool b_miss_known) {
       }
       return LV_BMER;
     } else {
-      lq_flush(w, MAIL_B);
+      lq_sync_for(w, MAIL_B, cfg->gb, w.bm);
       if (kt_find(w, cfg->l_b, false, cfg->gb, w.bm, RNG_LB, CINC_B, counts)) return LV_BMER;
       if (w.bm.dir != w.bm_u.dir && kt_find(w, cfg->g_b, true, cfg->gb, w.bm_u, RNG_B, CINC_B, counts)) return LV_BMER_UNC;
     }
   }
   if (km_almost_full(w.sm_, cfg->gs, smargin)) {
     if (kt_find(w, cfg->g_s, true, cfg->gs, w.sm_, RNG_S, CINC_S, counts)) return LV_SMER;
-    lq_flush(w, MAIL_S);
+    lq_sync_for(w, MAIL_S, cfg->gs, w.sm_);
     if (kt_find(w, cfg->l_s, false, cfg->gs, w.sm_, RNG_LS, CINC_S, counts)) return LV_SMER;
   } else if (find_counts_p(w, counts))
     return LV_PMER;
@@ -1254,6 +1296,9 @@ FQ_DEV void flush_pushes(Wk &w, u32 a, u32 b) {
     if (w.mn[MAIL_B] + tb > mb.cap || w.mn[MAIL_S] + ts > ms.cap || w.mn[MAIL_P] + tp > mp.cap) { w.err = FQSX_ERR_MAIL_FULL; return; }
     if (nb) mb.list[(u64)w.tid * mb.cap + w.mn[MAIL_B] + ob] = sm->pv_b[t];
     if (nsm) ms.list[(u64)w.tid * ms.cap + w.mn[MAIL_S] + os] = sm->pv_s[t];
+    // LDS mirror of the entries still pending for the local tables
+    if (w.pq_n[0] != ~0u && w.pq_n[0] + tb <= 64) { if (nb) sm->pq_key[0][w.pq_n[0] + ob] = sm->pv_b[t]; w.pq_n[0] += tb; } else w.pq_n[0] = ~0u;
+    if (w.pq_n[1] != ~0u && w.pq_n[1] + ts <= 64) { if (nsm) sm->pq_key[1][w.pq_n[1] + os] = sm->pv_s[t]; w.pq_n[1] += ts; } else w.pq_n[1] = ~0u;
     if (npm) {
       u64 *dst = mp.list + (u64)w.tid * mp.cap + w.mn[MAIL_P] + op;
       dst[0] = sm->pv_pd[t];
@@ -1522,6 +1567,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
     w.repm_gate = !((nf ? (double)nu / (double)nf : 0.0) < 7.0);
   }
   w.la[0] = w.la[1] = w.la[2] = 0;
+  w.pq_n[0] = w.pq_n[1] = 0;
   FQ_SYNC();
   w.enc.low = ws->rc_low; w.enc.range = ws->rc_range; w.enc.len = ws->out_len;
   w.enc.cap = cfg.out_cap; w.enc.out = cfg.out + (u64)tid * cfg.out_cap;

@@ -76,6 +76,15 @@ int fqsx_dna_stats(fqsx_dna *, uint64_t out[32]);
 int fqsx_dna_set_profiling(fqsx_dna *, int enable);
 int fqsx_dna_kernel_times(fqsx_dna *, double out[6]);
 
+/* Host-side (CPU) read-length stream that accompanies every DNA stream in the container
+ * (CMetaCompressor::CompressReadLen, fqs/meta.cpp:48-113; one symbol per read, not part of the hot path).
+ * Same worker partition as the DNA path; streams valid until the next call. */
+typedef struct fqsx_meta fqsx_meta;
+int fqsx_meta_create(uint32_t T, fqsx_meta **out);
+int fqsx_meta_encode_block(fqsx_meta *, const uint32_t *read_len, uint32_t n_reads, const uint8_t **streams,
+                           uint64_t *lens);
+void fqsx_meta_destroy(fqsx_meta *);
+
 const char *fqsx_last_error(void);
 const char *fqsx_version(void);
 

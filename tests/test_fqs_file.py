@@ -1,0 +1,54 @@
+"""Complete .fqs files written around the DNA path: byte identity with the reference's own files and
+round trip through the unmodified reference decompressor (oracle/_ref/fqs-1.1 d)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import EMU_LIB, GOLD, ROOT, c1_records, c4_records
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.fqsfile import compress_records
+
+REF = os.path.join(ROOT, "oracle", "_ref", "fqs-1.1")
+
+
+def _decode_with_reference(data: bytes, tmp_path):
+    f = tmp_path / "x.fqs"
+    f.write_bytes(data)
+    out = tmp_path / "x.fq"
+    subprocess.check_call([REF, "d", "-out", str(out), str(f)], stdout=subprocess.DEVNULL)
+    return out.read_bytes().split(b"\n")[1::4]
+
+
+def _lib(request):
+    return None if request.node.get_closest_marker("gpu") else EMU_LIB
+
+
+@pytest.mark.parametrize("name,rec_fn,T,gs", [("c4_ragged_o_t3.fqs", c4_records, 3, 1), ("c1_10k_o_t4.fqs", c1_records, 4, 1)])
+def test_file_identical_to_reference_original_order(built, name, rec_fn, T, gs):
+    data = compress_records(rec_fn(), T, "o", gs, lib_path=EMU_LIB)
+    assert data == open(os.path.join(GOLD, name), "rb").read()
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference binary not built")
+@pytest.mark.parametrize("order", ["o", "s"])
+def test_reference_decoder_reads_our_file(built, tmp_path, order):
+    rec = c4_records()
+    data = compress_records(rec, 5, order, 1, lib_path=EMU_LIB)
+    got = _decode_with_reference(data, tmp_path)
+    if order == "o":
+        want = [rec.seq[i] for i in range(len(rec))]
+    else:
+        want = [rec.seq[int(i)] for i in np.concatenate(hp.sorted_order(rec))]
+    assert got[:len(want)] == want
+
+
+@pytest.mark.gpu
+def test_gpu_file_identical_to_reference_and_decodes(tmp_path):
+    data = compress_records(c1_records(), 4, "o", 1)
+    assert data == open(os.path.join(GOLD, "c1_10k_o_t4.fqs"), "rb").read()
+    if os.path.exists(REF):
+        rec = c4_records()
+        got = _decode_with_reference(compress_records(rec, 64, "s", 1), tmp_path)
+        assert got[:len(rec)] == [rec.seq[int(i)] for i in np.concatenate(hp.sorted_order(rec))]
