@@ -37,9 +37,18 @@ FQ_KERNEL64 void k_encode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
   FQ_SHARED WgShared sm;
   encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
 }
-FQ_KERNEL64 void k_insert_phase(DevCfg cfg) {
+FQ_KERNEL64 void k_insert_phase(DevCfg cfg) {  // grid = 3 * T: (owner, mailbox kind)
   FQ_SHARED WgShared sm;
-  insert_phase_body(cfg, &sm, FQ_BLOCK);
+  insert_phase_body(cfg, &sm, FQ_BLOCK / 3, FQ_BLOCK % 3);
+}
+// gathers the T streams of the block into one contiguous buffer (one D2H transfer per block)
+FQ_KERNEL64 void k_compact_streams(DevCfg cfg, const u64 *lens, u8 *dst) {
+  const u32 tid = FQ_BLOCK;
+  u64 off = 0;
+  for (u32 t = 0; t < tid; ++t) off += lens[t];
+  const u64 n = lens[tid] <= cfg.out_cap ? lens[tid] : 0;
+  const u8 *src = cfg.out + (u64)tid * cfg.out_cap;
+  for (u64 i = FQ_LANE; i < n; i += FQ_WAVE) dst[off + i] = src[i];
 }
 FQ_KERNEL64 void k_finish_block(DevCfg cfg, u64 *lens /*[T+1]*/) {
   if (FQ_LANE == 0) {
@@ -153,6 +162,8 @@ struct fqsx_dna {
   u64 *d_off;
   u32 *d_demand;
   u64 *d_lens;
+  u8 *d_compact;
+  u64 compact_cap;
   std::vector<u32> h_demand, h_filled;
   std::vector<u8> h_out;
   std::vector<u64> h_lens;
@@ -433,12 +444,11 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
       if (need * 2 > cap && (rc = grow_global(c, t, cap, pow2_at_least(need * 2 + 2)))) return rc;
     }
     for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_scatter, T * cfg.mail[k].n_tiles, 64, cfg, k);
-    LAUNCH(c, 1, k_insert_phase, T, 64, cfg);
+    LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg);
     // ClearKmersToHT, dna.cpp:2475-2488 (mailbox counters are rewritten by the next encode launch)
     if ((rc = dzero(c, cfg.l_b.slots, need_lb * T * sizeof(u64)))) return rc;
     if ((rc = dzero(c, cfg.l_s.slots, need_ls * T * sizeof(u64)))) return rc;
-    if ((rc = dzero(c, cfg.l_b.filled, T * sizeof(u32)))) return rc;
-    if ((rc = dzero(c, cfg.l_s.filled, T * sizeof(u32)))) return rc;
+    if ((rc = dzero(c, cfg.l_s.filled, 2 * T * sizeof(u32)))) return rc;  // l_s.filled and l_b.filled are adjacent
   }
   LAUNCH(c, 2, k_finish_block, T, 64, cfg, c->d_lens);
   // ---- results
@@ -454,21 +464,21 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
     if (c->h_lens[t] > c->out_cap) { g_err = "stream overflow"; return FQSX_E_DEVICE; }
     total += c->h_lens[t];
   }
+  if (total > c->compact_cap) {
+    dfree(c, c->d_compact);
+    if ((rc = dalloc(c, &p, total + total / 2 + 4096, false))) return rc;
+    c->d_compact = (u8 *)p;
+    c->compact_cap = total + total / 2 + 4096;
+  }
+  LAUNCH(c, 2, k_compact_streams, T, 64, cfg, (const u64 *)c->d_lens, c->d_compact);
   c->h_out.resize(total ? total : 1);
+  if (total && (rc = d2h_sync(c, c->h_out.data(), c->d_compact, total))) return rc;
   u64 pos = 0;
   for (u32 t = 0; t < T; ++t) {
-#ifndef FQSX_EMU
-    HIPCHK(hipMemcpyAsync(c->h_out.data() + pos, cfg.out + (u64)t * cfg.out_cap, c->h_lens[t], hipMemcpyDeviceToHost, c->stream));
-#else
-    memcpy(c->h_out.data() + pos, cfg.out + (u64)t * cfg.out_cap, c->h_lens[t]);
-#endif
     streams[t] = c->h_out.data() + pos;
     lens[t] = c->h_lens[t];
     pos += c->h_lens[t];
   }
-#ifndef FQSX_EMU
-  HIPCHK(hipStreamSynchronize(c->stream));
-#endif
   return FQSX_OK;
 }
 
@@ -496,8 +506,11 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   if ((rc = ktab_alloc(c, cfg.g_b, T, c->gb_cap, cfg.bmer, 6, true))) return rc;
   // local tables: geometry chosen per block; counters allocated here
   c->ls_cap = c->lb_cap = 1024;
-  if ((rc = ktab_alloc(c, cfg.l_s, T, c->ls_cap, cfg.smer, 12, true))) return rc;
-  if ((rc = ktab_alloc(c, cfg.l_b, T, c->lb_cap, cfg.bmer, 6, true))) return rc;
+  if ((rc = ktab_alloc(c, cfg.l_s, T, c->ls_cap, cfg.smer, 12, false))) return rc;
+  if ((rc = ktab_alloc(c, cfg.l_b, T, c->lb_cap, cfg.bmer, 6, false))) return rc;
+  if ((rc = dalloc(c, &p, 2 * (u64)T * sizeof(u32), true))) return rc;  // occupancy counters of both, adjacent
+  cfg.l_s.filled = (u32 *)p;
+  cfg.l_b.filled = (u32 *)p + T;
   // contexts
   c->ctx_cap = 1u << 14;
   if ((rc = dalloc(c, &p, c->ctx_cap * T * sizeof(CtxSlot), true))) return rc;
@@ -606,6 +619,8 @@ int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) {
   c->dev_bases_cap = c->dev_off_cap = 0;
   c->d_bases = nullptr;
   c->d_off = nullptr;
+  c->d_compact = nullptr;
+  c->compact_cap = 0;
 #ifndef FQSX_EMU
   HIPCHK(hipStreamCreate(&c->stream));
   HIPCHK(hipEventCreate(&c->ev0));

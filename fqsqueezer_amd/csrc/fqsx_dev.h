@@ -1768,21 +1768,15 @@ FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor 
   }
 }
 
-// owner `tid` applies its group of every mailbox (InsertKmersToHT, dna.cpp:2393-2472)
-FQ_DEV void insert_phase_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
+// owner `tid` applies its group of mailbox `kind` (InsertKmersToHT, dna.cpp:2393-2472).  The three
+// mailboxes touch disjoint state (p-mer vector / ht_smer + cinc_s / ht_bmer + cinc_b), so they run as
+// three independent workgroups per owner.
+FQ_DEV void insert_phase_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 kind) {
   WState *ws = cfg.ws + tid;
-  u32 err = 0;
-  u64 n_words = 0, n_ins = 0, n_slots = 0;
-  FQ_SYNC();
-  for (u32 g = RNG_B; g <= RNG_S; ++g) {
-    for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) sm->mt[g][i] = ws->mt[g][i];
-    if (FQ_LANE == 0) sm->mt_idx[g] = ws->mt_idx[g];
-  }
-  FQ_SYNC();
-  // p-mers: saturating 2-bit increments; order-free, so lanes update concurrently with CAS
-  {
-    const Mail &m = cfg.mail[MAIL_P];
-    const u32 lo = m.dst_off[tid], hi = m.dst_off[tid + 1];
+  const Mail &m = cfg.mail[kind];
+  const u32 lo = m.dst_off[tid], hi = m.dst_off[tid + 1];
+  if (kind == MAIL_P) {
+    // p-mers: saturating 2-bit increments; order-free, so lanes update concurrently with CAS
     u64 nf = 0, nu = 0;
     for (u32 e = lo + FQ_LANE; e < hi; e += FQ_WAVE) {
       u64 idx = m.sorted[e];
@@ -1798,7 +1792,6 @@ FQ_DEV void insert_phase_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
       }
       ++nu;
     }
-    n_words += hi - lo;
     nf = wave_sum64(nf);
     nu = wave_sum64(nu);
     if (FQ_LANE == 0) {  // update_no_filled / update_no_updates, dna.cpp:2416-2418 (atomics, bit_vec.h:25-26)
@@ -1809,32 +1802,39 @@ FQ_DEV void insert_phase_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
       cfg.siv_stats[1] += nf;
       cfg.siv_stats[0] += nu + ws->hidden_updates;
 #endif
+      ws->hidden_updates = 0;
+      ws->stat[ST_SIV_WORDS] += hi - lo;
     }
-    FQ_SYNC_MEM();
-    ws->hidden_updates = 0;
+    return;
   }
-  // s-mers then b-mers
-  for (u32 kind = MAIL_S; kind <= MAIL_B; ++kind) {
-    const Mail &m = cfg.mail[kind];
-    const KTab &t = kind == MAIL_S ? cfg.g_s : cfg.g_b;
-    const u32 rng = kind == MAIL_S ? RNG_S : RNG_B;
-    const Cinc ci = kind == MAIL_S ? CINC_S : CINC_B;
-    const u32 lo = m.dst_off[tid], hi = m.dst_off[tid + 1];
-    insert_keys(cfg, sm, t, tid, m.sorted + lo, hi - lo, rng, ci, n_slots, err);
-    n_ins += hi - lo;
-  }
+  const KTab &t = kind == MAIL_S ? cfg.g_s : cfg.g_b;
+  const u32 rng = kind == MAIL_S ? RNG_S : RNG_B;
+  const Cinc ci = kind == MAIL_S ? CINC_S : CINC_B;
+  u32 err = 0;
+  u64 n_slots = 0;
   FQ_SYNC();
-  for (u32 g = RNG_B; g <= RNG_S; ++g) {
-    for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) ws->mt[g][i] = sm->mt[g][i];
-    ws->mt_idx[g] = sm->mt_idx[g];
+  for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) sm->mt[rng][i] = ws->mt[rng][i];
+  if (FQ_LANE == 0) sm->mt_idx[rng] = ws->mt_idx[rng];
+  FQ_SYNC();
+  insert_keys(cfg, sm, t, tid, m.sorted + lo, hi - lo, rng, ci, n_slots, err);
+  FQ_SYNC();
+  for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) ws->mt[rng][i] = sm->mt[rng][i];
+  n_slots = wave_sum64(n_slots);
+  if (FQ_LANE == 0) {
+    ws->mt_idx[rng] = sm->mt_idx[rng];
+#ifndef FQSX_EMU
+    atomicAdd((unsigned long long *)&ws->stat[ST_GINS], (unsigned long long)(hi - lo));
+    atomicAdd((unsigned long long *)&ws->stat[ST_GINS_SLOT], (unsigned long long)n_slots);
+#else
+    ws->stat[ST_GINS] += hi - lo;
+    ws->stat[ST_GINS_SLOT] += n_slots;
+#endif
   }
-  ws->stat[ST_GINS] += n_ins;
-  ws->stat[ST_GINS_SLOT] += wave_sum64(n_slots);
-  ws->stat[ST_SIV_WORDS] += n_words;
   if (err) *cfg.err = err;
 }
 
-// End() of the block's range coder: 8 flush bytes (sub_rc.h:79-86, application.cpp:664-665)
+// End() of the block's range coder: 8 flush bytes (sub_rc.h:79-86, application.cpp:664-665); the stream
+// is then copied behind the other workers' streams so the host fetches the block in one transfer
 FQ_DEV void finish_block_body(const DevCfg &cfg, u32 tid) {
   WState *ws = cfg.ws + tid;
   u64 low = ws->rc_low, len = ws->out_len;
