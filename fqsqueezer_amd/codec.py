@@ -105,12 +105,12 @@ class DnaCodec:
         return sum(self._lens[w] for w in range(self.T))
 
     def stats(self) -> dict:
-        a = (C.c_uint64 * 32)()
+        a = (C.c_uint64 * 48)()
         rc = self._lib.fqsx_dna_stats(self._h, a)
         if rc:
             raise FqsxError(f"fqsx_dna_stats: {rc}: {self._lib.fqsx_last_error().decode()}")
         d = dict(zip(STAT_NAMES, list(a)))
-        d["timers"] = list(a)[16:32]
+        d["timers"] = list(a)[16:48]
         return d
 
     def set_profiling(self, on: bool) -> None:

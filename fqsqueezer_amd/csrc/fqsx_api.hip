@@ -58,7 +58,7 @@ FQ_KERNEL64 void k_finish_block(DevCfg cfg, u64 *lens /*[T+1]*/) {
 }
 // gathers the per-worker accounting counters: out[i] = sum over workers of stat[i]
 FQ_KERNEL64 void k_gather_stats(DevCfg cfg, u64 *out) {
-  for (u32 i = FQ_LANE; i < 32; i += FQ_WAVE) {
+  for (u32 i = FQ_LANE; i < 48; i += FQ_WAVE) {
     u64 s = 0;
     for (u32 t = 0; t < cfg.T; ++t) s += cfg.ws[t].stat[i];
     out[i] = s;
@@ -572,11 +572,11 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   cfg.err = (u32 *)p;
   if ((rc = dalloc(c, &p, (2 * (u64)T + 1) * sizeof(u32), true))) return rc;
   c->d_demand = (u32 *)p;
-  if ((rc = dalloc(c, &p, ((u64)T + 48) * sizeof(u64), true))) return rc;
+  if ((rc = dalloc(c, &p, ((u64)T + 64) * sizeof(u64), true))) return rc;
   c->d_lens = (u64 *)p;
   c->h_demand.assign(2 * T + 1, 0);
   c->h_filled.assign(T, 0);
-  c->h_lens.assign(T + 48, 0);
+  c->h_lens.assign(T + 64, 0);
 #ifndef FQSX_EMU
   HIPCHK(hipStreamSynchronize(c->stream));
 #endif
@@ -686,10 +686,10 @@ int fqsx_dna_encode_block(fqsx_dna *c, const uint8_t *bases, const uint64_t *off
   return encode_block_impl(c, c->d_bases, c->d_off, off, n_reads, generation, streams, lens);
 }
 
-int fqsx_dna_stats(fqsx_dna *c, uint64_t out[32]) {
+int fqsx_dna_stats(fqsx_dna *c, uint64_t out[48]) {
   if (!c || !out) return FQSX_E_ARG;
   LAUNCH(c, 2, k_gather_stats, 1, 64, c->cfg, c->d_lens + c->T);
-  return d2h_sync(c, out, c->d_lens + c->T, 32 * sizeof(u64));
+  return d2h_sync(c, out, c->d_lens + c->T, 48 * sizeof(u64));
 }
 
 int fqsx_dna_set_profiling(fqsx_dna *c, int enable) {

@@ -32,7 +32,14 @@ struct WgShared {
   u8 pv_flag[FQSX_SPEC];       // PV_* bits
   u64 lev_tmp[10];             // level keys of a position coded outside the fast path
   u64 pq_key[2][64];           // LDS mirror of the list entries not yet applied to the local tables (b, s)
+  // stage P, positions whose global b-mer probe missed: the rest of find_counts' cascade and the
+  // Hamming-1 fall-back, resolved lane-parallel (valid while no pending local insert interferes)
+  u32 sx_lb[FQSX_SPEC];        // local b-mer counts, 4 x 8 bit
+  u64 sx_s[FQSX_SPEC];         // global s-mer counts, 4 x 16 bit
+  u64 sx_ls[FQSX_SPEC];        // local s-mer counts, 4 x 16 bit
+  u8 sx_flag[FQSX_SPEC];       // SX_* bits
 };
+enum { SX_VALID = 1, SX_LB = 2, SX_S = 4, SX_LS = 8 };
 enum { PV_B = 1, PV_S = 2, PV_P = 4, PV_PHID = 8, PV_PCAND = 16 };
 
 struct C4 { u32 c[4]; };
@@ -56,8 +63,9 @@ struct Wk {
   u32 mn[3];                            // entries appended to this worker's p/s/b mailbox lists
   u32 la[3];                            // list entries already applied to the local tables (b, s)
   u32 pq_n[2];                          // valid entries of the LDS mirror (b, s); ~0u = mirror overflowed
+  bool lq_applied;                      // a local-table flush happened since the last stage P (its local probes are stale)
   u64 st[ST_N];
-  u64 tm[16];
+  u64 tm[32];
   u32 err;
 };
 #ifdef FQSX_TIMING
@@ -375,12 +383,14 @@ FQ_DEV void lq_flush(Wk &w, u32 kind) {
   u32 a = w.la[kind], n = w.mn[kind];
   if (a >= n) { w.pq_n[kind == MAIL_S ? 1 : 0] = 0; return; }
   TM_BEGIN(t_lq);
+  TM_COUNT(w, CN_LQFLUSH);
   u64 ns = 0;
   u32 err = 0;
   FQ_SYNC_MEM();  // the list entries were written by other lanes
   insert_keys(*w.cfg, w.sm, kind == MAIL_S ? w.cfg->l_s : w.cfg->l_b, w.tid, m.list + (u64)w.tid * m.cap + a, n - a,
               kind == MAIL_S ? RNG_LS : RNG_LB, kind == MAIL_S ? CINC_S : CINC_B, ns, err);
   w.la[kind] = n;
+  w.lq_applied = true;
   w.pq_n[kind == MAIL_S ? 1 : 0] = 0;
   w.st[ST_LINS] += n - a;
   if (err) w.err = FQSX_ERR_LTAB_FULL;
@@ -985,9 +995,9 @@ FQ_DEV bool rough_p(Wk &w, C4 &counts) {  // find_counts_rough_p, dna.cpp:229-25
   return c4_any(counts);
 }
 // find_counts_rough_s / _b, dna.cpp:257-330: Hamming-1 neighbourhood, probes batched, merges serial
-FQ_DEV bool rough_kt(Wk &w, const KTab &t, const KGeom &g, const Kmer &can, u32 rng, const Cinc &ci, C4 &counts) {
+// probes of the Hamming-1 neighbourhood into the LDS batch; returns their number
+FQ_DEV u32 rough_probe(Wk &w, const KTab &t, const KGeom &g, const Kmer &can) {
   WgShared *sm = w.sm;
-  c4_zero(counts);
   const u32 n = 4 * (g.k - 1);
   FQ_SYNC();
   for (u32 q = FQ_LANE; q < n; q += FQ_WAVE) {
@@ -1002,6 +1012,12 @@ FQ_DEV bool rough_kt(Wk &w, const KTab &t, const KGeom &g, const Kmer &can, u32 
     sm->bk_dir[q] = nd ? 1 : 0;
   }
   batch_scan(w, t, true, n);
+  return n;
+}
+FQ_DEV bool rough_kt(Wk &w, const KTab &t, const KGeom &g, const Kmer &can, u32 rng, const Cinc &ci, C4 &counts) {
+  WgShared *sm = w.sm;
+  c4_zero(counts);
+  const u32 n = rough_probe(w, t, g, can);
   u64 hm[4];
   batch_hit_mask(w, n, hm);
   for (u32 r = 0; r < 4; ++r)
@@ -1188,6 +1204,37 @@ FQ_DEV void prefix_sorted(Wk &w, const u8 *p, u32 size) {  // compress_prefix_so
   push_p_both(w);
 }
 
+// Would a pending (not yet applied) local insert change a look-up of full k-mer `km`?  Pending = LDS
+// mirror of the list tail + the entries of chunk positions [q_done, j) that stage Q has not appended yet.
+FQ_DEV bool pend_conflict(Wk &w, u32 qi, const KGeom &g, const Kmer &km, u32 q_done, u32 j) {
+  WgShared *sm = w.sm;
+  const u32 pn = w.pq_n[qi];
+  if (pn == ~0u) return true;
+  const u32 k2 = 2 * g.k;
+  const bool nd = km_norm_dir(km, g);
+  const u64 v = (nd ? km.dir : km.rc) >> (64 - k2);
+  const u64 lowmask = (1ull << (k2 - 2)) - 1ull;
+  const u64 grp = nd ? (v >> 2) : (v & lowmask);
+  bool hit = false;
+  FQ_SYNC();
+  for (u32 t = FQ_LANE; t < pn; t += FQ_WAVE) {
+    u64 pv = sm->pq_key[qi][t] >> (64 - k2);
+    hit |= nd ? ((pv >> 2) == grp) : ((pv & lowmask) == grp);
+  }
+  for (u32 t = q_done + FQ_LANE; t < j; t += FQ_WAVE)
+    if (sm->pv_flag[t] & (qi ? PV_S : PV_B)) {
+      u64 pv = (qi ? sm->pv_s[t] : sm->pv_b[t]) >> (64 - k2);
+      hit |= nd ? ((pv >> 2) == grp) : ((pv & lowmask) == grp);
+    }
+  return wave_any(hit);
+}
+// repair_kmers_existing decision (dna.cpp:333-360): symbol to substitute or 0xff
+FQ_DEV u32 repair_decide(const Wk &w, const C4 &c, u32 sym) {
+  u32 mx = let_max(c, w.s_let);
+  if (sym == 4 || (mx != sym && c4_get(c, sym) == 0 && c4_get(c, mx) > 3)) return mx;
+  return 0xff;
+}
+
 // Stage P of one chunk of <= 64 suffix positions (one per lane).  Lane j rolls the six k-mers
 // forward to position i0+j, probes the global b-mer table and -- on a plain hit -- derives everything
 // that depends only on (counts, position, symbol): the 7 context keys, the symbol's rank, the
@@ -1195,8 +1242,9 @@ FQ_DEV void prefix_sorted(Wk &w, const u8 *p, u32 size) {  // compress_prefix_so
 FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n) {
   const DevCfg *cfg = w.cfg;
   WgShared *sm = w.sm;
-  u64 ns = 0;
-  u32 np = 0;
+  u64 ns = 0, nls = 0;
+  u32 np = 0, nlp = 0;
+  w.lq_applied = false;
   FQ_SYNC();
   for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
     // roll the six k-mers j symbols forward in closed form: only the last min(j, k) new symbols matter
@@ -1248,11 +1296,43 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n) {
           sm->sp_cnt[j] = c.c[0] | (c.c[1] << 8) | (c.c[2] << 16) | (c.c[3] << 24);
           sm->sp_rsym[j] = (u8)rank_sym(w, c, sym);
           // repair_kmers_existing decision (dna.cpp:333-360)
-          u32 mx = let_max(c, w.s_let);
-          if (sym == 4 || (mx != sym && c4_get(c, sym) == 0 && c4_get(c, mx) > 3)) rep = mx;
+          rep = repair_decide(w, c, sym);
         }
-      } else
+      } else {
+        // global b-mer miss: rest of find_counts' cascade (dna.cpp:478-499) for the common case of a full
+        // s-mer and no pending correction; the local probes see the tables as of the last flush
         flag = 3;
+        u32 xf = 0;
+        if (bm.dir == bu.dir && sk.cur == cfg->gs.k) {
+          xf = SX_VALID;
+          C4 l;
+          c4_zero(l);
+          tab_scan(cfg->l_b, w.tid, key, nd, l, nls);
+          ++nlp;
+          if (c4_any(l)) {
+            xf |= SX_LB;
+            sm->sx_lb[j] = l.c[0] | (l.c[1] << 8) | (l.c[2] << 16) | (l.c[3] << 24);
+          } else {
+            const bool nds = km_norm_dir(sk, cfg->gs);
+            const u64 ks = nds ? sk.dir : sk.rc;
+            c4_zero(l);
+            tab_scan(cfg->g_s, sb_owner(cfg, ks), ks, nds, l, ns);
+            ++np;
+            if (c4_any(l)) {
+              xf |= SX_S;
+              sm->sx_s[j] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
+            } else {
+              tab_scan(cfg->l_s, w.tid, ks, nds, l, nls);
+              ++nlp;
+              if (c4_any(l)) {
+                xf |= SX_LS;
+                sm->sx_ls[j] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
+              }
+            }
+          }
+        }
+        sm->sx_flag[j] = (u8)xf;
+      }
     }
     sm->sp_flag[j] = (u8)flag;
     sm->sp_rep[j] = (u8)rep;
@@ -1276,6 +1356,8 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n) {
   FQ_SYNC();
   w.st[ST_GPROBE] += wave_sum32(np);
   w.st[ST_GSLOT] += wave_sum64(ns);
+  w.st[ST_LPROBE] += wave_sum32(nlp);
+  w.st[ST_LSLOT] += wave_sum64(nls);
 }
 
 // Stage Q: append the mailbox entries of chunk positions [a,b) to this worker's lists, lane-parallel,
@@ -1356,6 +1438,11 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {
       const u32 sym = rd_sym(w, p, pos, size);
       const u64 sym_k = sym == 4 ? 0 : sym;
       const u32 flag = sm->sp_flag[j];
+      if (flag == 3 && j > 0 && w.lq_applied && (sm->sx_flag[j] & SX_VALID)) {
+        // the local tables changed since stage P probed them: re-run stage P from this position
+        TM_COUNT(w, CN_LQSTALE);
+        break;
+      }
       TM_BEGIN(t_code);
       if (flag == 1) {
         // fast path: level bmer; only the adaptive model and the range coder are serial
@@ -1381,35 +1468,75 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {
           dirty = true;
         }
       } else {
-        // complete reference logic on the exact k-mers of this position
-        flush_pushes(w, q_done, j);
-        q_done = j;
-        load_state(w, j);
+        // not settled by stage P alone
         C4 counts;
+        c4_zero(counts);
+        u32 level = LV_NONE, nrun_here = sm->sp_nrun[j];
+        bool rough = false, loaded = false, resolved = false;
         TM_COUNT(w, CN_SLOW);
-        TM_BEGIN(t_fc);
-        u32 level = find_counts(w, counts, flag == 3);
-        TM_END(w, TM_FINDC, t_fc);
-        if (level == LV_BMER_UNC) {
-          w.bm = w.bm_u; w.sm_ = w.sm_u; w.pm = w.pm_u;
-          w.cor_pos = 0;
-          level = LV_BMER;
-          dirty = true;
-        }
-        bool rough = false;
-        if (level == LV_NONE) {
-          TM_BEGIN(t_r);
-          TM_COUNT(w, CN_ROUGH);
-          if (km_full(w.bm, cfg->gb)) {
-            if (rough_kt(w, cfg->g_b, cfg->gb, w.bm, RNG_B, CINC_B, counts)) { level = LV_PMER; rough = true; }
-          } else if (km_full(w.sm_, cfg->gs)) {
-            if (rough_kt(w, cfg->g_s, cfg->gs, w.sm_, RNG_S, CINC_S, counts)) { level = LV_PMER; rough = true; }
-          } else if (km_full(w.pm, cfg->gp)) {
-            if (rough_p(w, counts)) { level = LV_PMER; rough = true; }
+        const u32 xf = flag == 3 ? sm->sx_flag[j] : 0;
+        if ((xf & SX_VALID) && !w.lq_applied) {
+          // the cascade was resolved in stage P; it stands unless a pending local insert interferes
+          Kmer bmj, smj;
+          bmj.dir = sm->sp_sdir[2][j]; bmj.rc = sm->sp_src[2][j]; bmj.cur = sm->sp_scur[2][j];
+          smj.dir = sm->sp_sdir[1][j]; smj.rc = sm->sp_src[1][j]; smj.cur = sm->sp_scur[1][j];
+          bool conflict = pend_conflict(w, 0, cfg->gb, bmj, q_done, j);
+          if (!conflict && !(xf & (SX_LB | SX_S))) conflict = pend_conflict(w, 1, cfg->gs, smj, q_done, j);
+          if (conflict) TM_COUNT(w, CN_CONFLICT);
+          if (!conflict) {
+            resolved = true;
+            TM_COUNT(w, CN_EXT);
+            if (xf & SX_LB) {
+              u32 pc = sm->sx_lb[j];
+              counts.c[0] = pc & 0xff; counts.c[1] = (pc >> 8) & 0xff; counts.c[2] = (pc >> 16) & 0xff; counts.c[3] = pc >> 24;
+              level = LV_BMER;
+            } else if (xf & (SX_S | SX_LS)) {
+              u64 pc = (xf & SX_S) ? sm->sx_s[j] : sm->sx_ls[j];
+              counts.c[0] = (u32)(pc & 0xffff); counts.c[1] = (u32)((pc >> 16) & 0xffff);
+              counts.c[2] = (u32)((pc >> 32) & 0xffff); counts.c[3] = (u32)(pc >> 48);
+              level = LV_SMER;
+            } else {
+              TM_BEGIN(t_r);
+              TM_COUNT(w, CN_ROUGH);
+              rough = rough_kt(w, cfg->g_b, cfg->gb, bmj, RNG_B, CINC_B, counts);  // dna.cpp:711-718
+              if (rough) level = LV_PMER;
+              TM_END(w, TM_ROUGH, t_r);
+            }
           }
-          TM_END(w, TM_ROUGH, t_r);
         }
-        if (level != LV_NONE && w.N_run < 2) {
+        if (flag == 0) TM_COUNT(w, CN_EARLY);
+        if (!resolved) {
+          TM_COUNT(w, CN_GENERIC);
+          // complete reference logic on the exact k-mers of this position
+          flush_pushes(w, q_done, j);
+          q_done = j;
+          load_state(w, j);
+          loaded = true;
+          nrun_here = w.N_run;
+          TM_BEGIN(t_fc);
+          level = find_counts(w, counts, flag == 3);
+          TM_END(w, TM_FINDC, t_fc);
+          if (level == LV_BMER_UNC) {
+            w.bm = w.bm_u; w.sm_ = w.sm_u; w.pm = w.pm_u;
+            w.cor_pos = 0;
+            level = LV_BMER;
+            dirty = true;
+          }
+          if (level == LV_NONE) {
+            TM_BEGIN(t_r);
+            TM_COUNT(w, CN_ROUGH);
+            if (km_full(w.bm, cfg->gb)) {
+              if (rough_kt(w, cfg->g_b, cfg->gb, w.bm, RNG_B, CINC_B, counts)) { level = LV_PMER; rough = true; }
+            } else if (km_full(w.sm_, cfg->gs)) {
+              if (rough_kt(w, cfg->g_s, cfg->gs, w.sm_, RNG_S, CINC_S, counts)) { level = LV_PMER; rough = true; }
+            } else if (km_full(w.pm, cfg->gp)) {
+              if (rough_p(w, counts)) { level = LV_PMER; rough = true; }
+            }
+            TM_END(w, TM_ROUGH, t_r);
+          }
+        }
+        // code the symbol (dna.cpp:737-801)
+        if (level != LV_NONE && nrun_here < 2) {
           int cor_dist = level == LV_PMER ? (int)cfg->pmer : level == LV_SMER ? (int)cfg->smer : (int)cfg->bmer;
           int d = (int)pos - (int)w.cor_pos;
           u32 cor_zone = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
@@ -1429,45 +1556,68 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {
           code_letter(w, pos, sym, size);
           ctx_r_sym = (ctx_r_sym << 1) & 0xff;
         }
-        if (sym == 4) ++w.N_run; else w.N_run = 0;
-        replace_last_all(w, sym_k);
-        // this position's mailbox entries from the exact k-mers (dna.cpp:818-852)
-        u32 pf = 0;
-        if (sym < 4) {
-          bool pmer_insert = true;
-          if (km_full(w.bm, cfg->gb)) {
-            pf |= PV_B;
-            if ((level == LV_SMER || level == LV_BMER || level == LV_MIXED) && c4_get(counts, sym) >= 3) pmer_insert = false;
+        // mailbox entries and context repair (dna.cpp:803-874)
+        const bool lvl_sbm = level == LV_SMER || level == LV_BMER || level == LV_MIXED;
+        if (loaded) {
+          if (sym == 4) ++w.N_run; else w.N_run = 0;
+          replace_last_all(w, sym_k);
+          u32 pf = 0;
+          if (sym < 4) {
+            bool pmer_insert = true;
+            if (km_full(w.bm, cfg->gb)) {
+              pf |= PV_B;
+              if (lvl_sbm && c4_get(counts, sym) >= 3) pmer_insert = false;
+            }
+            if (km_full(w.sm_, cfg->gs)) pf |= PV_S;
+            if (km_full(w.pm, cfg->gp) && pos - w.cor_pos >= cfg->pmer - 1) pf |= pmer_insert ? PV_P : PV_PHID;
           }
-          if (km_full(w.sm_, cfg->gs)) pf |= PV_S;
-          if (km_full(w.pm, cfg->gp) && pos - w.cor_pos >= cfg->pmer - 1) pf |= pmer_insert ? PV_P : PV_PHID;
-        }
-        FQ_SYNC();
-        if (FQ_LANE == 0) {
-          sm->pv_b[j] = km_norm(w.bm, cfg->gb);
-          sm->pv_s[j] = km_norm(w.sm_, cfg->gs);
-          sm->pv_pd[j] = km_aligned_dir(w.pm);
-          sm->pv_pr[j] = km_aligned_rc(w.pm);
-          sm->pv_flag[j] = (u8)pf;
-        }
-        FQ_SYNC();
-        w_pos = j + 1;
-        if (km_full(w.bm, cfg->gb)) {
-          bool rep = false;
-          if (level == LV_BMER || level == LV_MIXED) rep = repair_existing(w, pos, counts, sym);
-          else if (level == LV_NONE || level == LV_PMER) {
-            flush_pushes(w, q_done, j + 1);  // repair_missing probes only the global table; keep list order anyway
-            q_done = j + 1;
-            TM_BEGIN(t_rm);
-            TM_COUNT(w, CN_REPM);
-            rep = repair_missing(w, pos);
-            TM_END(w, TM_REPM, t_rm);
+          FQ_SYNC();
+          if (FQ_LANE == 0) {
+            sm->pv_b[j] = km_norm(w.bm, cfg->gb);
+            sm->pv_s[j] = km_norm(w.sm_, cfg->gs);
+            sm->pv_pd[j] = km_aligned_dir(w.pm);
+            sm->pv_pr[j] = km_aligned_rc(w.pm);
+            sm->pv_flag[j] = (u8)pf;
           }
-          if (rep) {
+          FQ_SYNC();
+          w_pos = j + 1;
+        } else {
+          // stage P's entries stand (k-mers unmodified); settle the p-mer entry, which depends on the level
+          u32 pf = sm->pv_flag[j];
+          if (pf & PV_PCAND) {
+            pf |= (lvl_sbm && c4_get(counts, sym) >= 3) ? PV_PHID : PV_P;   // the b-mer is full on this path
+            FQ_SYNC();
+            if (FQ_LANE == 0) sm->pv_flag[j] = (u8)pf;
+            FQ_SYNC();
+          }
+        }
+        // repairs need the exact k-mers only when they can fire
+        const bool b_full = loaded ? km_full(w.bm, cfg->gb) : true;
+        if (b_full) {
+          const bool chk_existing = level == LV_BMER || level == LV_MIXED;
+          const bool chk_missing = (level == LV_NONE || level == LV_PMER) && w.repm_gate;
+          const bool fire = chk_existing ? repair_decide(w, counts, sym) != 0xff : chk_missing;
+          if (fire) {
+            if (!loaded) {
+              load_state(w, j);
+              if (sym == 4) ++w.N_run; else w.N_run = 0;
+              replace_last_all(w, sym_k);
+              w_pos = j + 1;
+            }
             flush_pushes(w, q_done, j + 1);
             q_done = j + 1;
-            push_b_local(w);
-            dirty = true;
+            bool rep;
+            if (chk_existing) rep = repair_existing(w, pos, counts, sym);
+            else {
+              TM_BEGIN(t_rm);
+              TM_COUNT(w, CN_REPM);
+              rep = repair_missing(w, pos);
+              TM_END(w, TM_REPM, t_rm);
+            }
+            if (rep) {
+              push_b_local(w);
+              dirty = true;
+            }
           }
         }
         TM_END(w, TM_SLOW, t_code);
@@ -1540,7 +1690,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.ws = ws;
   w.err = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
-  for (u32 i = 0; i < 16; ++i) w.tm[i] = 0;
+  for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
   TM_BEGIN(t_total);
   const u64 T = cfg.T;
   // PartitionForWorkers, reads_block.h:197-214
@@ -1600,7 +1750,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   ws->hidden_updates = w.hidden;
   TM_END(w, TM_TOTAL, t_total);
   for (u32 i = 0; i < ST_N; ++i) ws->stat[i] += w.st[i];
-  for (u32 i = 0; i < 16; ++i) ws->stat[16 + i] += w.tm[i];
+  for (u32 i = 0; i < 32; ++i) ws->stat[16 + i] += w.tm[i];
   FQ_SYNC();
   for (u32 g = 0; g < 4; ++g) {
     for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) ws->mt[g][i] = sm->mt[g][i];

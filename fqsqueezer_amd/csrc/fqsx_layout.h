@@ -91,7 +91,7 @@ struct WState {
   u64 out_len;
   u32 mt_idx[4];                       // cinc_b, cinc_s, cinc_lb, cinc_ls (dna.h:113-116)
   u32 mt[4][624];
-  u64 stat[32];                        // probe/byte accounting, see ST_*; [16..23] in-kernel section times (10 ns ticks)
+  u64 stat[48];                        // probe/byte accounting, see ST_*; [16..23] in-kernel section times (10 ns ticks)
 };
 enum { RNG_B = 0, RNG_S = 1, RNG_LB = 2, RNG_LS = 3 };
 enum {
@@ -111,7 +111,8 @@ enum {
 };
 // section timers (only maintained by -DFQSX_TIMING builds)
 enum { TM_TOTAL = 0, TM_SPEC, TM_FAST, TM_SLOW, TM_POST, TM_READ_HEAD, TM_LQ, TM_ROUGH, TM_REPM, TM_FINDC,
-       CN_FAST, CN_SLOW, CN_CHUNK, CN_DIRTY, CN_ROUGH, CN_REPM, TM_N };
+       CN_FAST, CN_SLOW, CN_CHUNK, CN_DIRTY, CN_ROUGH, CN_REPM,
+       CN_EXT, CN_GENERIC, CN_LQFLUSH, CN_CONFLICT, CN_LQSTALE, CN_EARLY, CN_P2, TM_P2, TM_N };
 
 struct DevCfg {
   u32 T, mode;                 // mode 0 = original order, 1 = sorted (params.h:18)

@@ -67,8 +67,8 @@ int fqsx_dna_encode_block_dev(fqsx_dna *, const uint8_t *d_bases, const uint64_t
  * [0] global probes [1] global slots read [2] local probes [3] local slots read
  * [4] global inserts [5] slots read by them [6] siv words touched [7] context slots read
  * [8] symbols range-coded [9] local inserts [10] mailbox entries [11] input bases
- * [16..31] in-kernel section timers / event counts (10 ns ticks, only in -DFQSX_TIMING diagnostic builds) */
-int fqsx_dna_stats(fqsx_dna *, uint64_t out[32]);
+ * [16..47] in-kernel section timers / event counts (10 ns ticks, only in -DFQSX_TIMING diagnostic builds) */
+int fqsx_dna_stats(fqsx_dna *, uint64_t out[48]);
 
 /* Kernel timing: when enabled every launch is bracketed by HIP events on the codec's stream.
  * out[0..2] = accumulated milliseconds of the encode-segment, insert-phase and all other
