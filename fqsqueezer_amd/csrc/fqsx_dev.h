@@ -152,12 +152,14 @@ FQ_DEV u32 cinc_decode(const Cinc &c, u32 v) {  // utils.h:264-270
 }
 FQ_DEV u32 cinc_encode(WgShared *sm, u32 g, const Cinc &c, u32 real) {  // utils.h:272-290
   if (real <= c.thr) return real;
-  u32 lo = c.thr, hi = (real < c.maxv ? real : c.maxv);
-  while (lo < hi) {  // last position whose mapped value is <= real (upper_bound - 1)
-    u32 mid = (lo + hi + 1) / 2;
-    if (cinc_map(c, mid) <= real) lo = mid; else hi = mid - 1;
-  }
-  u32 pos = lo;
+  // last position whose mapped value is <= real (upper_bound - 1): largest n with mult*n(n+1)/2 <= real-thr,
+  // from the float square root plus an exact correction
+  const u32 R = real - c.thr;
+  u32 n = (u32)((sqrtf(1.0f + 8.0f * (float)R / (float)c.mult) - 1.0f) * 0.5f);
+  while (c.mult * (n * (n + 1) / 2) > R) --n;
+  while (c.mult * ((n + 1) * (n + 2) / 2) <= R) ++n;
+  u32 pos = c.thr + n;
+  if (pos > c.maxv) pos = c.maxv;
   if (pos >= c.maxv) return c.maxv;
   u32 mp = cinc_map(c, pos);
   u32 rest = real - mp;
@@ -505,12 +507,26 @@ FQ_DEV u64 siv_count_equal(Wk &w, u64 lo, u64 hi, u64 flag) {
   if (start >= hi) return 0;
   const u64 *sv = w.cfg->siv;
   const u64 rep = flag * 0x5555555555555555ULL;
-  u64 w0 = start >> 5, w1 = (hi - 1) >> 5, r = 0;
-  for (u64 x = w0 + FQ_LANE; x <= w1; x += FQ_WAVE) {
+  const u64 w0 = start >> 5, w1 = (hi - 1) >> 5;
+  const u64 m0 = ~0ull << (2 * (start & 31));
+  const u64 m1 = (hi & 31) ? ~(~0ull << (2 * (hi & 31))) : ~0ull;
+  u64 r = 0;
+  u64 x = w0 + FQ_LANE;
+  // four independent 512-byte wave loads in flight per iteration (the sweep is pure streaming)
+  for (; x + 3 * FQ_WAVE <= w1; x += 4 * FQ_WAVE) {
+    u64 d0 = sv[x], d1 = sv[x + FQ_WAVE], d2 = sv[x + 2 * FQ_WAVE], d3 = sv[x + 3 * FQ_WAVE];
+    d0 ^= rep; d1 ^= rep; d2 ^= rep; d3 ^= rep;
+    u64 e0 = ~(d0 | (d0 >> 1)) & 0x5555555555555555ULL, e1 = ~(d1 | (d1 >> 1)) & 0x5555555555555555ULL;
+    u64 e2 = ~(d2 | (d2 >> 1)) & 0x5555555555555555ULL, e3 = ~(d3 | (d3 >> 1)) & 0x5555555555555555ULL;
+    if (x == w0) e0 &= m0;
+    if (x + 3 * FQ_WAVE == w1) e3 &= m1;
+    r += popc64(e0) + popc64(e1) + popc64(e2) + popc64(e3);
+  }
+  for (; x <= w1; x += FQ_WAVE) {
     u64 d = sv[x] ^ rep;
     u64 eq = ~(d | (d >> 1)) & 0x5555555555555555ULL;
-    if (x == w0) eq &= ~0ull << (2 * (start & 31));
-    if (x == w1 && (hi & 31)) eq &= ~(~0ull << (2 * (hi & 31)));
+    if (x == w0) eq &= m0;
+    if (x == w1) eq &= m1;
     r += popc64(eq);
   }
   w.st[ST_SIV_WORDS] += w1 - w0 + 1;
@@ -827,6 +843,46 @@ FQ_DEV u64 conv_count(u64 c, u32 level, u32 cl) {  // code_ctx.cpp:15-23
   if (level == LV_BMER) return conv_lev3(c, cl);
   return conv_lev24(c, cl);
 }
+// The same quantisers as threshold tables (count of thresholds <= c): used by the wave-uniform
+// variant below, where the 24 compares of one quantiser are one ballot.
+#ifndef FQSX_EMU
+#define FQ_CONST __device__ const
+#else
+#define FQ_CONST static const
+#endif
+#define NOLIM 0xffffffffu
+FQ_CONST u32 CONV_D[12] = {5, 8, 8, 8, 3, 5, 10, 10, 3, 5, 10, 15};
+FQ_CONST u32 CONV_LIM[12][24] = {
+    // level pmer (conv_lev1), cnt_lev 0..3
+    {8, 16, 32, 64, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM},
+    {16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 288, 384, 512, 1024, 2048, NOLIM, NOLIM, NOLIM},
+    {16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 288, 384, 512, 1024, 2048, NOLIM, NOLIM, NOLIM},
+    {16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 288, 384, 512, 1024, 2048, NOLIM, NOLIM, NOLIM},
+    // levels smer / mixed / bmer_unc (conv_lev24)
+    {5, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM},
+    {8, 13, 20, 30, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM},
+    {15, 20, 30, 50, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM},
+    {16, 24, 32, 48, 64, 128, 256, 512, 1024, 2048, 2080, 2112, 2176, 2240, 2304, 2432, 2560, 2816, 3072, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM},
+    // level bmer (conv_lev3)
+    {5, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM},
+    {8, 13, 20, 30, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM},
+    {13, 20, 30, 50, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM},
+    {18, 20, 25, 30, 40, 50, 60, 64, 68, 72, 76, 80, 84, 88, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM, NOLIM}};
+// wave-uniform convert_count (code_ctx.cpp:15-239): all lanes pass the same c
+FQ_DEV u64 conv_wave(u64 c, u32 level, u32 cl) {
+  const u32 e = (level == LV_PMER ? 0u : level == LV_BMER ? 8u : 4u) + cl;
+  const u32 D = CONV_D[e];
+  const u64 f = (u64)cl << 5;
+  if (c < D) return f + c;
+#if FQ_WAVE > 1
+  const u32 lim = FQ_LANE < 24 ? CONV_LIM[e][FQ_LANE] : NOLIM;
+  const u32 cnt = popc64(wave_ballot((u64)lim <= c));
+#else
+  u32 cnt = 0;
+  for (u32 i = 0; i < 24; ++i) cnt += (u64)CONV_LIM[e][i] <= c;
+#endif
+  return f + D + cnt;
+}
 FQ_DEV void sort_desc4(u32 d[4], const C4 &c) {  // sort_copy_stats, utils.cpp:109-126 (descending, stable)
   u32 a = c.c[0], b = c.c[1], e = c.c[2], f = c.c[3], t;
   // insertion network that only swaps on strict "greater", i.e. stable
@@ -893,6 +949,50 @@ FQ_DEV void ctx_codes(u64 a[7], const DevCfg *cfg, const C4 &counts, const u64 *
   ctx += conv_count(srt[1], level, 3) << SH_C1;
   ctx += conv_count(srt[2], level, 1) << SH_C2;
   ctx += conv_count(srt[3], level, 1) << SH_C3;
+  a[4] = ctx | mask;
+  mask ^= EN_LETMAX;
+  ctx += (u64)let_max(counts, sl) << SH_LETMAX;
+  a[5] = ctx | mask;
+  ctx &= ~EN_POS;
+  if (in_lim) ctx += ((u64)pos + (1u << 13)) << SH_POS;
+  else if (eor) ctx += eor_v << SH_POS;
+  else ctx += ((u64)plim + pos / 8 + (1u << 13)) << SH_POS;
+  a[6] = ctx | mask;
+}
+// determine_ctx_codes for wave-uniform arguments (the commit loop): same keys, quantisers by ballot
+FQ_DEV void ctx_codes_wave(u64 a[7], const DevCfg *cfg, const C4 &counts, const u64 *sl, u32 pos, u32 level, u32 cor_zone, u64 ctx_r_sym, u32 read_len) {
+  u64 mask = ~0ull, ctx = 0;
+  u32 plim = level == 0 ? 0u : level == 1 ? cfg->pmer : level == 2 ? cfg->smer : cfg->bmer;
+  u32 srt[4];
+  sort_desc4(srt, counts);
+  a[0] = ctx | mask;
+  mask ^= EN_LEVEL | EN_CN(0) | EN_CN(1) | EN_CN(2) | EN_CN(3) | EN_POS;
+  ctx += (u64)level << SH_LEVEL;
+  const u64 c01 = conv_wave(srt[0], level, 1), c11 = conv_wave(srt[1], level, 1);
+  const u64 c21 = conv_wave(srt[2], level, 1), c31 = conv_wave(srt[3], level, 1);
+  ctx += c01 << SH_C0;
+  ctx += c11 << SH_C1;
+  ctx += conv_wave(srt[2], level, 0) << SH_C2;
+  ctx += conv_wave(srt[3], level, 0) << SH_C3;
+  const bool in_lim = pos < plim, eor = pos + 5 >= read_len;
+  const u64 eor_v = 0x3fffull - (u64)(u32)(read_len - pos);
+  if (in_lim) ctx += (u64)pos << SH_POS;
+  else if (eor) ctx += eor_v << SH_POS;
+  else ctx += (u64)(plim + pos / 16) << SH_POS;
+  a[1] = ctx | mask;
+  mask ^= EN_CORZ | EN_RSYM;
+  ctx += (u64)cor_zone << SH_CORZ;
+  ctx += (u64)popc64(ctx_r_sym) << SH_RSYM;
+  a[2] = ctx | mask;
+  ctx &= ~(EN_CN(0) | EN_CN(1));
+  ctx += conv_wave(srt[0], level, 2) << SH_C0;
+  ctx += conv_wave(srt[1], level, 2) << SH_C1;
+  a[3] = ctx | mask;
+  ctx &= ~(EN_CN(0) | EN_CN(1) | EN_CN(2) | EN_CN(3));
+  ctx += conv_wave(srt[0], level, 3) << SH_C0;
+  ctx += conv_wave(srt[1], level, 3) << SH_C1;
+  ctx += c21 << SH_C2;
+  ctx += c31 << SH_C3;
   a[4] = ctx | mask;
   mask ^= EN_LETMAX;
   ctx += (u64)let_max(counts, sl) << SH_LETMAX;
@@ -1542,7 +1642,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {
           u32 cor_zone = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
           if (rough) cor_zone = 3;
           u64 lev[7];
-          ctx_codes(lev, cfg, counts, w.s_let, pos, level, cor_zone, ctx_r_sym, size);
+          ctx_codes_wave(lev, cfg, counts, w.s_let, pos, level, cor_zone, ctx_r_sym, size);
           FQ_SYNC();
           for (u32 l = 0; l < 7; ++l) sm->lev_tmp[l] = lev[l];
           FQ_SYNC();

@@ -78,6 +78,7 @@ FQ_DEV u64 atomic_cas64(u64 *p, u64 expect, u64 desired) {
 FQ_DEV double ema_update(double avg, double level) { return __dadd_rn(__dmul_rn(0.999, avg), __dmul_rn(1.0 - 0.999, level)); }
 
 #else  // ---------------------------------------------------------------- host emulation
+#include <math.h>
 #include <string.h>
 #define FQ_DEV static inline
 #define FQ_DEVN static
