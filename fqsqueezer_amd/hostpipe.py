@@ -265,3 +265,76 @@ def write_fqs(header: bytes, blocks: Iterable[FqsBlock]) -> bytes:
                 out.append(put_varint(len(st[sid])))
                 out.append(st[sid])
     return b"".join(out)
+
+
+# ----------------------------------------------------------------------------------------
+# paired-end host logic
+def _host_lib():
+    """libfqsx_host.so: the CPU-only helpers of csrc/fqsx_host.cpp (exact std::sort bin order, meta coder)."""
+    import ctypes as C
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "libfqsx_host.so")
+    src = os.path.join(here, "csrc", "fqsx_host.cpp")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", lib])
+    h = C.CDLL(lib)
+    h.fqsx_sort_bin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    return h
+
+
+def sorted_order_exact(rec: Records) -> List[np.ndarray]:
+    """Like sorted_order(), but reads that compare equal are ordered exactly as the reference's
+    std::sort leaves them (needed for paired-end data, where the mates follow this order)."""
+    n = len(rec)
+    all_idx = np.arange(n, dtype=np.int64)
+    bases, off = block_arrays(rec, all_idx)
+    bases = np.ascontiguousarray(bases)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    if isinstance(rec.seq, np.ndarray):
+        first4 = _NT_ARR[rec.seq[:, :4]]
+        bins = ((_CODE_NT[first4[:, 0]] * 4 + _CODE_NT[first4[:, 1]]) * 4 + _CODE_NT[first4[:, 2]]) * 4 + _CODE_NT[first4[:, 3]]
+    else:
+        bins = np.array([sum(_CODE_NT[c] << (2 * (3 - k)) for k, c in enumerate(s[:4])) for s in rec.seq], dtype=np.int64)
+    h = _host_lib()
+    out = []
+    for b in range(NO_BINS):
+        members = np.flatnonzero(bins == b).astype(np.uint32)     # input order inside the bin file
+        if not len(members):
+            continue
+        res = np.empty_like(members)
+        rc = h.fqsx_sort_bin(bases.ctypes.data, off.ctypes.data, members.ctypes.data, len(members), res.ctypes.data)
+        assert rc == 0
+        out.append(res.astype(np.int64))
+    return out
+
+
+def form_blocks_pe(rec1: Records, rec2: Records, dna_mode: str = "pe_sorted") -> List[np.ndarray]:
+    """Blocks of *pair* indices (CReadsBlock::Read(f1,f2), reads_block.h:141-166: pairs are appended
+    until fewer than 2*102400 bytes remain; sorted mode: one input file pair per non-empty bin, mates
+    follow mate 1's order, io.h:541-550)."""
+    sizes = rec1.record_sizes() + rec2.record_sizes()
+    groups = sorted_order_exact(rec1) if dna_mode == "pe_sorted" else [np.arange(len(rec1), dtype=np.int64)]
+    blocks: List[np.ndarray] = []
+    for g in groups:
+        cs = np.cumsum(sizes[g])
+        start, base = 0, 0
+        while start < len(g):
+            j = int(np.searchsorted(cs, base + READS_BLOCK_SIZE - 2 * BLOCK_SIZE_MARGIN, side="right"))
+            end = min(j + 1, len(g))
+            blocks.append(g[start:end])
+            start = end
+            base = int(cs[end - 1])
+    return blocks
+
+
+def block_arrays_pe(rec1: Records, rec2: Records, idx: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Interleaved mates (r1_0, r2_0, r1_1, r2_1, ...) of one block: bases + 2*n_pairs+1 offsets."""
+    parts = []
+    for i in idx:
+        parts.append(rec1.seq_bytes(int(i)))
+        parts.append(rec2.seq_bytes(int(i)))
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    return np.frombuffer(b"".join(parts), dtype=np.uint8), off

@@ -110,3 +110,27 @@ def synth_ragged(n_reads: int, genome_len: int, seed: int, min_len: int = 30, ma
     ids = [b"@rag.%d" % (i + 1) for i in range(n_reads)]
     quals = [bytes([33 + int(x) for x in rng.integers(2, 41, size=len(s))]) for s in seqs]
     return ids, seqs, quals
+
+
+def synth_pairs(n_pairs: int, read_len: int, genome_len: int, seed: int, frag_min: int = 300, frag_max: int = 600,
+                sub_rate: float = 0.005, n_rate: float = 0.001):
+    """Paired-end reads: fragment of random length, mate 1 from its start (forward), mate 2 the reverse
+    complement of its end; fragment strand 50/50.  Returns two (n_pairs, read_len) uint8 arrays."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    genome = _ACGT[rng.integers(0, 4, size=genome_len, dtype=np.uint8)]
+    frag = rng.integers(frag_min, frag_max + 1, size=n_pairs, dtype=np.int64)
+    pos = (rng.random(n_pairs) * (genome_len - frag)).astype(np.int64)
+    strand = rng.integers(0, 2, size=n_pairs, dtype=np.uint8)
+    ar = np.arange(read_len, dtype=np.int64)
+    left = genome[pos[:, None] + ar[None, :]]
+    right = _COMP[genome[(pos + frag - read_len)[:, None] + ar[None, :]][:, ::-1]]
+    r1 = np.where(strand[:, None] == 0, left, right)
+    r2 = np.where(strand[:, None] == 0, right, left)
+    out = []
+    for r in (r1, r2):
+        u = rng.random(size=(n_pairs, read_len))
+        alt = _ACGT[rng.integers(0, 4, size=(n_pairs, read_len), dtype=np.uint8)]
+        r = np.where(u < sub_rate, alt, r)
+        r = np.where((u >= sub_rate) & (u < sub_rate + n_rate), np.uint8(ord("N")), r)
+        out.append(np.ascontiguousarray(r))
+    return out[0], out[1]

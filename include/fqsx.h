@@ -83,7 +83,15 @@ typedef struct fqsx_meta fqsx_meta;
 int fqsx_meta_create(uint32_t T, fqsx_meta **out);
 int fqsx_meta_encode_block(fqsx_meta *, const uint32_t *read_len, uint32_t n_reads, const uint8_t **streams,
                            uint64_t *lens);
+/* paired != 0: reads alternate mate 1 / mate 2 (CompressReadLenPE, fqs/meta.cpp:100-107) */
+int fqsx_meta_encode_block_pe(fqsx_meta *, const uint32_t *read_len, uint32_t n_reads, int paired,
+                              const uint8_t **streams, uint64_t *lens);
 void fqsx_meta_destroy(fqsx_meta *);
+
+/* Host-side read order inside one bin of `fqs e -om s`: std::sort with the comparator of
+ * CSortedFASTQFile::sort_reads (fqs/io.h:499-528) applied to reads idx_in[0..n) (indices into off[]),
+ * result in idx_out.  Same libstdc++ algorithm on the same initial order = same order of equal reads. */
+int fqsx_sort_bin(const uint8_t *bases, const uint64_t *off, const uint32_t *idx_in, uint32_t n, uint32_t *idx_out);
 
 const char *fqsx_last_error(void);
 const char *fqsx_version(void);

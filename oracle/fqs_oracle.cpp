@@ -346,6 +346,59 @@ struct Siv {
 };
 
 // ---------------------------------------------------------------------------------------
+// CHT_pair_kmers (ht_kmer.h:559-663, ht_kmer.cpp:17-230): multimap key -> {(value, count)} with saturating
+// counts.  insert() is commutative (count = min(sum, max)) and find() is consumed as a multiset by
+// merge_minim_results, so one flat table (no T partitions) gives identical results.
+struct PairTable {
+  std::vector<u64> key, val;
+  u64 hmask = 0, filled = 0, value_mask = 0, max_counter = 0;
+  u32 cshift = 0;
+  void init(u32 k, u64 cap) {
+    cshift = 2 * k;
+    value_mask = (1ull << cshift) - 1ull;
+    max_counter = (~0ull) >> cshift;
+    key.assign(cap, 0); val.assign(cap, 0);
+    hmask = cap - 1; filled = 0;
+  }
+  void clear() { std::fill(key.begin(), key.end(), 0); std::fill(val.begin(), val.end(), 0); filled = 0; }
+  bool empty_at(u64 p) const { return key[p] == 0 && val[p] == 0; }
+  void grow() {
+    std::vector<u64> ok, ov;
+    ok.swap(key); ov.swap(val);
+    key.assign(ok.size() * 2, 0); val.assign(ok.size() * 2, 0);
+    hmask = key.size() - 1;
+    for (size_t i = 0; i < ok.size(); ++i)
+      if (ok[i] || ov[i]) {
+        u64 p = murmur64(ok[i]) & hmask;
+        while (!empty_at(p)) p = (p + 1) & hmask;
+        key[p] = ok[i]; val[p] = ov[i];
+      }
+  }
+  void insert(u64 k, u64 v, u64 count) {  // ht_kmer.cpp:124-187
+    if (k == value_mask || v == value_mask) return;
+    if ((filled + 1) * 2 > key.size()) grow();
+    for (u64 p = murmur64(k) & hmask;; p = (p + 1) & hmask) {
+      if (empty_at(p)) {
+        if (count > max_counter) count = max_counter;
+        key[p] = k; val[p] = v + (count << cshift);
+        ++filled;
+        return;
+      }
+      if (key[p] == k && (val[p] & value_mask) == v) {
+        u64 cur = val[p] >> cshift;
+        if (cur + count < max_counter) val[p] += count << cshift;
+        else val[p] += (max_counter - cur) << cshift;
+        return;
+      }
+    }
+  }
+  void find(u64 k, std::vector<u64> &out) const {  // ht_kmer.cpp:211-228
+    for (u64 p = murmur64(k) & hmask; !empty_at(p); p = (p + 1) & hmask)
+      if (key[p] == k) out.push_back(val[p]);
+  }
+};
+
+// ---------------------------------------------------------------------------------------
 // CRangeEncoder, sub_rc.h:32-87
 struct RangeEnc {
   u64 low, range;
@@ -621,6 +674,8 @@ struct Shared {
   KTable smer, bmer;
   // mailboxes [src][dst], application.h:56-59
   std::vector<std::vector<std::vector<u64>>> p_add, s_add, b_add;
+  PairTable pe;                                 // ht_pe_mers, application.cpp:89
+  std::vector<std::vector<u64>> pe_add;         // pe_mers_to_add, flattened per source: (key, value, weight) triples
   Counters cnt;
 };
 
@@ -638,6 +693,11 @@ struct Worker {
   CounterInc cinc_b, cinc_s, cinc_lb, cinc_ls;
   u64 s_letters[4] = {0, 0, 0, 0};
   KTable lb, ls;
+  PairTable lpe;                                // ht_pe_mers_local
+  Model m_minim_id;                             // ctx_rc_pe_minimizer_id, dna.cpp:142
+  CtxMap m_minim_pos;                           // m_ctx_rc_minimizer_pos
+  Model t_minim_pos;
+  std::vector<u64> v_minim_cand, v_minim_top;
   Kmer pmer, smer, bmer, pmer_u, smer_u, bmer_u, pmer_prev;
   u32 cor_pos = 0, N_run = 0;
   u64 hidden_updates = 0;
@@ -665,6 +725,10 @@ struct Worker {
     lb.init(sh->kl.bmer, 6, 1u << 12, &c.lprobes, &c.slots);
     ls.init(sh->kl.smer, 12, 1u << 12, &c.lprobes, &c.slots);
     pmer_mod_shift = 2 * sh->kl.pmer - 12;
+    lpe.init(sh->kl.bmer, 1u << 10);
+    m_minim_id.init(16, nullptr, 1 << 15);
+    m_minim_pos.init(&c.ctx);
+    t_minim_pos.init(256, nullptr, 1 << 15);
   }
 
   u32 p_owner(u64 x) const { return (u32)((x >> pmer_mod_shift) % sh->T); }          // dna.cpp:658
@@ -895,11 +959,11 @@ struct Worker {
     push_p(pmer.aligned_rc());
   }
 
-  void suffix(const u8 *p, u32 size, bool original_order) {  // compress_suffix, dna.cpp:674-877
+  void suffix(const u8 *p, u32 size, bool original_order, u32 start_pos = 0, bool reversed_pe = false) {  // compress_suffix, dna.cpp:674-877
     u32 counts[4] = {0, 0, 0, 0};
     u64 ctx_r_sym = 0;
     const KLen &kl = sh->kl;
-    for (u32 i = original_order ? kl.prefix : kl.pmer; i < size; ++i) {
+    for (u32 i = start_pos ? start_pos : original_order ? kl.prefix : kl.pmer; i < size; ++i) {
       u8 sym = (u8)dna_code(p[i]);
       u64 sym_k = sym == 4 ? 0 : sym;
       pmer.insert_zero(); smer.insert_zero(); bmer.insert_zero();
@@ -926,7 +990,8 @@ struct Worker {
         u32 cor_zone = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0;
         if (rough) cor_zone = 3;
         u64 lev[7];
-        ctx_codes(lev, kl, counts, s_letters, i, level, cor_zone, ctx_r_sym, size);
+        if (!reversed_pe) ctx_codes(lev, kl, counts, s_letters, i, level, cor_zone, ctx_r_sym, size);
+        else ctx_codes(lev, kl, counts, s_letters, size - i - 1, level, cor_zone, ctx_r_sym, ~0u);  // dna.cpp:750-752
         Model *m = find_leveled(m_codes, lev, 7, t_codes, avg_code, CODE_THR);
         u8 r_sym = rank(counts, sym);
         m->encode(rc, r_sym, &sh->cnt.coded);
@@ -980,19 +1045,174 @@ struct Worker {
     }
   }
 
-  void compress_read(const u8 *p, u32 size, bool original_order) {  // CompressDirect/Sorted, dna.cpp:1517-1556,1716-1754
+  void compress_read(const u8 *p, u32 size, bool original_order, bool first_of_pair = true) {  // CompressDirect/Sorted, dna.cpp:1517-1556,1716-1754
     ctx_letters = 0;
-    bool same = read_prev.size() == size && (size == 0 || !memcmp(read_prev.data(), p, size));
-    m_flags.get(ctx_flags, t_flags)->encode(rc, same, &sh->cnt.coded);
-    ctx_flags = ((ctx_flags << 1) + (u64)same) & 0xff;
-    if (same) return;
+    if (first_of_pair) {
+      bool same = read_prev.size() == size && (size == 0 || !memcmp(read_prev.data(), p, size));
+      m_flags.get(ctx_flags, t_flags)->encode(rc, same, &sh->cnt.coded);
+      ctx_flags = ((ctx_flags << 1) + (u64)same) & 0xff;
+      if (same) return;
+    }
     pmer.reset(); smer.reset(); bmer.reset();
     pmer_u.reset(); smer_u.reset(); bmer_u.reset();
     cor_pos = 0; N_run = 0;
     if (original_order) prefix_direct(p); else prefix_sorted(p);
     suffix(p, size, original_order);
-    read_prev.assign(p, p + size);
+    if (first_of_pair) read_prev.assign(p, p + size);
     update_s_letters(p, size);
+  }
+
+  // ---- paired-end (dna.cpp:880-1136,1559-1638,1757-1880)
+  bool valid_minimizer(u64 x) const { u64 f = x >> (2 * sh->kl.bmer - 6); return f != 0 && f != 1; }            // dna.cpp:879-889
+  bool valid_maximizer(u64 x) const { u64 f = x >> (2 * sh->kl.bmer - 6); return f != 0x3e && f != 0x3f; }      // dna.cpp:892-902
+  // direct-strand b-mer roller of find_minimizer/maximizer/generate_read_bmers (CKmer direct mode)
+  struct DirK {
+    u64 v = 0; u32 cur = 0, k = 0;
+    void reset() { v = 0; cur = 0; }
+    void insert(u64 s) { v = ((v << 2) | s) & ((1ull << (2 * k)) - 1ull); if (cur < k) ++cur; }
+    bool full() const { return cur == k; }
+  };
+  u64 find_minimizer(const u8 *p, int size) const {  // dna.cpp:999-1023
+    DirK b; b.k = sh->kl.bmer;
+    u64 best = sh->pe.value_mask;
+    for (int i = 0; i < size; ++i) {
+      u32 sym = dna_code(p[i]);
+      if (sym == 4) b.reset();
+      else { b.insert(sym); if (b.full() && b.v < best && valid_minimizer(b.v)) best = b.v; }
+    }
+    return best;
+  }
+  u64 find_maximizer(const u8 *p, int size) const {  // dna.cpp:1026-1050 (walks the read backwards)
+    DirK b; b.k = sh->kl.bmer;
+    u64 best = 0;
+    for (int i = size - 1; i >= 0; --i) {
+      u32 sym = dna_code(p[i]);
+      if (sym == 4) b.reset();
+      else { b.insert(sym); if (b.full() && b.v > best && valid_maximizer(b.v)) best = b.v; }
+    }
+    return best;
+  }
+  void merge_minim_results() {  // dna.cpp:905-971
+    std::vector<u64> &c = v_minim_cand, &top = v_minim_top;
+    if (c.size() == 1) { std::swap(c, top); return; }
+    const u64 cs = 2 * (u64)sh->kl.bmer, vm = (1ull << cs) - 1ull, maxc = (~0ull) >> cs;
+    auto by_count = [&](u64 x, u64 y) { u64 xc = x >> cs, yc = y >> cs; if (xc != yc) return xc > yc; return (x & vm) < (y & vm); };
+    if (c.size() > 48) { std::partial_sort(c.begin(), c.begin() + 48, c.end(), by_count); c.resize(48); }
+    std::sort(c.begin(), c.end(), [vm](u64 x, u64 y) { return (x & vm) < (y & vm); });
+    top.clear();
+    top.push_back(c.front());
+    for (size_t i = 1; i < c.size(); ++i)
+      if ((top.back() & vm) != (c[i] & vm)) top.push_back(c[i]);
+      else {
+        u64 cx = top.back() >> cs, cy = c[i] >> cs;
+        if (cx + cy > maxc) cy = maxc - cx;
+        top.back() += cy << cs;
+      }
+    if (top.size() <= 16) std::sort(top.begin(), top.end(), by_count);
+    else std::partial_sort(top.begin(), top.begin() + 16, top.end(), by_count);
+  }
+  bool find_minim_cand(const u8 *p, u32 size) {  // dna.cpp:1757-1787
+    v_minim_cand.clear();
+    int k = (int)sh->kl.bmer, mss = (int)size - k + 1;
+    int sp1 = mss / 4, sp2 = 2 * mss / 4, sp3 = 3 * mss / 4;
+    u64 m[4] = {find_minimizer(p, sp1 + k - 1), find_minimizer(p + sp1, sp2 - sp1 + k - 1),
+                find_minimizer(p + sp2, sp3 - sp2 + k - 1), find_minimizer(p + sp3, (int)size - sp3)};
+    for (int i = 0; i < 4; ++i) sh->pe.find(m[i], v_minim_cand);
+    for (int i = 0; i < 4; ++i) lpe.find(m[i], v_minim_cand);
+    if (v_minim_cand.empty()) return false;
+    merge_minim_results();
+    return true;
+  }
+  void seed_kmers(const u8 *p, int from, int to) {  // dna.cpp:1577-1592,1616-1631
+    pmer.reset(); smer.reset(); bmer.reset(); pmer_u.reset(); smer_u.reset(); bmer_u.reset();
+    cor_pos = 0; N_run = 0;
+    ctx_letters = ~0ull;
+    for (int i = from; i < to; ++i) {
+      u32 c = dna_code(p[i]);
+      ctx_letters = (ctx_letters << 4) + c;
+      if (c == 4) c = 0;
+      pmer.insert(c); bmer.insert(c); smer.insert(c);
+      pmer_u.insert(c); bmer_u.insert(c); smer_u.insert(c);
+    }
+  }
+  void compress_with_minim(const u8 *p, u32 size, u32 mpos) {  // CompressDirectWithMinim, dna.cpp:1559-1638
+    const u32 k = sh->kl.bmer;
+    seed_kmers(p, (int)mpos, (int)(mpos + k));
+    suffix(p, size, true, k + mpos);
+    std::vector<u8> rcp;
+    for (int i = (int)mpos + (int)k - 1; i >= 0; --i) {
+      u8 c = p[i];
+      rcp.push_back(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N');  // utils.h:103-114
+    }
+    seed_kmers(rcp.data(), 0, (int)k);
+    suffix(rcp.data(), (u32)rcp.size(), true, k, true);
+    update_s_letters(p, size);
+  }
+  void pe_push(u64 key, u64 value, u64 weight) {  // my_pe_mers_to_add + ht_pe_mers_local->insert, dna.cpp:1090-1135
+    std::vector<u64> &v = sh->pe_add[tid];
+    v.push_back(key); v.push_back(value); v.push_back(weight);
+    lpe.insert(key, value, weight);
+  }
+  void append_pe_mers3(const u8 *p1, u32 size1, const u8 *p2, u32 size2) {  // dna.cpp:1053-1136
+    const int k = (int)sh->kl.bmer;
+    int mss = (int)size1 - k + 1, a = mss / 3, b = 2 * mss / 3;
+    u64 m11 = find_minimizer(p1, a + k - 1), m12 = find_minimizer(p1 + a, b - a + k - 1), m13 = find_minimizer(p1 + b, (int)size1 - b);
+    mss = (int)size2 - k + 1; a = mss / 3; b = 2 * mss / 3;
+    u64 m21 = find_minimizer(p2, a + k - 1), m22 = find_minimizer(p2 + a, b - a + k - 1), m23 = find_minimizer(p2 + b, (int)size2 - b);
+    int mid1 = ((int)size1 + k) / 2, mid2 = ((int)size2 + k) / 2;
+    u64 x1 = find_maximizer(p1 + mid1 - k + 1, (int)size1 - (mid1 - k + 1));
+    u64 x2 = find_minimizer(p2 + mid2 - k + 1, (int)size2 - (mid2 - k + 1));  // sic: minimizer (quirk 6)
+    x1 = (~x1) & sh->pe.value_mask;
+    x2 = (~x2) & sh->pe.value_mask;
+    pe_push(m11, m21, 2); pe_push(m11, m23, 4); pe_push(m11, x1, 1);
+    pe_push(m12, m21, 3); pe_push(m12, m23, 3);
+    pe_push(m13, m21, 4); pe_push(m13, m23, 2);
+    pe_push(m21, m11, 2); pe_push(m21, m13, 4); pe_push(m21, x2, 1);
+    pe_push(m22, m11, 3); pe_push(m22, m13, 4);
+    pe_push(m23, m11, 4); pe_push(m23, m13, 2);
+  }
+  void compress_pair(const u8 *p1, u32 size1, const u8 *p2, u32 size2, bool original_order) {  // CompressPE, dna.cpp:1790-1880
+    u64 *nc = &sh->cnt.coded;
+    compress_read(p1, size1, original_order, true);
+    bool found = find_minim_cand(p1, size1);
+    u32 mpos = 0;
+    int mid = -1;
+    if (found) {
+      const u32 k = sh->kl.bmer;
+      std::vector<std::pair<u64, u32>> rb;  // generate_read_bmers, dna.cpp:974-996
+      DirK b; b.k = k;
+      for (u32 i = 0; i < size2; ++i) {
+        u32 sym = dna_code(p2[i]);
+        if (sym == 4) b.reset();
+        else { b.insert(sym); if (b.full() && valid_minimizer(b.v)) rb.emplace_back(b.v, i - (k - 1)); }
+      }
+      for (size_t i = 0; i < v_minim_top.size() && mid < 0; ++i) {
+        u64 m = v_minim_top[i] & sh->pe.value_mask;
+        for (auto &x : rb)
+          if (x.first == m) { mid = (int)i; mpos = x.second; break; }
+      }
+      if (mid < 0 || mid > 14) mid = 15;
+    }
+    if (mid < 0) compress_read(p2, size2, true, false);
+    else {
+      m_minim_id.encode(rc, (u32)mid, nc);
+      if (mid == 15) compress_read(p2, size2, true, false);
+      else {
+        if (mpos < 254) m_minim_pos.get((u64)mid, t_minim_pos)->encode(rc, mpos, nc);
+        else if (mpos < 65536) {
+          m_minim_pos.get((u64)mid, t_minim_pos)->encode(rc, 254, nc);
+          m_minim_pos.get((u64)mid + 0x100, t_minim_pos)->encode(rc, mpos >> 8, nc);
+          m_minim_pos.get((u64)mid + 0x200, t_minim_pos)->encode(rc, mpos & 0xff, nc);
+        } else {
+          m_minim_pos.get((u64)mid, t_minim_pos)->encode(rc, 255, nc);
+          m_minim_pos.get((u64)mid + 0x300, t_minim_pos)->encode(rc, mpos >> 16, nc);
+          m_minim_pos.get((u64)mid + 0x400, t_minim_pos)->encode(rc, (mpos >> 8) & 0xff, nc);
+          m_minim_pos.get((u64)mid + 0x500, t_minim_pos)->encode(rc, mpos & 0xff, nc);
+        }
+        compress_with_minim(p2, size2, mpos);
+      }
+    }
+    append_pe_mers3(p1, size1, p2, size2);
   }
 
   void insert_phase() {  // InsertKmersToHT, dna.cpp:2393-2472 (column tid of every mailbox, source order)
@@ -1006,10 +1226,17 @@ struct Worker {
       for (u64 x : sh->s_add[i][tid]) { sh->smer.insert(x, cinc_s); ++sh->cnt.inserts; }
     for (u32 i = 0; i < sh->T; ++i)
       for (u64 x : sh->b_add[i][tid]) { sh->bmer.insert(x, cinc_b); ++sh->cnt.inserts; }
+    if (tid == 0)  // pair inserts are commutative (saturating sums): owner sharding does not matter
+      for (u32 i = 0; i < sh->T; ++i) {
+        std::vector<u64> &v = sh->pe_add[i];
+        for (size_t j = 0; j + 3 <= v.size(); j += 3) sh->pe.insert(v[j], v[j + 1], v[j + 2]);
+      }
   }
   void clear_phase() {  // ClearKmersToHT, dna.cpp:2475-2488
     for (u32 i = 0; i < sh->T; ++i) { sh->p_add[tid][i].clear(); sh->s_add[tid][i].clear(); sh->b_add[tid][i].clear(); }
     lb.clear(); ls.clear();
+    sh->pe_add[tid].clear();
+    lpe.clear();
   }
 };
 
@@ -1026,7 +1253,7 @@ extern "C" {
 fqo_codec *fqo_create(const uint8_t *h) {
   if (!h || h[0] != 'K' || h[1] != 'C' || h[2] != 'S' || h[3] != 'D') return nullptr;  // params.h:102-129
   u32 T = h[4], mode = h[5];
-  if (T == 0 || mode > 1) return nullptr;
+  if (T == 0 || mode > 3) return nullptr;
   fqo_codec *c = new fqo_codec;
   Shared &s = c->sh;
   s.T = T; s.dna_mode = mode;
@@ -1036,6 +1263,8 @@ fqo_codec *fqo_create(const uint8_t *h) {
   s.bmer.init(s.kl.bmer, 6, 1u << 16, &s.cnt.probes, &s.cnt.slots);
   s.p_add.assign(T, std::vector<std::vector<u64>>(T));
   s.s_add = s.p_add; s.b_add = s.p_add;
+  s.pe.init(s.kl.bmer, 1u << 16);
+  s.pe_add.assign(T, std::vector<u64>());
   for (u32 i = 0; i < T; ++i) { c->w.push_back(new Worker); c->w.back()->init(&s, i); }
   return c;
 }
@@ -1058,7 +1287,7 @@ int fqo_encode_block(fqo_codec *c, const uint8_t *bases, const uint64_t *off, ui
   u64 cap = (u64)n_reads / T / 2;
   if (S > cap) S = cap;
   if (S) --S;
-  const bool orig = s.dna_mode == 0;
+  const bool orig = s.dna_mode == 0 || s.dna_mode == 2, paired = s.dna_mode >= 2;
   for (u64 t = 0; t < T; ++t) {  // application.cpp:624-628
     Worker &w = *c->w[t];
     w.read_prev.clear();
@@ -1070,10 +1299,21 @@ int fqo_encode_block(fqo_codec *c, const uint8_t *bases, const uint64_t *off, ui
     for (u64 t = 0; t < T; ++t) {  // application.cpp:630-656
       Worker &w = *c->w[t];
       u64 stop;  // one past the last read of this segment
-      if (seg < S) stop = (seg + 1) * (last[t] - first[t]) / (S + 1) + first[t] + 1;
-      else stop = last[t];
+      if (seg < S) {
+        u64 ns = (seg + 1) * (last[t] - first[t]) / (S + 1) + first[t];
+        if (!paired) stop = ns + 1;                     // SE: sync after read i == next_synchro (application.cpp:643)
+        else {                                          // PE: after the first pair with i >= next_synchro (application.cpp:1170)
+          u64 i = cursor[t];
+          while (i < ns) i += 2;
+          stop = i + 2;
+        }
+      } else stop = last[t];
       if (stop > last[t]) stop = last[t];
-      for (u64 i = cursor[t]; i < stop; ++i) w.compress_read(bases + off[i], (u32)(off[i + 1] - off[i]), orig);
+      if (!paired)
+        for (u64 i = cursor[t]; i < stop; ++i) w.compress_read(bases + off[i], (u32)(off[i + 1] - off[i]), orig);
+      else
+        for (u64 i = cursor[t]; i + 1 < stop; i += 2)
+          w.compress_pair(bases + off[i], (u32)(off[i + 1] - off[i]), bases + off[i + 1], (u32)(off[i + 2] - off[i + 1]), orig);
       if (stop > cursor[t]) cursor[t] = stop;
     }
     for (u64 t = 0; t < T; ++t) c->w[t]->insert_phase();

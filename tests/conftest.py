@@ -97,3 +97,28 @@ def check_against_digest(make_codec, json_name, max_blocks=None):
     if max_blocks is None:
         assert total == d["dna_bytes"]
     return codec
+
+
+def c5_records():
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.synth import read_id, synth_pairs, synth_quals
+    r1, r2 = synth_pairs(4000, 100, 60000, 5)
+    return (hp.Records([read_id(i, 1) for i in range(4000)], r1, synth_quals(4000, 100, 5)),
+            hp.Records([read_id(i, 2) for i in range(4000)], r2, synth_quals(4000, 100, 6)))
+
+
+def check_against_fqs_pe(make_codec, recs, fqs_name):
+    from fqsqueezer_amd import hostpipe as hp
+    rec1, rec2 = recs
+    header, blocks = hp.parse_fqs(open(os.path.join(GOLD, fqs_name), "rb").read())
+    mode = {2: "pe_original", 3: "pe_sorted"}[header[5]]
+    blks = hp.form_blocks_pe(rec1, rec2, mode)
+    assert len(blks) == len(blocks)
+    codec = make_codec(header)
+    for g, (idx, ref) in enumerate(zip(blks, blocks)):
+        assert 2 * len(idx) == ref.n_reads
+        bases, off = hp.block_arrays_pe(rec1, rec2, idx)
+        streams = codec.encode_block(bases, off, g)
+        for w, s in enumerate(streams):
+            assert s == ref.streams[w][hp.STREAM_DNA], f"{fqs_name}: block {g} worker {w} differs from the reference"
+    return codec

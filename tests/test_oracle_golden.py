@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import c1_records, c4_records, check_against_digest, check_against_fqs
+from conftest import c1_records, c4_records, c5_records, check_against_digest, check_against_fqs, check_against_fqs_pe
 from oracle.pyoracle import OracleCodec, lib
 
 
@@ -16,6 +16,11 @@ def test_oracle_matches_reference_10k(name):
 @pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
 def test_oracle_matches_reference_ragged(name):
     check_against_fqs(OracleCodec, c4_records(), name)
+
+
+@pytest.mark.parametrize("name", ["c5_pe4k_o_t1.fqs", "c5_pe4k_o_t4.fqs", "c5_pe4k_s_t1.fqs", "c5_pe4k_s_t4.fqs"])
+def test_oracle_matches_reference_paired_end(name):
+    check_against_fqs_pe(OracleCodec, c5_records(), name)
 
 
 def test_oracle_matches_reference_150bp():

@@ -7,6 +7,7 @@ Fixtures (data only -- inputs are re-generated deterministically by fqsqueezer_a
   c2_1M_s_t{1,8,64}.json    per-block SHA-256 + sizes of the reference DNA streams,
                             1M x 100bp, G=5Mbp, seed 2, -om s -gs 5   (BASELINE configs[1])
   c4_ragged_{o,s}_t3.fqs   3000 ragged reads (30-160 bp, N runs, duplicates), G=60kbp, seed 4, -gs 1
+  c5_pe4k_{o,s}_t{1,4}.fqs  4000 pairs x 100bp (fragments 300-600), G=60kbp, seed 5, `-p`, -gs 1 (paired-end path)
   c3_50k150_s_t8.json       50k x 150bp, G=250kbp, seed 3, -om s -gs 8 (150 bp metric shape)
 Usage: python tools/make_golden.py [--work /tmp/w] [--only c1|c2|c3]
 """
@@ -72,6 +73,18 @@ def main():
                 f.write(i + b"\n" + sq + b"\n+\n" + q + b"\n")
         for om in "os":
             run_ref(fq, os.path.join(GOLD, f"c4_ragged_{om}_t3.fqs"), om, 3, 1, a.work)
+    if a.only in ("", "c5"):
+        from fqsqueezer_amd.synth import synth_pairs
+        r1, r2 = synth_pairs(4000, 100, 60000, 5)
+        f1, f2 = os.path.join(a.work, "c5_1.fq"), os.path.join(a.work, "c5_2.fq")
+        write_fastq(f1, r1, seed=5, mate=1)
+        write_fastq(f2, r2, seed=6, mate=2)
+        for om in "os":
+            for t in (1, 4):
+                out = os.path.join(GOLD, f"c5_pe4k_{om}_t{t}.fqs")
+                if not os.path.exists(out):
+                    subprocess.check_call([REF, "e", "-p", "-om", om, "-t", str(t), "-gs", "1", "-qm", "n", "-im", "n", "-v", "0",
+                                           "-tmp", os.path.join(a.work, "tmpp_"), "-out", out, f1, f2], stdout=subprocess.DEVNULL)
     if a.only in ("", "c3"):
         fq = os.path.join(a.work, "c3.fq")
         if not os.path.exists(fq):
