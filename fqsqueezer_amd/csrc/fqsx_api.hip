@@ -82,6 +82,34 @@ FQ_KERNEL64 void k_part_scatter(DevCfg cfg, u32 kind) {
   FQ_SHARED u32 ld[64];
   part_scatter_body(cfg, kind, FQ_BLOCK, cursor, ld);
 }
+// paired-end insert phase: per-owner demand, then the inserts
+FQ_KERNEL64 void k_pe_demand(DevCfg cfg, u32 *demand) {
+  FQ_SHARED WgShared sm;
+  pe_insert_body(cfg, &sm, FQ_BLOCK, true, demand);
+}
+FQ_KERNEL64 void k_pe_insert(DevCfg cfg) {
+  FQ_SHARED WgShared sm;
+  pe_insert_body(cfg, &sm, FQ_BLOCK, false, nullptr);
+}
+FQ_KERNEL void k_rehash_ptab(PTab o, PTab n, u32 n_sub) {
+  const u64 ocap = o.cap_mask + 1, total = ocap * n_sub;
+#ifndef FQSX_EMU
+  const u64 gstride = (u64)gridDim.x * blockDim.x;
+  for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gstride) {
+#else
+  for (u64 g = 0; g < total; ++g) {
+#endif
+    const u32 sub = (u32)(g / ocap);
+    const u64 k = o.key[(u64)sub * o.stride + (g % ocap)], v = o.val[(u64)sub * o.stride + (g % ocap)];
+    if (k == 0 && v == 0) continue;
+    u64 *nk = n.key + (u64)sub * n.stride, *nv = n.val + (u64)sub * n.stride;
+    u64 p = murmur64(k) & n.cap_mask;
+    for (;;) {  // valid keys are non-zero (a minimizer never starts with AAA), so the key word claims the slot
+      if (nk[p] == 0 && atomic_cas64(&nk[p], 0, k) == 0) { nv[p] = v; break; }
+      p = (p + 1) & n.cap_mask;
+    }
+  }
+}
 // re-insert every occupied slot of `o` into the (empty, larger) table `n`; layout-free, so parallel
 FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub) {
   const u64 ocap = o.cap_mask + 1;
@@ -155,7 +183,9 @@ struct fqsx_dna {
   double k_ms[3];
   u64 k_n[3];
   // capacities (host mirror)
-  u64 gs_cap, gb_cap, ls_cap, lb_cap, ctx_cap, out_cap;
+  u64 gs_cap, gb_cap, ls_cap, lb_cap, ctx_cap, out_cap, gpe_cap, lpe_cap;
+  u32 pe_cap;
+  bool paired;
   u32 mail_cap[3];
   u64 dev_bases_cap, dev_off_cap;
   u8 *d_bases;
@@ -321,6 +351,36 @@ int grow_global(fqsx_dna *c, KTab &t, u64 &cap_field, u64 new_cap) {
   return FQSX_OK;
 }
 
+int ptab_alloc(fqsx_dna *c, PTab &t, u32 n_sub, u64 cap, bool with_filled) {
+  void *p = nullptr;
+  int rc;
+  if ((rc = dalloc(c, &p, cap * n_sub * sizeof(u64), true))) return rc;
+  t.key = (u64 *)p;
+  if ((rc = dalloc(c, &p, cap * n_sub * sizeof(u64), true))) return rc;
+  t.val = (u64 *)p;
+  t.cap_mask = cap - 1;
+  t.stride = cap;
+  if (with_filled) {
+    if ((rc = dalloc(c, &p, (u64)n_sub * sizeof(u32), true))) return rc;
+    t.filled = (u32 *)p;
+  }
+  return FQSX_OK;
+}
+int grow_gpe(fqsx_dna *c, u64 new_cap) {
+  PTab n = c->cfg.g_pe;
+  int rc = ptab_alloc(c, n, c->T, new_cap, false);
+  if (rc) return rc;
+  LAUNCH(c, 2, k_rehash_ptab, REHASH_GRID, 256, c->cfg.g_pe, n, c->T);
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  dfree(c, c->cfg.g_pe.key);
+  dfree(c, c->cfg.g_pe.val);
+  c->cfg.g_pe = n;
+  c->gpe_cap = new_cap;
+  return FQSX_OK;
+}
+
 int grow_ctx(fqsx_dna *c, u64 new_cap) {
   void *p = nullptr;
   int rc = dalloc(c, &p, new_cap * c->T * sizeof(CtxSlot), true);
@@ -375,7 +435,12 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
     max_wreads = std::max(max_wreads, last - first);
     u64 cur = first;
     for (u64 seg = 0; seg <= S; ++seg) {
-      u64 stop = seg < S ? (seg + 1) * (last - first) / (S + 1) + first + 1 : last;
+      u64 stop = last;
+      if (seg < S) {
+        const u64 ns = (seg + 1) * (last - first) / (S + 1) + first;
+        if (!c->paired) stop = ns + 1;
+        else { u64 i = cur; if (i < ns) i += (ns - i + 1) & ~1ull; stop = i + 2; }
+      }
       if (stop > last) stop = last;
       if (stop > cur) {
         max_seg_bases = std::max(max_seg_bases, h_off[stop] - h_off[cur]);
@@ -386,6 +451,7 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
   }
   int rc;
   void *p = nullptr;
+  if (c->paired && (n_reads & 1)) { g_err = "paired-end blocks need an even number of reads"; return FQSX_E_ARG; }
   // ---- per-block buffers
   u64 need_out = max_wbases + 16 * max_wreads + 1024;
   if (need_out > c->out_cap) {
@@ -410,6 +476,27 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
     dfree(c, cfg.l_s.slots);
     if ((rc = ktab_alloc(c, cfg.l_s, T, need_ls, cfg.smer, 12, false))) return rc;
     c->ls_cap = need_ls;
+  }
+  u64 need_lpe = 0;
+  if (c->paired) {
+    const u64 seg_pairs = max_seg_reads / 2 + 1;
+    const u64 need_list = 14 * seg_pairs + 16;
+    if (need_list > c->pe_cap) {
+      if (cfg.pe_list) dfree(c, cfg.pe_list);
+      c->pe_cap = (u32)(need_list + need_list / 4);
+      if ((rc = dalloc(c, &p, (u64)T * c->pe_cap * 3 * sizeof(u64), false))) return rc;
+      cfg.pe_list = (u64 *)p;
+      cfg.pe_cap = c->pe_cap;
+    }
+    need_lpe = pow2_at_least(2 * 14 * seg_pairs + 64);
+    if (need_lpe > c->lpe_cap) {
+      dfree(c, cfg.l_pe.key);
+      dfree(c, cfg.l_pe.val);
+      if ((rc = ptab_alloc(c, cfg.l_pe, T, need_lpe, false))) return rc;
+      c->lpe_cap = need_lpe;
+    }
+    cfg.l_pe.cap_mask = need_lpe - 1;
+    cfg.l_pe.stride = need_lpe;
   }
   // active geometry of the local tables for this block (cleared after every phase)
   cfg.l_b.cap_mask = need_lb - 1; cfg.l_b.stride = need_lb;
@@ -442,6 +529,18 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
       u64 need = 0;
       for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_filled[o] + c->h_demand[which * T + o]);
       if (need * 2 > cap && (rc = grow_global(c, t, cap, pow2_at_least(need * 2 + 2)))) return rc;
+    }
+    if (c->paired) {  // pair table: size for the exact per-owner demand, then insert
+      LAUNCH(c, 2, k_pe_demand, T, 64, cfg, c->d_demand);
+      if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, T * sizeof(u32)))) return rc;
+      if ((rc = d2h_sync(c, c->h_filled.data(), cfg.g_pe.filled, T * sizeof(u32)))) return rc;
+      u64 need = 0;
+      for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_filled[o] + c->h_demand[o]);
+      if (need * 2 > c->gpe_cap && (rc = grow_gpe(c, pow2_at_least(need * 2 + 2)))) return rc;
+      LAUNCH(c, 2, k_pe_insert, T, 64, cfg);
+      if ((rc = dzero(c, cfg.l_pe.key, need_lpe * T * sizeof(u64)))) return rc;
+      if ((rc = dzero(c, cfg.l_pe.val, need_lpe * T * sizeof(u64)))) return rc;
+      if ((rc = dzero(c, cfg.l_pe.filled, T * sizeof(u32)))) return rc;
     }
     for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_scatter, T * cfg.mail[k].n_tiles, 64, cfg, k);
     LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg);
@@ -532,6 +631,8 @@ int create_impl(fqsx_dna *c, const u8 *h) {
     fill(SM_OFF_PSF, 65536, SM_PSF_N + 1, SM_PSF_N);
     fill(SM_OFF_PSNB, 65536, 6, cfg.ps_nobytes_n);
     fill(SM_OFF_NIB, 68, SM_NIB_N + 1, SM_NIB_N);
+    tpl.resize(SM_TOTAL_U16, 0);   // 256-symbol models stay zero (lazily initialised); ctx_rc_pe_minimizer_id at the end
+    fill(SM_OFF_MID, 1, SM_NIB_N + 1, SM_NIB_N);
     if ((rc = dalloc(c, &p, (u64)T * SM_TOTAL_U16 * sizeof(u16), false))) return rc;
     cfg.small = (u16 *)p;
     if ((rc = h2d(c, cfg.small, tpl.data(), tpl.size() * sizeof(u16)))) return rc;
@@ -540,7 +641,7 @@ int create_impl(fqsx_dna *c, const u8 *h) {
 #endif
     for (u32 t = 1; t < T; ++t)
       if ((rc = d2d(c, cfg.small + (u64)t * SM_TOTAL_U16, cfg.small, tpl.size() * sizeof(u16)))) return rc;
-    if ((rc = dalloc(c, &p, (u64)T * SM_BYTE_ENTRIES, true))) return rc;
+    if ((rc = dalloc(c, &p, (u64)T * SM_LAZY_ENTRIES, true))) return rc;
     cfg.byte_init = (u8 *)p;
   }
   // worker state: four std::mt19937 seeded 5481 (utils.h:296), everything else zero (dna.cpp:148-171)
@@ -568,6 +669,17 @@ int create_impl(fqsx_dna *c, const u8 *h) {
     cfg.mail[k].dst_off = (u32 *)p;
     if ((rc = mail_alloc(c, k, FQSX_TILE))) return rc;
   }
+  c->paired = cfg.mode >= 2;
+  c->gpe_cap = c->lpe_cap = 0;
+  c->pe_cap = 0;
+  if (c->paired) {  // ht_pe_mers (application.cpp:89) and ht_pe_mers_local (dna.cpp:105-107)
+    c->gpe_cap = pow2_at_least(std::max<u64>(1024, (1ull << 20) / T));
+    if ((rc = ptab_alloc(c, cfg.g_pe, T, c->gpe_cap, true))) return rc;
+    c->lpe_cap = 1024;
+    if ((rc = ptab_alloc(c, cfg.l_pe, T, c->lpe_cap, true))) return rc;
+    if ((rc = dalloc(c, &p, (u64)T * sizeof(u32), true))) return rc;
+    cfg.pe_n = (u32 *)p;
+  }
   if ((rc = dalloc(c, &p, sizeof(u32) * 4, true))) return rc;
   cfg.err = (u32 *)p;
   if ((rc = dalloc(c, &p, (2 * (u64)T + 1) * sizeof(u32), true))) return rc;
@@ -594,7 +706,7 @@ int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) {
     return FQSX_E_ARG;
   }
   if (h[4] == 0) { g_err = "no_threads must be >= 1"; return FQSX_E_ARG; }
-  if (h[5] > 1) { g_err = "dna_mode not implemented (paired-end)"; return FQSX_E_ARG; }
+  if (h[5] > 3) { g_err = "unknown dna_mode"; return FQSX_E_ARG; }
   if (h[11] < 12 || h[11] > 18 || h[12] <= h[11] || h[13] <= h[12] + 1 || h[13] > 27 || h[10] >= h[11]) {
     g_err = "unsupported k-mer lengths";
     return FQSX_E_ARG;

@@ -31,6 +31,10 @@ struct WgShared {
   u64 pv_b[FQSX_SPEC], pv_s[FQSX_SPEC], pv_pd[FQSX_SPEC], pv_pr[FQSX_SPEC];
   u8 pv_flag[FQSX_SPEC];       // PV_* bits
   u64 lev_tmp[10];             // level keys of a position coded outside the fast path
+  u8 r2c[FQSX_RD_LDS];         // paired-end: codes of the second mate
+  u64 pe_cand[512];            // paired-end: candidate partner b-mers (value | count << 2k)
+  u64 pe_top[64];
+  u64 pe_bk[3][64];            // paired-end insert batch (key, value, weight)
   u64 pq_key[2][64];           // LDS mirror of the list entries not yet applied to the local tables (b, s)
   // stage P, positions whose global b-mer probe missed: the rest of find_counts' cascade and the
   // Hamming-1 fall-back, resolved lane-parallel (valid while no pending local insert interferes)
@@ -61,6 +65,7 @@ struct Wk {
   u64 hidden;
   bool repm_gate;                       // siv avg_filling_factor() >= 7 (constant within a segment)
   u32 mn[3];                            // entries appended to this worker's p/s/b mailbox lists
+  u32 pe_n;                             // paired-end triples pushed in this launch
   u32 la[3];                            // list entries already applied to the local tables (b, s)
   u32 pq_n[2];                          // valid entries of the LDS mirror (b, s); ~0u = mirror overflowed
   bool lq_applied;                      // a local-table flush happened since the last stage P (its local probes are stale)
@@ -1285,7 +1290,7 @@ FQ_DEV void prefix_sorted(Wk &w, const u8 *p, u32 size) {  // compress_prefix_so
     } else {
       u32 hi_byte = (u32)(dif >> (nb * 8 - 8));
       u32 e = (u32)flag * 4u + (nb - 2);
-      u8 *bi = cfg->byte_init + (u64)w.tid * SM_BYTE_ENTRIES;
+      u8 *bi = cfg->byte_init + (u64)w.tid * SM_LAZY_ENTRIES;
       sm_encode256(w, sb + SM_OFF_BYTE + (u64)e * (SM_BYTE_N + 1), bi + e, hi_byte);
       for (u32 i = 0; i + 1 < nb; ++i) {
         u32 e2 = 16u + ((e * 256u + hi_byte) * 4u + i);
@@ -1339,7 +1344,7 @@ FQ_DEV u32 repair_decide(const Wk &w, const C4 &c, u32 sym) {
 // forward to position i0+j, probes the global b-mer table and -- on a plain hit -- derives everything
 // that depends only on (counts, position, symbol): the 7 context keys, the symbol's rank, the
 // repair decision; it also prepares the position's mailbox entries.
-FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n) {
+FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed) {
   const DevCfg *cfg = w.cfg;
   WgShared *sm = w.sm;
   u64 ns = 0, nls = 0;
@@ -1391,7 +1396,8 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n) {
           int cor_dist = (int)cfg->bmer, d = (int)i - (int)w.cor_pos;
           u32 cz = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
           u64 lev[7];
-          ctx_codes(lev, cfg, c, w.s_let, i, LV_BMER, cz, 0, size);
+          if (!reversed) ctx_codes(lev, cfg, c, w.s_let, i, LV_BMER, cz, 0, size);
+          else ctx_codes(lev, cfg, c, w.s_let, size - i - 1, LV_BMER, cz, 0, ~0u);  // dna.cpp:750-752
           for (u32 l = 0; l < 7; ++l) sm->sp_key[j][l] = lev[l];
           sm->sp_cnt[j] = c.c[0] | (c.c[1] << 8) | (c.c[2] << 16) | (c.c[3] << 24);
           sm->sp_rsym[j] = (u8)rank_sym(w, c, sym);
@@ -1509,24 +1515,26 @@ FQ_DEV void replace_last_all(Wk &w, u64 symk) {
   km_replace_last(w.pm_u, symk); km_replace_last(w.sm_u, symk); km_replace_last(w.bm_u, symk);
 }
 // ctx_letters before position i: reset (all ones) followed by the symbols 0..i-1 (dna.cpp:108-110,803)
-FQ_DEV u64 letters_before(Wk &w, const u8 *p, u32 i, u32 size) {
+FQ_DEV u64 letters_before(Wk &w, const u8 *p, u32 i, u32 size, u32 hist_start) {
   u64 ctx = ~0ull;
-  for (u32 t = i > 16 ? i - 16 : 0; t < i; ++t) ctx = (ctx << 4) + rd_sym(w, p, t, size);
+  u32 t0 = i > 16 ? i - 16 : 0;
+  if (t0 < hist_start) t0 = hist_start;   // symbols before hist_start were never fed (minimizer-anchored coding)
+  for (u32 t = t0; t < i; ++t) ctx = (ctx << 4) + rd_sym(w, p, t, size);
   return ctx;
 }
 
 // compress_suffix, dna.cpp:674-877, as chunks of stage P (parallel) -> stage C (the serial loop below:
 // context look-up + range coding, plus the complete reference logic for positions P could not
 // settle) -> stage Q (parallel mailbox appends)
-FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {
+FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_pos = 0, bool reversed = false, u32 hist_start = 0) {
   const DevCfg *cfg = w.cfg;
   WgShared *sm = w.sm;
   u64 ctx_r_sym = 0;
-  u32 i = original_order ? cfg->prefix : cfg->pmer;
+  u32 i = start_pos ? start_pos : original_order ? cfg->prefix : cfg->pmer;
   while (i < size && !w.err) {
     const u32 n = size - i < FQSX_SPEC ? size - i : FQSX_SPEC;
     TM_BEGIN(t_sp);
-    speculate(w, p, size, i, n);
+    speculate(w, p, size, i, n, reversed);
     TM_END(w, TM_SPEC, t_sp);
     TM_COUNT(w, CN_CHUNK);
     u32 q_done = 0;   // chunk positions whose mailbox entries are already in the lists
@@ -1642,7 +1650,8 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {
           u32 cor_zone = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
           if (rough) cor_zone = 3;
           u64 lev[7];
-          ctx_codes_wave(lev, cfg, counts, w.s_let, pos, level, cor_zone, ctx_r_sym, size);
+          if (!reversed) ctx_codes_wave(lev, cfg, counts, w.s_let, pos, level, cor_zone, ctx_r_sym, size);
+          else ctx_codes_wave(lev, cfg, counts, w.s_let, size - pos - 1, level, cor_zone, ctx_r_sym, ~0u);
           FQ_SYNC();
           for (u32 l = 0; l < 7; ++l) sm->lev_tmp[l] = lev[l];
           FQ_SYNC();
@@ -1652,7 +1661,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {
           if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
           ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;  // update_ctx_r_sym, dna.cpp:664-671
         } else {
-          w.ctx_letters = letters_before(w, p, pos, size);
+          w.ctx_letters = letters_before(w, p, pos, size, hist_start);
           code_letter(w, pos, sym, size);
           ctx_r_sym = (ctx_r_sym << 1) & 0xff;
         }
@@ -1738,10 +1747,11 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order) {
 
 // CompressDirect / CompressSorted, dna.cpp:1517-1556,1716-1754.  `prev` is the previous read of
 // this worker inside the block (read_prev is cleared per block, application.cpp:624), or null.
-FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev_size) {
+// first_of_pair = false: the second mate coded by CompressDirect(..., false): direct prefix, no duplicate flag
+FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev_size, bool first_of_pair = true) {
   const DevCfg *cfg = w.cfg;
   WgShared *sm = w.sm;
-  const bool orig = cfg->mode == 0;
+  const bool orig = !first_of_pair || cfg->mode == 0 || cfg->mode == 2;
   // duplicate test + staging of the read's codes in LDS + letter histogram, all lane-parallel
   TM_BEGIN(t_head);
   bool diff = prev == nullptr || prev_size != size;
@@ -1757,12 +1767,12 @@ FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev
   FQ_SYNC();
   bool same = !wave_any(diff);
   if (prev == nullptr || prev_size != size) same = false;
-  {
+  if (first_of_pair) {
     u16 *m = small_base(w) + SM_OFF_FLAGS + w.ws->ctx_flags * (SM_FLAGS_N + 1);
     sm_encode(w, m, SM_FLAGS_N, 1u << 12, same ? 1u : 0u);
     w.ws->ctx_flags = ((w.ws->ctx_flags << 1) + (same ? 1u : 0u)) & 0xff;
+    if (same) return;
   }
-  if (same) return;
   km_reset(w.pm); km_reset(w.sm_); km_reset(w.bm);
   km_reset(w.pm_u); km_reset(w.sm_u); km_reset(w.bm_u);
   w.cor_pos = 0;
@@ -1776,6 +1786,8 @@ FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev
   w.s_let[1] += h1 + h2; w.s_let[2] += h1 + h2;
   w.st[ST_BASES] += size;
 }
+
+#include "fqsx_pe.h"
 
 // ---------------------------------------------------------------------------------------
 // kernel bodies
@@ -1803,7 +1815,18 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
     ws->rc_range = 0xff00000000000000ULL;
     ws->out_len = 0;
   }
-  u64 stop = seg < S ? ((u64)seg + 1) * (last - first) / ((u64)S + 1) + first + 1 : last;
+  const bool paired = cfg.mode >= 2;
+  u64 stop;
+  if (seg < S) {
+    const u64 ns = ((u64)seg + 1) * (last - first) / ((u64)S + 1) + first;
+    if (!paired) stop = ns + 1;            // SE: synchronise after read i == next_synchro (application.cpp:643)
+    else {                                 // PE: after the first pair with i >= next_synchro (application.cpp:1170)
+      u64 i = ws->cursor;
+      if (i < ns) i += (ns - i + 1) & ~1ull;
+      stop = i + 2;
+    }
+  } else
+    stop = last;
   if (stop > last) stop = last;
   // load state
   FQ_SYNC();
@@ -1828,17 +1851,31 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   km_reset(w.pm); km_reset(w.sm_); km_reset(w.bm); km_reset(w.pm_u); km_reset(w.sm_u); km_reset(w.bm_u);
 
   u64 cur = ws->cursor;
-  for (u64 i = cur; i < stop && !w.err; ++i) {
-    u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
-    const u8 *prev = nullptr;
-    u32 prev_size = 0;
-    if (i > first) {
-      u64 q0 = cfg.read_off[i - 1];
-      prev = cfg.bases + q0;
-      prev_size = (u32)(o0 - q0);
+  w.pe_n = 0;
+  if (!paired)
+    for (u64 i = cur; i < stop && !w.err; ++i) {
+      u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
+      const u8 *prev = nullptr;
+      u32 prev_size = 0;
+      if (i > first) {
+        u64 q0 = cfg.read_off[i - 1];
+        prev = cfg.bases + q0;
+        prev_size = (u32)(o0 - q0);
+      }
+      compress_read(w, cfg.bases + o0, (u32)(o1 - o0), prev, prev_size);
     }
-    compress_read(w, cfg.bases + o0, (u32)(o1 - o0), prev, prev_size);
-  }
+  else
+    for (u64 i = cur; i + 1 < stop && !w.err; i += 2) {
+      u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1], o2 = cfg.read_off[i + 2];
+      const u8 *prev = nullptr;
+      u32 prev_size = 0;
+      if (i > first) {  // read_prev = previous first mate of this worker in the block (dna.cpp:1748-1749)
+        u64 q0 = cfg.read_off[i - 2], q1 = cfg.read_off[i - 1];
+        prev = cfg.bases + q0;
+        prev_size = (u32)(q1 - q0);
+      }
+      compress_pair(w, cfg.bases + o0, (u32)(o1 - o0), cfg.bases + o1, (u32)(o2 - o1), prev, prev_size);
+    }
   if (stop > cur) cur = stop;
   // (entries still pending for the local tables need not be applied: ClearKmersToHT empties them next)
 
@@ -1857,6 +1894,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
     ws->mt_idx[g] = sm->mt_idx[g];
   }
   for (u32 k = 0; k < 3; ++k) cfg.mail[k].n[tid] = w.mn[k];
+  if (paired) cfg.pe_n[tid] = w.pe_n;
   if (w.err) *cfg.err = w.err;
 }
 

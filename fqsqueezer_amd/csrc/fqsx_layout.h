@@ -62,6 +62,15 @@ struct Mail {
 };
 enum { MAIL_P = 0, MAIL_S = 1, MAIL_B = 2 };
 
+// Paired-end minimizer-pair table (CHT_pair_kmers, ht_kmer.h:559-663): slot = (key, value | count << 2k),
+// (0,0) = empty; sub-table d holds the keys with (murmur64(key) >> 48) mod T == d (ht_kmer.h:599-611).
+struct PTab {
+  u64 *key, *val;
+  u64 cap_mask;   // capacity-1 of every sub-table
+  u64 stride;     // slots between sub-tables
+  u32 *filled;    // [n_sub]
+};
+
 // offsets (in u16 units) of the small direct-indexed models inside a worker's model block
 // every model = N stats followed by its total
 #define SM_FLAGS_N 2u       /* m_ctx_rc_flags: key = 8-bit duplicate-flag history */
@@ -76,7 +85,11 @@ enum { MAIL_P = 0, MAIL_S = 1, MAIL_B = 2 };
 #define SM_OFF_NIB (SM_OFF_PSNB + 65536u * (5u + 1u))
 #define SM_OFF_BYTE (SM_OFF_NIB + 68u * (SM_NIB_N + 1u))
 #define SM_BYTE_ENTRIES (16u + 16384u)
-#define SM_TOTAL_U16 (SM_OFF_BYTE + SM_BYTE_ENTRIES * (SM_BYTE_N + 1u))
+#define SM_OFF_MPOS (SM_OFF_BYTE + SM_BYTE_ENTRIES * (SM_BYTE_N + 1u))   /* m_ctx_rc_minimizer_pos: 15 ids x 6 key classes */
+#define SM_MPOS_ENTRIES 96u
+#define SM_OFF_MID (SM_OFF_MPOS + SM_MPOS_ENTRIES * (SM_BYTE_N + 1u))  /* ctx_rc_pe_minimizer_id: one 16-symbol model */
+#define SM_TOTAL_U16 (SM_OFF_MID + (SM_NIB_N + 1u))
+#define SM_LAZY_ENTRIES (SM_BYTE_ENTRIES + SM_MPOS_ENTRIES)           /* lazily initialised 256-symbol models */
 
 // per-worker persistent state (dna.cpp:148-171 and the encoder objects of application.cpp:580-584)
 struct WState {
@@ -129,9 +142,13 @@ struct DevCfg {
   u64 ctx_cap_mask;
   u32 *ctx_filled;             // [T]
   u16 *small;                  // [T][SM_TOTAL_U16]
-  u8 *byte_init;               // [T][SM_BYTE_ENTRIES] lazy-init flags of the 256-symbol models
+  u8 *byte_init;               // [T][SM_LAZY_ENTRIES] lazy-init flags of the 256-symbol models
   WState *ws;                  // [T]
   Mail mail[3];
+  PTab g_pe, l_pe;             // paired-end: global (owner-sharded) and per-worker local pair tables
+  u64 *pe_list;                // [T][pe_cap][3] (key, value, weight) triples pushed by each source
+  u32 *pe_n;                   // [T]
+  u32 pe_cap;                  // triples per source
   const u8 *bases;             // block input: concatenated ASCII reads
   const u64 *read_off;         // n_reads+1
   u8 *out;                     // [T][out_cap] DNA streams of the block
@@ -145,4 +162,6 @@ enum {
   FQSX_ERR_LTAB_FULL = 3,
   FQSX_ERR_CTX_FULL = 4,
   FQSX_ERR_MAIL_FULL = 5,
+  FQSX_ERR_PE_FULL = 6,
+  FQSX_ERR_PE_READ_TOO_LONG = 7,
 };

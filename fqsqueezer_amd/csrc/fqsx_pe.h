@@ -1,0 +1,431 @@
+// fqsx_pe.h -- paired-end part of the DNA path (CompressPE and helpers, dna.cpp:880-1136,1559-1638,1757-1880;
+// CHT_pair_kmers, ht_kmer.h:559-663 / ht_kmer.cpp).  Included by fqsx_dev.h.
+//
+// Per pair the PE-specific work is small (4+8 minimizer windows, 8 pair-table look-ups, <= 14 inserts); it is
+// written wave-uniform with lane-parallel selection steps.  The per-base coding of both mates reuses the
+// staged suffix coder (with a start position and the reversed-context variant for the left part of an
+// anchored second mate).
+#pragma once
+
+// ---- direct-strand b-mer windows (find_minimizer / find_maximizer / generate_read_bmers)
+FQ_DEV bool pe_valid_minimizer(const DevCfg *cfg, u64 x) { u64 f = x >> (2 * cfg->bmer - 6); return f != 0 && f != 1; }        // dna.cpp:879-889
+FQ_DEV bool pe_valid_maximizer(const DevCfg *cfg, u64 x) { u64 f = x >> (2 * cfg->bmer - 6); return f != 0x3e && f != 0x3f; }  // dna.cpp:892-902
+FQ_DEV u64 pe_value_mask(const DevCfg *cfg) { return (1ull << (2 * cfg->bmer)) - 1ull; }
+
+// find_minimizer over codes[off .. off+size), dna.cpp:999-1023
+FQ_DEV u64 pe_find_minimizer(const DevCfg *cfg, const u8 *codes, int off, int size) {
+  const u32 k = cfg->bmer;
+  const u64 vm = pe_value_mask(cfg);
+  u64 best = vm, v = 0;
+  u32 cur = 0;
+  for (int i = 0; i < size; ++i) {
+    u32 sym = codes[off + i];
+    if (sym == 4) { v = 0; cur = 0; }
+    else {
+      v = ((v << 2) | sym) & vm;
+      if (cur < k) ++cur;
+      if (cur == k && v < best && pe_valid_minimizer(cfg, v)) best = v;
+    }
+  }
+  return best;
+}
+// find_maximizer (walks the window backwards), dna.cpp:1026-1050
+FQ_DEV u64 pe_find_maximizer(const DevCfg *cfg, const u8 *codes, int off, int size) {
+  const u32 k = cfg->bmer;
+  const u64 vm = pe_value_mask(cfg);
+  u64 best = 0, v = 0;
+  u32 cur = 0;
+  for (int i = size - 1; i >= 0; --i) {
+    u32 sym = codes[off + i];
+    if (sym == 4) { v = 0; cur = 0; }
+    else {
+      v = ((v << 2) | sym) & vm;
+      if (cur < k) ++cur;
+      if (cur == k && v > best && pe_valid_maximizer(cfg, v)) best = v;
+    }
+  }
+  return best;
+}
+
+// ---- pair tables
+FQ_DEV u32 pe_owner(const DevCfg *cfg, u64 h) { return (u32)((h >> 48) % cfg->T); }  // get_part_id_from_hash, ht_kmer.h:599-602
+
+// CHT_pair_kmers::find (ht_kmer.cpp:211-228): append every (value|count) stored under `key` to the LDS candidate
+// list; when the list fills up it is cut to its best 48 entries (exact: top-48 of a union is the top-48 of the
+// parts' top-48, and merge_minim_results keeps only those when more than 48 exist)
+FQ_DEV void pe_reduce48(Wk &w, u32 &n);
+FQ_DEV void ptab_find(Wk &w, const PTab &t, u32 sub, u64 key, u32 &n) {
+  const u64 h = murmur64(key);
+  const u64 *tk = t.key + (u64)sub * t.stride, *tv = t.val + (u64)sub * t.stride;
+  u64 p = h & t.cap_mask;
+  for (u64 it = 0; it <= t.cap_mask; ++it) {
+    u64 k = tk[p], v = tv[p];
+    if (k == 0 && v == 0) break;
+    if (k == key) {
+      if (n == 512) pe_reduce48(w, n);
+      FQ_SYNC();
+      if (FQ_LANE == 0) w.sm->pe_cand[n] = v;
+      FQ_SYNC();
+      ++n;
+    }
+    p = (p + 1) & t.cap_mask;
+  }
+}
+// CHT_pair_kmers::insert (ht_kmer.cpp:124-187), wave-uniform (used for the worker-private table)
+FQ_DEV void ptab_insert_uniform(Wk &w, const PTab &t, u32 sub, u64 key, u64 value, u64 count) {
+  const DevCfg *cfg = w.cfg;
+  const u64 vm = pe_value_mask(cfg), maxc = (~0ull) >> (2 * cfg->bmer);
+  const u32 cs = 2 * cfg->bmer;
+  if (key == vm || value == vm) return;
+  u64 *tk = t.key + (u64)sub * t.stride, *tv = t.val + (u64)sub * t.stride;
+  u64 p = murmur64(key) & t.cap_mask;
+  for (u64 it = 0; it <= t.cap_mask; ++it) {
+    u64 k = tk[p], v = tv[p];
+    if (k == 0 && v == 0) {
+      u32 f = t.filled[sub];
+      if ((u64)f * 10 >= (t.cap_mask + 1) * 9) { w.err = FQSX_ERR_PE_FULL; return; }
+      if (count > maxc) count = maxc;
+      tk[p] = key;
+      tv[p] = value + (count << cs);
+      t.filled[sub] = f + 1;
+      return;
+    }
+    if (k == key && (v & vm) == value) {
+      u64 cur = v >> cs;
+      tv[p] = cur + count < maxc ? v + (count << cs) : v + ((maxc - cur) << cs);
+      return;
+    }
+    p = (p + 1) & t.cap_mask;
+  }
+  w.err = FQSX_ERR_PE_FULL;
+}
+
+// ---- candidate ranking (merge_minim_results, dna.cpp:905-971)
+// order A: counter descending, then value ascending; order B: value ascending.  rank = number of entries that
+// precede (ties by index); entries with rank < keep are written to dst[rank].
+FQ_DEV void pe_rank_select(Wk &w, const u64 *src, u32 n, u64 *dst, u32 keep, bool by_count) {
+  const u32 cs = 2 * w.cfg->bmer;
+  const u64 vm = pe_value_mask(w.cfg);
+  FQ_SYNC();
+  for (u32 i = FQ_LANE; i < n; i += FQ_WAVE) {
+    const u64 x = src[i], xc = x >> cs, xv = x & vm;
+    u32 rank = 0;
+    for (u32 j = 0; j < n; ++j) {
+      const u64 y = src[j], yc = y >> cs, yv = y & vm;
+      bool before;
+      if (by_count) before = yc != xc ? yc > xc : yv != xv ? yv < xv : j < i;
+      else before = yv != xv ? yv < xv : j < i;
+      rank += before ? 1u : 0u;
+    }
+    if (rank < keep) dst[rank] = x;
+  }
+  FQ_SYNC();
+}
+FQ_DEV void pe_reduce48(Wk &w, u32 &n) {
+  WgShared *sm = w.sm;
+  pe_rank_select(w, sm->pe_cand, n, sm->pe_top, 48, true);
+  for (u32 i = FQ_LANE; i < 48; i += FQ_WAVE) sm->pe_cand[i] = sm->pe_top[i];
+  FQ_SYNC();
+  n = 48;
+}
+// leaves the best (<= 16) merged candidates in sm->pe_top, in order; returns their number
+FQ_DEV u32 pe_merge_candidates(Wk &w, u32 n) {
+  WgShared *sm = w.sm;
+  const u32 cs = 2 * w.cfg->bmer;
+  const u64 vm = pe_value_mask(w.cfg), maxc = (~0ull) >> cs;
+  if (n == 1) {
+    FQ_SYNC();
+    if (FQ_LANE == 0) sm->pe_top[0] = sm->pe_cand[0];
+    FQ_SYNC();
+    return 1;
+  }
+  if (n > 48) pe_reduce48(w, n);
+  pe_rank_select(w, sm->pe_cand, n, sm->pe_top, n, false);  // sort by value
+  // merge equal values, summing the counters with saturation (dna.cpp:937-950); result back into pe_cand
+  u32 m = 0;
+  u64 cur = sm->pe_top[0];
+  for (u32 i = 1; i < n; ++i) {
+    u64 x = sm->pe_top[i];
+    if ((cur & vm) != (x & vm)) {
+      FQ_SYNC();
+      if (FQ_LANE == 0) sm->pe_cand[m] = cur;
+      ++m;
+      cur = x;
+    } else {
+      u64 cx = cur >> cs, cy = x >> cs;
+      if (cx + cy > maxc) cy = maxc - cx;
+      cur += cy << cs;
+    }
+  }
+  FQ_SYNC();
+  if (FQ_LANE == 0) sm->pe_cand[m] = cur;
+  ++m;
+  FQ_SYNC();
+  pe_rank_select(w, sm->pe_cand, m, sm->pe_top, 16, true);  // only the first 15 can be selected (dna.cpp:1827-1828)
+  return m < 16 ? m : 16;
+}
+
+FQ_DEV void pe_push(Wk &w, u64 key, u64 value, u64 weight) {  // my_pe_mers_to_add + ht_pe_mers_local->insert
+  const DevCfg *cfg = w.cfg;
+  if (w.pe_n >= cfg->pe_cap) { w.err = FQSX_ERR_PE_FULL; return; }
+  u64 *d = cfg->pe_list + ((u64)w.tid * cfg->pe_cap + w.pe_n) * 3;
+  d[0] = key; d[1] = value; d[2] = weight;
+  ++w.pe_n;
+  ptab_insert_uniform(w, cfg->l_pe, w.tid, key, value, weight);
+}
+
+FQ_DEV void pe_seed_kmers(Wk &w, const u8 *codes, u32 from, u32 to) {  // dna.cpp:1577-1592,1616-1631
+  const DevCfg *cfg = w.cfg;
+  km_reset(w.pm); km_reset(w.sm_); km_reset(w.bm);
+  km_reset(w.pm_u); km_reset(w.sm_u); km_reset(w.bm_u);
+  w.cor_pos = 0;
+  w.N_run = 0;
+  for (u32 i = from; i < to; ++i) {
+    u32 c = codes[i];
+    if (c == 4) c = 0;
+    insert_all(w, c);
+  }
+}
+
+// CompressPE, dna.cpp:1790-1880
+FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size2, const u8 *prev, u32 prev_size) {
+  const DevCfg *cfg = w.cfg;
+  WgShared *sm = w.sm;
+  const int k = (int)cfg->bmer;
+  const u64 vm = pe_value_mask(cfg);
+  if (size1 > FQSX_RD_LDS || size2 > FQSX_RD_LDS) { w.err = FQSX_ERR_PE_READ_TOO_LONG; return; }
+  // first mate
+  compress_read(w, p1, size1, prev, prev_size, true);
+  if (w.err) return;
+  // (a duplicate first mate returns early from the coder but sm->rd was staged before that)
+  // minimizers of the first mate: 4 windows for the look-up (dna.cpp:1761-1769), 3 + 1 for the inserts (:1055-1083)
+  u64 m1[4], a1[3], x1;
+  {
+    int mss = (int)size1 - k + 1, s1 = mss / 4, s2 = 2 * mss / 4, s3 = 3 * mss / 4;
+    m1[0] = pe_find_minimizer(cfg, sm->rd, 0, s1 + k - 1);
+    m1[1] = pe_find_minimizer(cfg, sm->rd, s1, s2 - s1 + k - 1);
+    m1[2] = pe_find_minimizer(cfg, sm->rd, s2, s3 - s2 + k - 1);
+    m1[3] = pe_find_minimizer(cfg, sm->rd, s3, (int)size1 - s3);
+    int a = mss / 3, b = 2 * mss / 3;
+    a1[0] = pe_find_minimizer(cfg, sm->rd, 0, a + k - 1);
+    a1[1] = pe_find_minimizer(cfg, sm->rd, a, b - a + k - 1);
+    a1[2] = pe_find_minimizer(cfg, sm->rd, b, (int)size1 - b);
+    int mid1 = ((int)size1 + k) / 2;
+    x1 = (~pe_find_maximizer(cfg, sm->rd, mid1 - k + 1, (int)size1 - (mid1 - k + 1))) & vm;
+  }
+  // second mate's codes
+  FQ_SYNC();
+  for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) sm->r2c[i] = (u8)dna_code(p2[i]);
+  FQ_SYNC();
+  u64 a2[3], x2;
+  {
+    int mss = (int)size2 - k + 1, a = mss / 3, b = 2 * mss / 3;
+    a2[0] = pe_find_minimizer(cfg, sm->r2c, 0, a + k - 1);
+    a2[1] = pe_find_minimizer(cfg, sm->r2c, a, b - a + k - 1);
+    a2[2] = pe_find_minimizer(cfg, sm->r2c, b, (int)size2 - b);
+    int mid2 = ((int)size2 + k) / 2;
+    x2 = (~pe_find_minimizer(cfg, sm->r2c, mid2 - k + 1, (int)size2 - (mid2 - k + 1))) & vm;  // sic: minimizer (dna.cpp:1087)
+  }
+  // find_minim_cand: global then local table, 4 minimizers each (dna.cpp:1771-1779)
+  u32 nc = 0;
+  for (u32 i = 0; i < 4; ++i) ptab_find(w, cfg->g_pe, pe_owner(cfg, murmur64(m1[i])), m1[i], nc);
+  for (u32 i = 0; i < 4; ++i) ptab_find(w, cfg->l_pe, w.tid, m1[i], nc);
+  int mid = -1;
+  u32 mpos = 0;
+  if (nc) {
+    const u32 ntop = pe_merge_candidates(w, nc);
+    // first listed candidate occurring in the second mate, and its first position (dna.cpp:1806-1819,974-996)
+    u32 best_c = 0xffffffffu, best_pos = 0;
+    for (u32 base = 0; base < size2; base += FQ_WAVE) {
+      const u32 e = base + FQ_LANE;  // b-mer ending at position e
+      u64 v = 0;
+      bool ok = e < size2 && e + 1 >= (u32)k;
+      if (ok)
+        for (int t = 0; t < k; ++t) {
+          u32 c = sm->r2c[e + 1 - k + t];
+          if (c == 4) ok = false;
+          v = (v << 2) | (c & 3);
+        }
+      ok = ok && pe_valid_minimizer(cfg, v);
+      for (u32 c = 0; c < ntop && c < best_c; ++c) {
+        u64 hit = wave_ballot(ok && v == (sm->pe_top[c] & vm));
+        if (hit) {
+          best_c = c;
+#if FQ_WAVE > 1
+          best_pos = base + ctz64(hit) + 1 - (u32)k;
+#else
+          best_pos = e + 1 - (u32)k;
+#endif
+        }
+      }
+    }
+    mid = best_c == 0xffffffffu || best_c > 14 ? 15 : (int)best_c;
+    mpos = best_pos;
+  }
+  u16 *sb = small_base(w);
+  if (mid < 0) compress_read(w, p2, size2, nullptr, 0, false);
+  else {
+    sm_encode(w, sb + SM_OFF_MID, SM_NIB_N, 1u << 15, (u32)mid);  // ctx_rc_pe_minimizer_id, dna.cpp:1835
+    if (mid == 15) compress_read(w, p2, size2, nullptr, 0, false);
+    else {
+      // position of the anchor (dna.cpp:1840-1868); models keyed by id (+0x100..0x500 for the escape bytes)
+      u8 *bi = cfg->byte_init + (u64)w.tid * SM_LAZY_ENTRIES + SM_BYTE_ENTRIES;
+      u16 *mp = sb + SM_OFF_MPOS;
+#define MPOS_ENC(cls, sym) sm_encode256(w, mp + (u64)((cls) * 16 + mid) * (SM_BYTE_N + 1), bi + ((cls) * 16 + mid), (sym))
+      if (mpos < 254) MPOS_ENC(0, mpos);
+      else if (mpos < 65536) { MPOS_ENC(0, 254); MPOS_ENC(1, mpos >> 8); MPOS_ENC(2, mpos & 0xff); }
+      else { MPOS_ENC(0, 255); MPOS_ENC(3, mpos >> 16); MPOS_ENC(4, (mpos >> 8) & 0xff); MPOS_ENC(5, mpos & 0xff); }
+#undef MPOS_ENC
+      // CompressDirectWithMinim (dna.cpp:1559-1638): right part forwards from the anchor ...
+      FQ_SYNC();
+      for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) sm->rd[i] = sm->r2c[i];
+      FQ_SYNC();
+      pe_seed_kmers(w, sm->rd, mpos, mpos + (u32)k);
+      suffix(w, p2, size2, true, (u32)k + mpos, false, mpos);
+      // ... then the left part on the reverse complement, anchored at the same b-mer
+      const u32 rsz = mpos + (u32)k;
+      FQ_SYNC();
+      for (u32 i = FQ_LANE; i < rsz; i += FQ_WAVE) {
+        u32 c = sm->r2c[rsz - 1 - i];
+        sm->rd[i] = (u8)(c == 4 ? 4 : 3 - c);
+      }
+      FQ_SYNC();
+      pe_seed_kmers(w, sm->rd, 0, (u32)k);
+      suffix(w, p2, rsz, true, (u32)k, true, 0);
+      // update_s_letters(p2), dna.cpp:1635
+      u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+      for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) {
+        u32 c = sm->r2c[i];
+        h0 += c == 0; h1 += c == 1; h2 += c == 2; h3 += c == 3;
+      }
+      h0 = wave_sum32(h0); h1 = wave_sum32(h1); h2 = wave_sum32(h2); h3 = wave_sum32(h3);
+      w.s_let[0] += h0 + h3; w.s_let[3] += h0 + h3;
+      w.s_let[1] += h1 + h2; w.s_let[2] += h1 + h2;
+      w.st[ST_BASES] += size2;
+    }
+  }
+  if (w.err) return;
+  // append_pe_mers3, dna.cpp:1090-1135
+  pe_push(w, a1[0], a2[0], 2); pe_push(w, a1[0], a2[2], 4); pe_push(w, a1[0], x1, 1);
+  pe_push(w, a1[1], a2[0], 3); pe_push(w, a1[1], a2[2], 3);
+  pe_push(w, a1[2], a2[0], 4); pe_push(w, a1[2], a2[2], 2);
+  pe_push(w, a2[0], a1[0], 2); pe_push(w, a2[0], a1[2], 4); pe_push(w, a2[0], x2, 1);
+  pe_push(w, a2[1], a1[0], 3); pe_push(w, a2[1], a1[2], 4);
+  pe_push(w, a2[2], a1[0], 4); pe_push(w, a2[2], a1[2], 2);
+}
+
+// ---- insert phase: owner `tid` scans every source's triples and applies those it owns.  Inserts commute
+// (count = min(sum, max)), so the scan order is irrelevant; a batch of <= 64 owned triples is applied
+// lane-parallel unless two of them touch the same slot.
+FQ_DEV void pe_apply_batch(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n, u32 &err) {
+  const PTab &t = cfg.g_pe;
+  const u32 cs = 2 * cfg.bmer;
+  const u64 vm = (1ull << cs) - 1ull, maxc = (~0ull) >> cs;
+  u64 *tk = t.key + (u64)tid * t.stride, *tv = t.val + (u64)tid * t.stride;
+  const u32 lane = FQ_LANE;
+  const bool act = lane < n;
+  u64 key = 0, value = 0, cnt = 0, pos = ~0ull, oldv = 0;
+  bool found = false;
+  if (act) {
+    key = sm->pe_bk[0][lane]; value = sm->pe_bk[1][lane]; cnt = sm->pe_bk[2][lane];
+    u64 p = murmur64(key) & t.cap_mask;
+    for (u64 it = 0; it <= t.cap_mask; ++it) {
+      u64 k = tk[p], v = tv[p];
+      if (k == 0 && v == 0) break;
+      if (k == key && (v & vm) == value) { found = true; oldv = v; break; }
+      p = (p + 1) & t.cap_mask;
+    }
+    pos = p;
+  }
+  FQ_SYNC();
+  sm->bk_key[lane] = pos;
+  FQ_SYNC();
+  bool clash = false;
+#if FQ_WAVE > 1
+  if (act)
+    for (u32 j = 0; j < n; ++j)
+      if (j != lane && sm->bk_key[j] == pos) clash = true;
+#endif
+  const u32 filled = t.filled[tid];
+  const u32 n_new = popc64(wave_ballot(act && !found));
+  if ((u64)(filled + n_new) * 10 >= (t.cap_mask + 1) * 9) { err = FQSX_ERR_PE_FULL; return; }
+  if (!wave_any(clash)) {
+    if (act) {
+      if (!found) {
+        tk[pos] = key;
+        tv[pos] = value + ((cnt > maxc ? maxc : cnt) << cs);
+      } else {
+        u64 cur = oldv >> cs;
+        tv[pos] = cur + cnt < maxc ? oldv + (cnt << cs) : oldv + ((maxc - cur) << cs);
+      }
+    }
+    if (lane == 0) t.filled[tid] = filled + n_new;
+    FQ_SYNC_MEM();
+    return;
+  }
+  FQ_SYNC_MEM();
+  for (u32 j = 0; j < n; ++j) {  // serial fallback
+    const u64 kj = sm->pe_bk[0][j], vj = sm->pe_bk[1][j];
+    u64 cj = sm->pe_bk[2][j];
+    u64 p = murmur64(kj) & t.cap_mask;
+    for (u64 it = 0; it <= t.cap_mask; ++it) {
+      u64 k = tk[p], v = tv[p];
+      if (k == 0 && v == 0) {
+        tk[p] = kj;
+        tv[p] = vj + ((cj > maxc ? maxc : cj) << cs);
+        t.filled[tid] = t.filled[tid] + 1;
+        break;
+      }
+      if (k == kj && (v & vm) == vj) {
+        u64 cur = v >> cs;
+        tv[p] = cur + cj < maxc ? v + (cj << cs) : v + ((maxc - cur) << cs);
+        break;
+      }
+      p = (p + 1) & t.cap_mask;
+    }
+  }
+  FQ_SYNC_MEM();
+}
+
+// count_only: number of triples owner `tid` will insert (upper bound of new slots) -> demand[tid]
+FQ_DEV void pe_insert_body(const DevCfg &cfg, WgShared *sm, u32 tid, bool count_only, u32 *demand) {
+  const u32 T = cfg.T;
+  const u64 vm = (1ull << (2 * cfg.bmer)) - 1ull;
+  u32 pending = 0, total = 0, err = 0;
+  for (u32 src = 0; src < T && !err; ++src) {
+    const u32 n = cfg.pe_n[src];
+    const u64 *list = cfg.pe_list + (u64)src * cfg.pe_cap * 3;
+    for (u32 base = 0; base < n && !err; base += FQ_WAVE) {
+      const u32 e = base + FQ_LANE;
+      u64 key = 0, value = 0, cnt = 0;
+      bool mine = false;
+      if (e < n) {
+        key = list[3 * (u64)e]; value = list[3 * (u64)e + 1]; cnt = list[3 * (u64)e + 2];
+        mine = key != vm && value != vm && pe_owner(&cfg, murmur64(key)) == tid;  // ht_kmer.cpp:126-127
+      }
+      const u64 bm = wave_ballot(mine);
+      const u32 cntm = popc64(bm);
+      total += cntm;
+      if (count_only || !cntm) continue;
+      if (pending + cntm > FQ_WAVE) {
+        pe_apply_batch(cfg, sm, tid, pending, err);
+        pending = 0;
+      }
+#if FQ_WAVE > 1
+      const u32 slot = pending + popc64(bm & ((1ull << FQ_LANE) - 1ull));
+#else
+      const u32 slot = pending;
+#endif
+      FQ_SYNC();
+      if (mine) { sm->pe_bk[0][slot] = key; sm->pe_bk[1][slot] = value; sm->pe_bk[2][slot] = cnt; }
+      FQ_SYNC();
+      pending += cntm;
+    }
+  }
+  if (count_only) {
+    if (FQ_LANE == 0) demand[tid] = total;
+    return;
+  }
+  if (pending && !err) pe_apply_batch(cfg, sm, tid, pending, err);
+  if (err) *cfg.err = err;
+}

@@ -43,7 +43,8 @@ enum {
  * ('K','C','S','D', no_threads T, dna_mode, quality_mode, id_mode, quality_thr,
  *  duplicates_check, prefix_len, pmer_len, smer_len, bmer_len, imer_len, hmer_len,
  *  ht_prefix_len; fqs/params.h:80-100).  T is the number of logical workers and is part of
- * the bitstream.  dna_mode 0 (se_original) and 1 (se_sorted) are implemented.
+ * the bitstream.  dna_mode 0..3 (se_original, se_sorted, pe_original, pe_sorted) are implemented; in the
+ * paired modes a block holds the mates interleaved (mate 1, mate 2, mate 1, ...) and n_reads is even.
  * device: HIP device ordinal. */
 int fqsx_dna_create(const uint8_t *header17, int device, fqsx_dna **out);
 void fqsx_dna_destroy(fqsx_dna *);

@@ -4,7 +4,7 @@ in the GPU-less container; the 64-lane paths are covered by tests/test_gpu_parit
 import numpy as np
 import pytest
 
-from conftest import EMU_LIB, c1_records, c4_records, check_against_digest, check_against_fqs
+from conftest import EMU_LIB, c1_records, c4_records, c5_records, check_against_digest, check_against_fqs, check_against_fqs_pe
 from fqsqueezer_amd import hostpipe as hp
 from fqsqueezer_amd.codec import DnaCodec
 from oracle.pyoracle import OracleCodec
@@ -31,6 +31,11 @@ def test_emu_matches_reference_ragged(name):
     check_against_fqs(emu, c4_records(), name)
 
 
+@pytest.mark.parametrize("name", ["c5_pe4k_o_t1.fqs", "c5_pe4k_o_t4.fqs", "c5_pe4k_s_t1.fqs", "c5_pe4k_s_t4.fqs"])
+def test_emu_matches_reference_paired_end(name):
+    check_against_fqs_pe(emu, c5_records(), name)
+
+
 def test_emu_matches_reference_150bp():
     check_against_digest(emu, "c3_50k150_s_t8.json")
 
@@ -49,6 +54,6 @@ def test_emu_matches_oracle_many_workers_and_tiny_blocks():
 def test_abi_rejects_bad_headers():
     from fqsqueezer_amd.codec import FqsxError
     good = hp.make_header(2, "se_sorted", 1)
-    for bad in [b"XCSD" + good[4:], good[:4] + bytes([0]) + good[5:], good[:5] + bytes([3]) + good[6:]]:
+    for bad in [b"XCSD" + good[4:], good[:4] + bytes([0]) + good[5:], good[:5] + bytes([4]) + good[6:]]:
         with pytest.raises(FqsxError):
             emu(bad)

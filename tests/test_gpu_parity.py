@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, c1_records, c4_records, check_against_digest, check_against_fqs
+from conftest import GOLD, c1_records, c4_records, c5_records, check_against_digest, check_against_fqs, check_against_fqs_pe
 from fqsqueezer_amd import hostpipe as hp
 
 pytestmark = pytest.mark.gpu
@@ -26,6 +26,22 @@ def test_hip_matches_reference_10k(name):
 @pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
 def test_hip_matches_reference_ragged(name):
     check_against_fqs(gpu, c4_records(), name)
+
+
+@pytest.mark.parametrize("name", ["c5_pe4k_o_t1.fqs", "c5_pe4k_o_t4.fqs", "c5_pe4k_s_t1.fqs", "c5_pe4k_s_t4.fqs"])
+def test_hip_matches_reference_paired_end(name):
+    check_against_fqs_pe(gpu, c5_records(), name)
+
+
+def test_hip_matches_oracle_paired_end_many_workers():
+    from oracle.pyoracle import OracleCodec
+    rec1, rec2 = c5_records()
+    for T, mode in [(16, "pe_sorted"), (64, "pe_original")]:
+        header = hp.make_header(T, mode, 1)
+        a, b = gpu(header), OracleCodec(header)
+        for g, idx in enumerate(hp.form_blocks_pe(rec1, rec2, mode)[:40]):
+            bases, off = hp.block_arrays_pe(rec1, rec2, idx)
+            assert a.encode_block(bases, off, g) == b.encode_block(bases, off, g)
 
 
 def test_hip_matches_reference_150bp():
