@@ -134,3 +134,22 @@ def synth_pairs(n_pairs: int, read_len: int, genome_len: int, seed: int, frag_mi
         r = np.where((u >= sub_rate) & (u < sub_rate + n_rate), np.uint8(ord("N")), r)
         out.append(np.ascontiguousarray(r))
     return out[0], out[1]
+
+
+def synth_mixed_lengths(n_reads: int = 1500, genome_len: int = 40000, seed: int = 7):
+    """Very short (20-31 bp, shorter than the b-mer), very long (4200-6000 bp, beyond the LDS staging
+    buffer) and ordinary reads with N runs.  Returns (ids, seqs, quals) lists of bytes."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    g = _ACGT[rng.integers(0, 4, size=genome_len, dtype=np.uint8)]
+    ids, seqs, quals = [], [], []
+    for i in range(n_reads):
+        r = rng.random()
+        L = int(rng.integers(20, 32)) if r < 0.4 else int(rng.integers(4200, 6000)) if r < 0.45 else int(rng.integers(60, 200))
+        pos = int(rng.integers(0, genome_len - L))
+        s = g[pos:pos + L].copy()
+        if rng.random() < 0.3:
+            s[int(rng.integers(0, L)):][:int(rng.integers(1, 12))] = ord("N")
+        ids.append(b"@x%d" % i)
+        seqs.append(s.tobytes())
+        quals.append(b"I" * L)
+    return ids, seqs, quals

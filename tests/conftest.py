@@ -122,3 +122,10 @@ def check_against_fqs_pe(make_codec, recs, fqs_name):
         for w, s in enumerate(streams):
             assert s == ref.streams[w][hp.STREAM_DNA], f"{fqs_name}: block {g} worker {w} differs from the reference"
     return codec
+
+
+def c7_records():
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.synth import synth_mixed_lengths
+    ids, seqs, quals = synth_mixed_lengths()
+    return hp.Records(ids, seqs, quals)

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, c1_records, c4_records, c5_records, check_against_digest, check_against_fqs, check_against_fqs_pe
+from conftest import GOLD, c1_records, c4_records, c5_records, c7_records, check_against_digest, check_against_fqs, check_against_fqs_pe
 from fqsqueezer_amd import hostpipe as hp
 
 pytestmark = pytest.mark.gpu
@@ -42,6 +42,15 @@ def test_hip_matches_oracle_paired_end_many_workers():
         for g, idx in enumerate(hp.form_blocks_pe(rec1, rec2, mode)[:40]):
             bases, off = hp.block_arrays_pe(rec1, rec2, idx)
             assert a.encode_block(bases, off, g) == b.encode_block(bases, off, g)
+
+
+@pytest.mark.parametrize("name", ["c7_mixedlen_o_t3.fqs", "c7_mixedlen_s_t3.fqs"])
+def test_hip_matches_reference_short_and_long_reads(name):
+    check_against_fqs(gpu, c7_records(), name)
+
+
+def test_hip_matches_reference_large_k_geometry():
+    check_against_digest(gpu, "c6_20k_gs300_s_t2.json")
 
 
 def test_hip_matches_reference_150bp():

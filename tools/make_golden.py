@@ -8,6 +8,8 @@ Fixtures (data only -- inputs are re-generated deterministically by fqsqueezer_a
                             1M x 100bp, G=5Mbp, seed 2, -om s -gs 5   (BASELINE configs[1])
   c4_ragged_{o,s}_t3.fqs   3000 ragged reads (30-160 bp, N runs, duplicates), G=60kbp, seed 4, -gs 1
   c5_pe4k_{o,s}_t{1,4}.fqs  4000 pairs x 100bp (fragments 300-600), G=60kbp, seed 5, `-p`, -gs 1 (paired-end path)
+  c6_20k_gs300_s_t2.json    20k x 100bp, G=1Mbp, seed 6, -gs 300 (k = 12/17/21/26: 4 GiB p-mer vector, 256-way partial look-ups)
+  c7_mixedlen_{o,s}_t3.fqs  1500 reads of 20-31 / 60-199 / 4200-5999 bp with N runs, G=40kbp, seed 7, -gs 1
   c3_50k150_s_t8.json       50k x 150bp, G=250kbp, seed 3, -om s -gs 8 (150 bp metric shape)
 Usage: python tools/make_golden.py [--work /tmp/w] [--only c1|c2|c3]
 """
@@ -85,6 +87,23 @@ def main():
                 if not os.path.exists(out):
                     subprocess.check_call([REF, "e", "-p", "-om", om, "-t", str(t), "-gs", "1", "-qm", "n", "-im", "n", "-v", "0",
                                            "-tmp", os.path.join(a.work, "tmpp_"), "-out", out, f1, f2], stdout=subprocess.DEVNULL)
+    if a.only in ("", "c6"):
+        fq = os.path.join(a.work, "c6.fq")
+        if not os.path.exists(fq):
+            write_fastq(fq, synth_reads(20000, 100, 1000000, 6), seed=6)
+        out = os.path.join(a.work, "c6_s_t2.fqs")
+        run_ref(fq, out, "s", 2, 300, a.work)
+        meta = {"reads": 20000, "len": 100, "genome": 1000000, "seed": 6, "gs": 300, "om": "s", "threads": 2}
+        json.dump(digest(out, meta), open(os.path.join(GOLD, "c6_20k_gs300_s_t2.json"), "w"))
+    if a.only in ("", "c7"):
+        from fqsqueezer_amd.synth import synth_mixed_lengths
+        ids, seqs, quals = synth_mixed_lengths()
+        fq = os.path.join(a.work, "c7.fq")
+        with open(fq, "wb") as f:
+            for i, sq, q in zip(ids, seqs, quals):
+                f.write(i + b"\n" + sq + b"\n+\n" + q + b"\n")
+        for om in "os":
+            run_ref(fq, os.path.join(GOLD, f"c7_mixedlen_{om}_t3.fqs"), om, 3, 1, a.work)
     if a.only in ("", "c3"):
         fq = os.path.join(a.work, "c3.fq")
         if not os.path.exists(fq):
