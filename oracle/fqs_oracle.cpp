@@ -400,9 +400,29 @@ struct PairTable {
 
 // ---------------------------------------------------------------------------------------
 // CRangeEncoder, sub_rc.h:32-87
-struct RangeEnc {
+struct RangeEnc {  // + CRangeDecoder, sub_rc.h:93-158, when dec is set
   u64 low, range;
   std::vector<u8> out;
+  bool dec = false;
+  const u8 *in = nullptr;
+  u64 in_len = 0, in_pos = 0, buffer = 0;
+  u8 get_byte() { return in_pos < in_len ? in[in_pos++] : (u8)0; }
+  void start_dec(const u8 *p, u64 n) {  // sub_rc.h:112-125
+    in = p; in_len = n; in_pos = 0; buffer = 0;
+    if (n >= 8) for (u32 i = 1; i <= 8; ++i) buffer |= (u64)get_byte() << (64 - i * 8);
+    low = 0; range = 0xff00000000000000ULL;
+  }
+  u64 cum_freq(u64 tot) { range /= tot; return buffer / range; }  // GetCumulativeFreq, sub_rc.h:127-131
+  void update(u64 freq, u64 cum) {  // UpdateFrequency, sub_rc.h:133-151
+    const u64 Top = 0x00ffffffffffffULL, M = 0xff00000000000000ULL;
+    u64 r = cum * range;
+    buffer -= r; low += r; range *= freq;
+    while (range <= Top) {
+      if ((low ^ (low + range)) & M) { u64 q = low; range = (q | Top) - q; }
+      buffer = (buffer << 8) + get_byte();
+      low <<= 8; range <<= 8;
+    }
+  }
   void start() { low = 0; range = 0xff00000000000000ULL; }
   void encode(u64 freq, u64 cum, u64 tot) {
     const u64 Top = 0x00ffffffffffffULL, M = 0xff00000000000000ULL;
@@ -442,14 +462,25 @@ struct Model {
       for (u32 i = 0; i < n; ++i) { st[i] = (st[i] + 1) / 2; total += st[i]; }
     }
   }
-  void encode(RangeEnc &rc, u32 x, u64 *n_coded) {  // rc.h:397-405,478-488,125-132
+  // Encode (rc.h:397-405,478-488) or, on a decoding coder, Decode (rc.h:407-421,490-503); returns the symbol
+  u32 encode(RangeEnc &rc, u32 x, u64 *n_coded) {
     u32 left = 0;
-    for (u32 i = 0; i < x; ++i) left += st[i];
-    rc.encode(st[x], left, total);
+    if (rc.dec) {
+      u64 lt = rc.cum_freq(total);
+      u32 t = 0;
+      x = n - 1;
+      for (u32 i = 0; i < n; ++i) { t += st[i]; if (t > lt) { x = i; break; } }  // GetSym, rc.h:134-146
+      for (u32 i = 0; i < x; ++i) left += st[i];
+      rc.update(st[x], left);
+    } else {
+      for (u32 i = 0; i < x; ++i) left += st[i];
+      rc.encode(st[x], left, total);
+    }
     st[x] += 4;
     total += 4;
     if (total >= max_total) rescale();
     ++*n_coded;
+    return x;
   }
 };
 
@@ -749,6 +780,13 @@ struct Worker {
     return r;
   }
 
+  u8 un_rank(const u32 counts[4], u8 r) const {  // dna.cpp:197-207
+    if (r == 4) return 4;
+    for (u8 i = 0; i < 4; ++i) if (rank(counts, i) == r) return i;
+    return 4;
+  }
+  static u8 alpha(u32 sym) { return (u8)"ACGTN"[sym]; }
+
   bool find_counts_p(const Kmer &km, u32 counts[4]) {  // dna.cpp:210-226
     if (!km.full()) {
       Kmer t = km;
@@ -897,17 +935,18 @@ struct Worker {
     return p->m;
   }
 
-  void code_letter(u32 pos, u8 sym, u32 read_len) {  // dna.cpp:776-785, :520-528
+  u8 code_letter(u32 pos, u8 sym, u32 read_len) {  // dna.cpp:776-785, :520-528 (decode: :1246-1254,1353-1360)
     u64 lev[10];
     ctx_letters_keys(lev, sh->kl, pos, ctx_letters, read_len);
-    find_leveled(m_letters, lev, 9, t_letters, avg_letters, LETTERS_THR)->encode(rc, sym, &sh->cnt.coded);
+    return (u8)find_leveled(m_letters, lev, 9, t_letters, avg_letters, LETTERS_THR)->encode(rc, sym, &sh->cnt.coded);
   }
 
-  void prefix_direct(const u8 *p) {  // compress_prefix_direct, dna.cpp:506-546 (start_pos == 0)
+  void prefix_direct(u8 *p) {  // compress_prefix_direct, dna.cpp:506-546 (start_pos == 0); decompress_prefix_direct :1347-1381
     ctx_letters = ~0ull;
     for (u32 i = 0; i < sh->kl.prefix; ++i) {
-      u8 sym = (u8)dna_code(p[i]);
-      code_letter(i, sym, 0);
+      u8 sym = rc.dec ? 0 : (u8)dna_code(p[i]);
+      sym = code_letter(i, sym, 0);
+      if (rc.dec) p[i] = alpha(sym);
       ctx_letters = (ctx_letters << 4) + sym;
       if (sym == 4) { sym = 0; cor_pos = i; }
       pmer.insert(sym); smer.insert(sym); bmer.insert(sym);
@@ -959,13 +998,56 @@ struct Worker {
     push_p(pmer.aligned_rc());
   }
 
-  void suffix(const u8 *p, u32 size, bool original_order, u32 start_pos = 0, bool reversed_pe = false) {  // compress_suffix, dna.cpp:674-877
+  void prefix_sorted_dec(u8 *p) {  // decompress_prefix_sorted, dna.cpp:1384-1514
+    u64 *nc = &sh->cnt.coded;
+    bool was_N = m_Ns.get(0, t_Ns)->encode(rc, 0, nc) != 0;
+    ctx_ps_flags = ((ctx_ps_flags << 1) + (u64)was_N) & 0xffff;
+    u64 flag = m_ps_flags.get(ctx_ps_flags, t_ps_flags)->encode(rc, 0, nc);
+    ctx_ps_flags = ((ctx_ps_flags << 3) + flag) & 0xffff;
+    if (flag < 4) {
+      u64 nb = m_ps_nobytes.get(ctx_ps_flags, t_ps_nobytes)->encode(rc, 0, nc) + 1, dif;
+      if (nb == 1) {
+        u64 hi = m_nibbles.get((1ull << 24) + flag, t_nibbles)->encode(rc, 0, nc);
+        u64 lo = m_nibbles.get((2ull << 24) + flag * 256 + hi, t_nibbles)->encode(rc, 0, nc);
+        dif = (hi << 4) + lo;
+      } else {
+        u64 hi_byte = m_bytes.get(flag * 65536 + nb * 256 + nb, t_bytes)->encode(rc, 0, nc);
+        dif = hi_byte << (nb * 8 - 8);
+        for (int i = 0; i < (int)nb - 1; ++i)
+          dif += (u64)m_bytes.get((flag << 24) + (nb << 16) + (hi_byte << 8) + (u64)i, t_bytes)->encode(rc, 0, nc) << (i * 8);
+      }
+      u64 k = pmer_prev.aligned_dir() + 1;
+      for (u64 j = 0; j <= dif; ++k)
+        if (sh->siv.test(k) == flag) ++j;
+      --k;
+      for (u32 i = 0; i < sh->kl.pmer; ++i) { pmer.insert_front(k & 3); k >>= 2; }
+    } else if (pmer_prev.full())
+      pmer = pmer_prev;
+    else {
+      for (u32 i = 0; i < sh->kl.pmer; ++i) pmer.insert(0);
+      pmer_prev = pmer;
+    }
+    ctx_letters = ~0ull;
+    for (u32 i = 0; i < sh->kl.pmer; ++i) {
+      u8 sym = (u8)pmer.symbol(i);
+      p[i] = alpha(sym);
+      if (was_N && sym == 3 && m_Ns.get((u64)i + 1, t_Ns)->encode(rc, 0, nc)) { p[i] = 'N'; sym = 4; }
+      ctx_letters = (ctx_letters << 4) + sym;
+      if (sym == 4) { sym = 3; N_run++; } else N_run = 0;
+      smer.insert(sym); bmer.insert(sym);
+      pmer_u.insert(sym); smer_u.insert(sym); bmer_u.insert(sym);
+    }
+    pmer_prev = pmer;
+    push_p(pmer.aligned_dir());
+    push_p(pmer.aligned_rc());
+  }
+
+  void suffix(u8 *p, u32 size, bool original_order, u32 start_pos = 0, bool reversed_pe = false) {  // compress_suffix, dna.cpp:674-877; decompress_suffix :1139-1345
     u32 counts[4] = {0, 0, 0, 0};
     u64 ctx_r_sym = 0;
     const KLen &kl = sh->kl;
     for (u32 i = start_pos ? start_pos : original_order ? kl.prefix : kl.pmer; i < size; ++i) {
-      u8 sym = (u8)dna_code(p[i]);
-      u64 sym_k = sym == 4 ? 0 : sym;
+      u8 sym = rc.dec ? 0 : (u8)dna_code(p[i]);
       pmer.insert_zero(); smer.insert_zero(); bmer.insert_zero();
       pmer_u.insert_zero(); smer_u.insert_zero(); bmer_u.insert_zero();
       u32 level = find_counts(counts);
@@ -993,13 +1075,16 @@ struct Worker {
         if (!reversed_pe) ctx_codes(lev, kl, counts, s_letters, i, level, cor_zone, ctx_r_sym, size);
         else ctx_codes(lev, kl, counts, s_letters, size - i - 1, level, cor_zone, ctx_r_sym, ~0u);  // dna.cpp:750-752
         Model *m = find_leveled(m_codes, lev, 7, t_codes, avg_code, CODE_THR);
-        u8 r_sym = rank(counts, sym);
-        m->encode(rc, r_sym, &sh->cnt.coded);
+        u8 r_sym = rc.dec ? 0 : rank(counts, sym);
+        r_sym = (u8)m->encode(rc, r_sym, &sh->cnt.coded);
+        if (rc.dec) sym = un_rank(counts, r_sym);
         ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0)) & 0xff;  // update_ctx_r_sym, dna.cpp:664-671
       } else {
-        code_letter(i, sym, size);
+        sym = code_letter(i, sym, size);
         ctx_r_sym = (ctx_r_sym << 1) & 0xff;
       }
+      if (rc.dec) p[i] = alpha(sym);
+      u64 sym_k = sym == 4 ? 0 : sym;
       ctx_letters = (ctx_letters << 4) + sym;
       if (sym == 4) ++N_run; else N_run = 0;
       pmer.replace_last(sym_k); smer.replace_last(sym_k); bmer.replace_last(sym_k);
@@ -1045,21 +1130,28 @@ struct Worker {
     }
   }
 
-  void compress_read(const u8 *p, u32 size, bool original_order, bool first_of_pair = true) {  // CompressDirect/Sorted, dna.cpp:1517-1556,1716-1754
+  // CompressDirect/Sorted, dna.cpp:1517-1556,1716-1754; on a decoding coder DecompressSE, dna.cpp:1883-1928 (p is written)
+  bool compress_read(u8 *p, u32 size, bool original_order, bool first_of_pair = true) {
     ctx_letters = 0;
     if (first_of_pair) {
-      bool same = read_prev.size() == size && (size == 0 || !memcmp(read_prev.data(), p, size));
-      m_flags.get(ctx_flags, t_flags)->encode(rc, same, &sh->cnt.coded);
+      bool same = !rc.dec && read_prev.size() == size && (size == 0 || !memcmp(read_prev.data(), p, size));
+      same = m_flags.get(ctx_flags, t_flags)->encode(rc, same, &sh->cnt.coded) != 0;
       ctx_flags = ((ctx_flags << 1) + (u64)same) & 0xff;
-      if (same) return;
+      if (same) {
+        if (rc.dec) memcpy(p, read_prev.data(), std::min<size_t>(size, read_prev.size()));
+        return true;
+      }
     }
     pmer.reset(); smer.reset(); bmer.reset();
     pmer_u.reset(); smer_u.reset(); bmer_u.reset();
     cor_pos = 0; N_run = 0;
-    if (original_order) prefix_direct(p); else prefix_sorted(p);
+    if (original_order) prefix_direct(p);
+    else if (rc.dec) prefix_sorted_dec(p);
+    else prefix_sorted(p);
     suffix(p, size, original_order);
     if (first_of_pair) read_prev.assign(p, p + size);
     update_s_letters(p, size);
+    return false;
   }
 
   // ---- paired-end (dna.cpp:880-1136,1559-1638,1757-1880)
@@ -1135,17 +1227,21 @@ struct Worker {
       pmer_u.insert(c); bmer_u.insert(c); smer_u.insert(c);
     }
   }
-  void compress_with_minim(const u8 *p, u32 size, u32 mpos) {  // CompressDirectWithMinim, dna.cpp:1559-1638
+  static u8 rc_alpha(u8 c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }  // utils.h:103-114
+  // CompressDirectWithMinim, dna.cpp:1559-1638; decoding: DecompressDirectWithMinim, :1641-1713 (anchor = minim b-mer)
+  void compress_with_minim(u8 *p, u32 size, u32 mpos, u64 minim = 0) {
     const u32 k = sh->kl.bmer;
+    if (rc.dec)
+      for (u32 i = 0; i < k; ++i) p[mpos + i] = alpha((u32)((minim >> (2 * (k - 1 - i))) & 3));
     seed_kmers(p, (int)mpos, (int)(mpos + k));
     suffix(p, size, true, k + mpos);
-    std::vector<u8> rcp;
-    for (int i = (int)mpos + (int)k - 1; i >= 0; --i) {
-      u8 c = p[i];
-      rcp.push_back(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N');  // utils.h:103-114
-    }
+    std::vector<u8> rcp(mpos + k, 'A');
+    const int from = rc.dec ? (int)mpos : 0;   // the decoder only knows the anchor yet
+    for (int i = (int)mpos + (int)k - 1, j = 0; i >= from; --i, ++j) rcp[j] = rc_alpha(p[i]);
     seed_kmers(rcp.data(), 0, (int)k);
     suffix(rcp.data(), (u32)rcp.size(), true, k, true);
+    if (rc.dec)
+      for (int i = (int)mpos - 1, j = (int)k; i >= 0; --i, ++j) p[i] = rc_alpha(rcp[j]);
     update_s_letters(p, size);
   }
   void pe_push(u64 key, u64 value, u64 weight) {  // my_pe_mers_to_add + ht_pe_mers_local->insert, dna.cpp:1090-1135
@@ -1171,7 +1267,33 @@ struct Worker {
     pe_push(m22, m11, 3); pe_push(m22, m13, 4);
     pe_push(m23, m11, 4); pe_push(m23, m13, 2);
   }
-  void compress_pair(const u8 *p1, u32 size1, const u8 *p2, u32 size2, bool original_order) {  // CompressPE, dna.cpp:1790-1880
+  void decompress_pair(u8 *p1, u32 size1, u8 *p2, u32 size2, bool original_order) {  // DecompressPE, dna.cpp:1931-2044
+    u64 *nc = &sh->cnt.coded;
+    compress_read(p1, size1, original_order, true);
+    bool found = find_minim_cand(p1, size1);
+    bool direct = !found;
+    u32 mid = 0, mpos = 0;
+    if (found) {
+      mid = m_minim_id.encode(rc, 0, nc);
+      if (mid == 15) direct = true;
+      else {
+        mpos = m_minim_pos.get((u64)mid, t_minim_pos)->encode(rc, 0, nc);
+        if (mpos == 254) {
+          mpos = m_minim_pos.get((u64)mid + 0x100, t_minim_pos)->encode(rc, 0, nc) << 8;
+          mpos += m_minim_pos.get((u64)mid + 0x200, t_minim_pos)->encode(rc, 0, nc);
+        } else if (mpos == 255) {
+          mpos = m_minim_pos.get((u64)mid + 0x300, t_minim_pos)->encode(rc, 0, nc) << 16;
+          mpos += m_minim_pos.get((u64)mid + 0x400, t_minim_pos)->encode(rc, 0, nc) << 8;
+          mpos += m_minim_pos.get((u64)mid + 0x500, t_minim_pos)->encode(rc, 0, nc);
+        }
+      }
+    }
+    if (direct) compress_read(p2, size2, true, false);
+    else compress_with_minim(p2, size2, mpos, v_minim_top[mid] & sh->pe.value_mask);
+    append_pe_mers3(p1, size1, p2, size2);
+  }
+  void compress_pair(u8 *p1, u32 size1, u8 *p2, u32 size2, bool original_order) {  // CompressPE, dna.cpp:1790-1880
+    if (rc.dec) { decompress_pair(p1, size1, p2, size2, original_order); return; }
     u64 *nc = &sh->cnt.coded;
     compress_read(p1, size1, original_order, true);
     bool found = find_minim_cand(p1, size1);
@@ -1271,7 +1393,10 @@ fqo_codec *fqo_create(const uint8_t *h) {
 
 void fqo_destroy(fqo_codec *c) { delete c; }
 
-int fqo_encode_block(fqo_codec *c, const uint8_t *bases, const uint64_t *off, uint32_t n_reads, uint32_t generation) {
+// one reads block through all T workers (application.cpp:610-669 / decoder mirror :874-917); when
+// dec_streams is given the workers decode from them and write the reads into `bases`
+static int run_block(fqo_codec *c, u8 *bases, const uint64_t *off, uint32_t n_reads, uint32_t generation,
+                     const uint8_t *const *dec_streams, const uint64_t *dec_lens) {
   Shared &s = c->sh;
   const u64 T = s.T;
   // PartitionForWorkers, reads_block.h:197-214
@@ -1292,7 +1417,8 @@ int fqo_encode_block(fqo_codec *c, const uint8_t *bases, const uint64_t *off, ui
     Worker &w = *c->w[t];
     w.read_prev.clear();
     w.rc.out.clear();
-    w.rc.start();
+    w.rc.dec = dec_streams != nullptr;
+    if (dec_streams) w.rc.start_dec(dec_streams[t], dec_lens[t]); else w.rc.start();
     cursor[t] = first[t];
   }
   for (u64 seg = 0; seg <= S; ++seg) {
@@ -1319,8 +1445,18 @@ int fqo_encode_block(fqo_codec *c, const uint8_t *bases, const uint64_t *off, ui
     for (u64 t = 0; t < T; ++t) c->w[t]->insert_phase();
     for (u64 t = 0; t < T; ++t) c->w[t]->clear_phase();
   }
-  for (u64 t = 0; t < T; ++t) c->w[t]->rc.end();  // application.cpp:664-665
+  if (!dec_streams)
+    for (u64 t = 0; t < T; ++t) c->w[t]->rc.end();  // application.cpp:664-665
   return 0;
+}
+
+int fqo_encode_block(fqo_codec *c, const uint8_t *bases, const uint64_t *off, uint32_t n_reads, uint32_t generation) {
+  return run_block(c, const_cast<u8 *>(bases), off, n_reads, generation, nullptr, nullptr);
+}
+
+int fqo_decode_block(fqo_codec *c, const uint8_t *const *streams, const uint64_t *lens, const uint64_t *off, uint32_t n_reads,
+                     uint32_t generation, uint8_t *bases_out) {
+  return run_block(c, bases_out, off, n_reads, generation, streams, lens);
 }
 
 const uint8_t *fqo_stream(fqo_codec *c, uint32_t worker, uint64_t *len) {

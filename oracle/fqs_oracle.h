@@ -37,6 +37,13 @@ int fqo_encode_block(fqo_codec *, const uint8_t *bases, const uint64_t *read_off
                      uint32_t n_reads, uint32_t generation);
 const uint8_t *fqo_stream(fqo_codec *, uint32_t worker, uint64_t *len);
 
+/* Decode one reads block (reference decoder workers, application.cpp:874-917; DecompressSE/PE,
+ * dna.cpp:1883-2044): streams[w]/lens[w] = worker w's DNA stream, read_off = n_reads+1 offsets of
+ * the reads inside bases_out (the read lengths come from the meta stream).  A codec object is
+ * used either for encoding or for decoding, never both. */
+int fqo_decode_block(fqo_codec *, const uint8_t *const *streams, const uint64_t *lens, const uint64_t *read_off,
+                     uint32_t n_reads, uint32_t generation, uint8_t *bases_out);
+
 /* Counters accumulated over all encode calls (SURVEY.md §8d accounting):
  * [0] global k-mer table probes (cluster scans)   [1] slots scanned by them
  * [2] global inserts  [3] siv word ops (incl. prefix scan words)

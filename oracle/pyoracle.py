@@ -36,6 +36,8 @@ def lib():
         _lib.fqo_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         _lib.fqo_stream.restype = C.POINTER(C.c_uint8)
         _lib.fqo_stream.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+        _lib.fqo_decode_block.restype = C.c_int
+        _lib.fqo_decode_block.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib.fqo_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _lib.fqo_kat_mt19937.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         _lib.fqo_kat_cinc.argtypes = [C.c_uint32] * 4 + [C.c_void_p] * 3
@@ -64,6 +66,17 @@ class OracleCodec:
         for w in range(self.T):
             p = lib().fqo_stream(self._h, w, C.byref(n))
             out.append(bytes(C.cast(p, C.POINTER(C.c_uint8 * n.value)).contents) if n.value else b"")
+        return out
+
+    def decode_block(self, streams, read_off: np.ndarray, generation: int) -> np.ndarray:
+        """Inverse of encode_block: T streams + read offsets -> concatenated base bytes."""
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        arr = (C.c_char_p * self.T)(*[bytes(x) for x in streams])
+        lens = np.array([len(x) for x in streams], dtype=np.uint64)
+        out = np.zeros(int(read_off[-1]), dtype=np.uint8)
+        rc = lib().fqo_decode_block(self._h, arr, lens.ctypes.data, read_off.ctypes.data, len(read_off) - 1, generation, out.ctypes.data)
+        if rc:
+            raise RuntimeError("oracle decode failed")
         return out
 
     def counters(self):

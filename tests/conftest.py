@@ -129,3 +129,22 @@ def c7_records():
     from fqsqueezer_amd.synth import synth_mixed_lengths
     ids, seqs, quals = synth_mixed_lengths()
     return hp.Records(ids, seqs, quals)
+
+
+def check_decode_fqs(make_codec, rec, fqs_name):
+    """Decode every block of a reference .fqs (its DNA streams + the known read lengths) and compare with the input."""
+    import numpy as np
+    from fqsqueezer_amd import hostpipe as hp
+    header, blocks = hp.parse_fqs(open(os.path.join(GOLD, fqs_name), "rb").read())
+    paired = header[5] >= 2
+    if paired:
+        mode = "pe_sorted" if header[5] == 3 else "pe_original"
+        blks = hp.form_blocks_pe(rec[0], rec[1], mode)
+    else:
+        blks = hp.form_blocks(rec, "se_sorted" if header[5] == 1 else "se_original")
+    codec = make_codec(header)
+    for g, (idx, ref) in enumerate(zip(blks, blocks)):
+        bases, off = hp.block_arrays_pe(rec[0], rec[1], idx) if paired else hp.block_arrays(rec, idx)
+        out = codec.decode_block([ref.streams[w][hp.STREAM_DNA] for w in range(header[4])], off, g)
+        assert np.array_equal(np.frombuffer(bytes(out), dtype=np.uint8), np.asarray(bases)), f"{fqs_name}: block {g} decoded wrongly"
+    return codec

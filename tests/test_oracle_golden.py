@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import c1_records, c4_records, c5_records, c7_records, check_against_digest, check_against_fqs, check_against_fqs_pe
+from conftest import c1_records, c4_records, c5_records, c7_records, check_against_digest, check_against_fqs, check_against_fqs_pe, check_decode_fqs
 from oracle.pyoracle import OracleCodec, lib
 
 
@@ -40,6 +40,12 @@ def test_oracle_matches_reference_150bp():
 @pytest.mark.parametrize("t", [1, 8, 64])
 def test_oracle_matches_reference_1M(t):
     check_against_digest(OracleCodec, f"c2_1M_s_t{t}.json")
+
+
+@pytest.mark.parametrize("name,recs", [("c1_10k_o_t4.fqs", c1_records), ("c1_10k_s_t4.fqs", c1_records), ("c4_ragged_s_t3.fqs", c4_records),
+                                       ("c7_mixedlen_o_t3.fqs", c7_records), ("c5_pe4k_o_t4.fqs", c5_records), ("c5_pe4k_s_t4.fqs", c5_records)])
+def test_oracle_decodes_reference_streams(name, recs):
+    check_decode_fqs(OracleCodec, recs(), name)
 
 
 def test_mt19937_known_answer():
