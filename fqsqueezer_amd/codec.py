@@ -42,6 +42,8 @@ def _load(path: str):
     lib.fqsx_dna_encode_block_dev.restype = C.c_int
     lib.fqsx_dna_encode_block_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                               C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.fqsx_dna_decode_block.restype = C.c_int
+    lib.fqsx_dna_decode_block.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     lib.fqsx_dna_stats.restype = C.c_int
     lib.fqsx_dna_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.fqsx_dna_set_profiling.argtypes = [C.c_void_p, C.c_int]
@@ -103,6 +105,18 @@ class DnaCodec:
         if collect:
             return self._collect()
         return sum(self._lens[w] for w in range(self.T))
+
+    def decode_block(self, streams, read_off: np.ndarray, generation: int) -> np.ndarray:
+        """Inverse of encode_block: the T DNA streams of a block + read offsets -> concatenated base bytes."""
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        arr = (C.c_char_p * self.T)(*[bytes(x) for x in streams])
+        lens = np.array([len(x) for x in streams], dtype=np.uint64)
+        out = np.zeros(max(1, int(read_off[-1])), dtype=np.uint8)
+        rc = self._lib.fqsx_dna_decode_block(self._h, arr, lens.ctypes.data, read_off.ctypes.data, len(read_off) - 1,
+                                             generation, out.ctypes.data)
+        if rc:
+            raise FqsxError(f"fqsx_dna_decode_block: {rc}: {self._lib.fqsx_last_error().decode()}")
+        return out[:int(read_off[-1])]
 
     def stats(self) -> dict:
         a = (C.c_uint64 * 48)()

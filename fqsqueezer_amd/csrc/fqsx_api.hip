@@ -37,6 +37,10 @@ FQ_KERNEL64 void k_encode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
   FQ_SHARED WgShared sm;
   encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
 }
+FQ_KERNEL64 void k_decode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
+  FQ_SHARED WgShared sm;
+  encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg, true);
+}
 FQ_KERNEL64 void k_insert_phase(DevCfg cfg) {  // grid = 3 * T: (owner, mailbox kind)
   FQ_SHARED WgShared sm;
   insert_phase_body(cfg, &sm, FQ_BLOCK / 3, FQ_BLOCK % 3);
@@ -193,7 +197,7 @@ struct fqsx_dna {
   u32 *d_demand;
   u64 *d_lens;
   u8 *d_compact;
-  u64 compact_cap;
+  u64 compact_cap, din_cap, dout_cap;
   std::vector<u32> h_demand, h_filled;
   std::vector<u8> h_out;
   std::vector<u64> h_lens;
@@ -415,8 +419,11 @@ int mail_alloc(fqsx_dna *c, u32 kind, u32 cap) {
   return FQSX_OK;
 }
 
+// decode: dec_streams/dec_lens (host) are the T input streams, bases_out (host) receives the block
 int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u64 *h_off, u32 n_reads, u32 generation,
-                      const u8 **streams, u64 *lens) {
+                      const u8 **streams, u64 *lens, const u8 *const *dec_streams = nullptr, const u64 *dec_lens = nullptr,
+                      u8 *bases_out = nullptr) {
+  const bool decode = dec_streams != nullptr;
   const u32 T = c->T;
   DevCfg &cfg = c->cfg;
   // ---- schedule (PartitionForWorkers reads_block.h:197-214; calc_no_synchronizations application.h:85-92)
@@ -510,9 +517,41 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
   }
   cfg.bases = d_bases;
   cfg.read_off = d_off;
+  if (decode) {  // upload the streams, size the output block and the per-worker code lines
+    std::vector<u64> doff(T + 1, 0);
+    for (u32 t = 0; t < T; ++t) doff[t + 1] = doff[t] + dec_lens[t];
+    u64 max_len = 0;
+    for (u32 i = 0; i < n_reads; ++i) max_len = std::max(max_len, h_off[i + 1] - h_off[i]);
+    const u64 need_in = doff[T] + 64, need_out = h_off[n_reads] + 64, need_sc = max_len + 64;
+    if (need_in > c->din_cap) {
+      dfree(c, (void *)cfg.din);
+      if ((rc = dalloc(c, &p, need_in + need_in / 4, false))) return rc;
+      cfg.din = (const u8 *)p; c->din_cap = need_in + need_in / 4;
+    }
+    if (need_out > c->dout_cap) {
+      dfree(c, cfg.dout);
+      if ((rc = dalloc(c, &p, need_out + need_out / 4, false))) return rc;
+      cfg.dout = (u8 *)p; c->dout_cap = need_out + need_out / 4;
+    }
+    if (need_sc > cfg.dcap) {
+      dfree(c, cfg.dscratch);
+      if ((rc = dalloc(c, &p, (u64)T * 2 * (need_sc + need_sc / 4), false))) return rc;
+      cfg.dscratch = (u8 *)p; cfg.dcap = need_sc + need_sc / 4;
+    }
+    if (!cfg.din_off && (rc = dalloc(c, &p, ((u64)T + 1) * sizeof(u64), false))) return rc;
+    if (!cfg.din_off) cfg.din_off = (const u64 *)p;
+    std::vector<u8> flat(doff[T] ? doff[T] : 1);
+    for (u32 t = 0; t < T; ++t) memcpy(flat.data() + doff[t], dec_streams[t], dec_lens[t]);
+    if ((rc = h2d(c, (void *)cfg.din, flat.data(), doff[T]))) return rc;
+    if ((rc = h2d(c, (void *)cfg.din_off, doff.data(), (T + 1) * sizeof(u64)))) return rc;
+#ifndef FQSX_EMU
+    HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  }
 
   for (u32 seg = 0; seg <= (u32)S; ++seg) {
-    LAUNCH(c, 0, k_encode_segment, T, 64, cfg, n_reads, (u32)S, seg);
+    if (decode) LAUNCH(c, 0, k_decode_segment, T, 64, cfg, n_reads, (u32)S, seg);
+    else LAUNCH(c, 0, k_encode_segment, T, 64, cfg, n_reads, (u32)S, seg);
     // size the global tables for this phase's inserts (exact per-owner demand)
     for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_count, T * cfg.mail[k].n_tiles, 64, cfg, k);
     for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_scan, T, 64, cfg, k);
@@ -548,6 +587,15 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
     if ((rc = dzero(c, cfg.l_b.slots, need_lb * T * sizeof(u64)))) return rc;
     if ((rc = dzero(c, cfg.l_s.slots, need_ls * T * sizeof(u64)))) return rc;
     if ((rc = dzero(c, cfg.l_s.filled, 2 * T * sizeof(u32)))) return rc;  // l_s.filled and l_b.filled are adjacent
+  }
+  if (decode) {
+    u32 derr = 0;
+    if ((rc = d2h_sync(c, &derr, cfg.err, sizeof(u32)))) return rc;
+    if (derr) {
+      g_err = "device error " + std::to_string(derr) + " while decoding block " + std::to_string(generation);
+      return FQSX_E_DEVICE;
+    }
+    return d2h_sync(c, bases_out, cfg.dout, h_off[n_reads]);
   }
   LAUNCH(c, 2, k_finish_block, T, 64, cfg, c->d_lens);
   // ---- results
@@ -733,6 +781,7 @@ int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) {
   c->d_off = nullptr;
   c->d_compact = nullptr;
   c->compact_cap = 0;
+  c->din_cap = c->dout_cap = 0;
 #ifndef FQSX_EMU
   HIPCHK(hipStreamCreate(&c->stream));
   HIPCHK(hipEventCreate(&c->ev0));
@@ -796,6 +845,25 @@ int fqsx_dna_encode_block(fqsx_dna *c, const uint8_t *bases, const uint64_t *off
   if ((rc = h2d(c, c->d_bases, bases, off[n_reads]))) return rc;
   if ((rc = h2d(c, c->d_off, off, no))) return rc;
   return encode_block_impl(c, c->d_bases, c->d_off, off, n_reads, generation, streams, lens);
+}
+
+int fqsx_dna_decode_block(fqsx_dna *c, const uint8_t *const *streams, const uint64_t *lens, const uint64_t *off, uint32_t n_reads,
+                          uint32_t generation, uint8_t *bases_out) {
+  if (!c || !streams || !lens || !off || !bases_out) { g_err = "null argument"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  int rc;
+  void *p = nullptr;
+  u64 no = ((u64)n_reads + 1) * sizeof(u64);
+  if (no > c->dev_off_cap) {
+    dfree(c, c->d_off);
+    if ((rc = dalloc(c, &p, no + no / 4, false))) return rc;
+    c->d_off = (u64 *)p;
+    c->dev_off_cap = no + no / 4;
+  }
+  if ((rc = h2d(c, c->d_off, off, no))) return rc;
+  return encode_block_impl(c, nullptr, c->d_off, off, n_reads, generation, nullptr, nullptr, streams, lens, bases_out);
 }
 
 int fqsx_dna_stats(fqsx_dna *c, uint64_t out[48]) {

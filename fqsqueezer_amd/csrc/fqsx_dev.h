@@ -66,6 +66,8 @@ struct Wk {
   bool repm_gate;                       // siv avg_filling_factor() >= 7 (constant within a segment)
   u32 mn[3];                            // entries appended to this worker's p/s/b mailbox lists
   u32 pe_n;                             // paired-end triples pushed in this launch
+  const u8 *din;                        // decoder input stream of this worker
+  u64 din_len, din_pos, din_buffer;
   u32 la[3];                            // list entries already applied to the local tables (b, s)
   u32 pq_n[2];                          // valid entries of the LDS mirror (b, s); ~0u = mirror overflowed
   bool lq_applied;                      // a local-table flush happened since the last stage P (its local probes are stale)
@@ -1305,6 +1307,7 @@ FQ_DEV void prefix_sorted(Wk &w, const u8 *p, u32 size) {  // compress_prefix_so
       if (ch == 'T' || ch == 'N') sm_encode(w, sb + SM_OFF_NS + (i + 1) * (SM_NS_N + 1), SM_NS_N, 1u << 12, ch == 'N' ? 1u : 0u);
     }
   ws->pmer_prev_dir = w.pm.dir;
+  ws->pmer_prev_rc = w.pm.rc;
   ws->pmer_prev_cur = w.pm.cur;
   push_p_both(w);
 }
@@ -1788,12 +1791,13 @@ FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev
 }
 
 #include "fqsx_pe.h"
+#include "fqsx_dec.h"
 
 // ---------------------------------------------------------------------------------------
 // kernel bodies
 
 // worker `tid` codes its reads of segment `seg` (application.cpp:610-656)
-FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg) {
+FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, bool decode = false) {
   Wk w;
   w.cfg = &cfg;
   w.sm = sm;
@@ -1814,6 +1818,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
     ws->rc_low = 0;
     ws->rc_range = 0xff00000000000000ULL;
     ws->out_len = 0;
+    ws->dec_pos = ~0ull;   // decoder: stream not started yet
   }
   const bool paired = cfg.mode >= 2;
   u64 stop;
@@ -1852,7 +1857,22 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
 
   u64 cur = ws->cursor;
   w.pe_n = 0;
-  if (!paired)
+  if (decode) {
+    w.din = cfg.din + cfg.din_off[tid];
+    w.din_len = cfg.din_off[tid + 1] - cfg.din_off[tid];
+    if (ws->dec_pos == ~0ull) rcd_start(w);
+    else { w.din_pos = ws->dec_pos; w.din_buffer = ws->dec_buffer; }
+    u8 *codes = cfg.dscratch + (u64)tid * 2 * cfg.dcap, *rcodes = codes + cfg.dcap;
+    for (u64 i = cur; i < stop && !w.err; i += paired ? 2 : 1) {
+      const u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
+      const u8 *prev_out = nullptr;
+      if (i > first) prev_out = cfg.dout + cfg.read_off[i - (paired ? 2 : 1)];
+      if (!paired) read_dec(w, codes, cfg.dout + o0, (u32)(o1 - o0), prev_out, true);
+      else if (i + 1 < stop) pair_dec(w, codes, rcodes, cfg.dout + o0, (u32)(o1 - o0), cfg.dout + o1, (u32)(cfg.read_off[i + 2] - o1), prev_out);
+    }
+    ws->dec_pos = w.din_pos;
+    ws->dec_buffer = w.din_buffer;
+  } else if (!paired)
     for (u64 i = cur; i < stop && !w.err; ++i) {
       u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
       const u8 *prev = nullptr;

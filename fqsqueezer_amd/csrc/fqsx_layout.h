@@ -96,12 +96,13 @@ struct WState {
   double avg_code, avg_letters;        // dna.h:34,37
   u64 ctx_flags, ctx_ps_flags;         // dna.h:84,87
   u64 s_letters[4];                    // dna.h:119
-  u64 pmer_prev_dir;                   // pmer_can_prev (dna.h:166); cur is 0 or pmer_len
+  u64 pmer_prev_dir, pmer_prev_rc;     // pmer_can_prev (dna.h:166); cur is 0 or pmer_len
   u32 pmer_prev_cur;
   u32 cursor;                          // next read of the block this worker codes
   u64 hidden_updates;                  // no_pmer_hidden_updates, dna.h:43
   u64 rc_low, rc_range;                // CRangeEncoder, sub_rc.h:44-45
   u64 out_len;
+  u64 dec_buffer, dec_pos;             // CRangeDecoder (sub_rc.h:154-157) when the codec decodes
   u32 mt_idx[4];                       // cinc_b, cinc_s, cinc_lb, cinc_ls (dna.h:113-116)
   u32 mt[4][624];
   u64 stat[48];                        // probe/byte accounting, see ST_*; [16..23] in-kernel section times (10 ns ticks)
@@ -153,6 +154,12 @@ struct DevCfg {
   const u64 *read_off;         // n_reads+1
   u8 *out;                     // [T][out_cap] DNA streams of the block
   u64 out_cap;
+  // decoding (k_decode_segment): input streams, output block, per-worker code lines
+  const u8 *din;               // the T DNA streams of the block, concatenated
+  const u64 *din_off;          // [T+1]
+  u8 *dout;                    // decoded block (ASCII), reads at read_off[]
+  u8 *dscratch;                // [T][2][dcap] 0..4 codes of the read being decoded (+ reverse-complement line)
+  u64 dcap;
   u32 *err;                    // device error word (0 = ok)
 };
 
@@ -164,4 +171,5 @@ enum {
   FQSX_ERR_MAIL_FULL = 5,
   FQSX_ERR_PE_FULL = 6,
   FQSX_ERR_PE_READ_TOO_LONG = 7,
+  FQSX_ERR_DECODE = 8,
 };

@@ -64,6 +64,14 @@ int fqsx_dna_encode_block_dev(fqsx_dna *, const uint8_t *d_bases, const uint64_t
                               const uint64_t *h_read_off, uint32_t n_reads, uint32_t generation,
                               const uint8_t **streams, uint64_t *lens);
 
+/* Decode one reads block: inverse of fqsx_dna_encode_block (replaces one generation of the reference's
+ * decoder workers, fqs/application.cpp:874-917 with CDNACompressor::DecompressSE / DecompressPE,
+ * fqs/dna.h:277-278).  streams[w]/lens[w] = worker w's DNA stream of the block (host memory), read_off =
+ * n_reads+1 offsets of the reads inside bases_out (the read lengths come from the meta stream).  A codec
+ * instance is used either for encoding or for decoding a file, never both. */
+int fqsx_dna_decode_block(fqsx_dna *, const uint8_t *const *streams, const uint64_t *lens, const uint64_t *read_off,
+                          uint32_t n_reads, uint32_t generation, uint8_t *bases_out);
+
 /* Accounting counters summed over workers since creation:
  * [0] global probes [1] global slots read [2] local probes [3] local slots read
  * [4] global inserts [5] slots read by them [6] siv words touched [7] context slots read

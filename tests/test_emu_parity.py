@@ -4,7 +4,7 @@ in the GPU-less container; the 64-lane paths are covered by tests/test_gpu_parit
 import numpy as np
 import pytest
 
-from conftest import EMU_LIB, c1_records, c4_records, c5_records, c7_records, check_against_digest, check_against_fqs, check_against_fqs_pe
+from conftest import EMU_LIB, c1_records, c4_records, c5_records, c7_records, check_against_digest, check_against_fqs, check_against_fqs_pe, check_decode_fqs
 from fqsqueezer_amd import hostpipe as hp
 from fqsqueezer_amd.codec import DnaCodec
 from oracle.pyoracle import OracleCodec
@@ -43,6 +43,13 @@ def test_emu_matches_reference_short_and_long_reads(name):
 
 def test_emu_matches_reference_large_k_geometry():
     check_against_digest(emu, "c6_20k_gs300_s_t2.json")
+
+
+@pytest.mark.parametrize("name,recs", [("c1_10k_o_t4.fqs", c1_records), ("c1_10k_s_t4.fqs", c1_records), ("c4_ragged_s_t3.fqs", c4_records),
+                                       ("c7_mixedlen_o_t3.fqs", c7_records), ("c7_mixedlen_s_t3.fqs", c7_records),
+                                       ("c5_pe4k_o_t4.fqs", c5_records), ("c5_pe4k_s_t4.fqs", c5_records)])
+def test_emu_decodes_reference_streams(name, recs):
+    check_decode_fqs(emu, recs(), name)
 
 
 def test_emu_matches_reference_150bp():

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, c1_records, c4_records, c5_records, c7_records, check_against_digest, check_against_fqs, check_against_fqs_pe
+from conftest import GOLD, c1_records, c4_records, c5_records, c7_records, check_against_digest, check_against_fqs, check_against_fqs_pe, check_decode_fqs
 from fqsqueezer_amd import hostpipe as hp
 
 pytestmark = pytest.mark.gpu
@@ -53,6 +53,13 @@ def test_hip_matches_reference_large_k_geometry():
     check_against_digest(gpu, "c6_20k_gs300_s_t2.json")
 
 
+@pytest.mark.parametrize("name,recs", [("c1_10k_o_t4.fqs", c1_records), ("c1_10k_s_t4.fqs", c1_records), ("c4_ragged_s_t3.fqs", c4_records),
+                                       ("c7_mixedlen_o_t3.fqs", c7_records), ("c7_mixedlen_s_t3.fqs", c7_records),
+                                       ("c5_pe4k_o_t4.fqs", c5_records), ("c5_pe4k_s_t4.fqs", c5_records)])
+def test_hip_decodes_reference_streams(name, recs):
+    check_decode_fqs(gpu, recs(), name)
+
+
 def test_hip_matches_reference_150bp():
     check_against_digest(gpu, "c3_50k150_s_t8.json")
 
@@ -74,6 +81,19 @@ def test_hip_matches_oracle_many_workers_and_tiny_blocks():
         for g, idx in enumerate(blks):
             bases, off = hp.block_arrays(rec, np.asarray(idx))
             assert a.encode_block(bases, off, g) == b.encode_block(bases, off, g)
+
+
+def test_gpu_encode_decode_round_trip_many_workers():
+    """encode -> decode entirely on the GPU at T=64 (size-independent property: the block comes back)."""
+    from fqsqueezer_amd.synth import synth_reads
+    reads = synth_reads(60000, 100, 600000, 11)
+    rec = hp.Records([b"@r%d" % i for i in range(len(reads))], reads, reads)
+    header = hp.make_header(64, "se_sorted", 1)
+    enc, dec = gpu(header), gpu(header)
+    for g, idx in enumerate(hp.form_blocks(rec, "se_sorted")):
+        bases, off = hp.block_arrays(rec, idx)
+        streams = enc.encode_block(bases, off, g)
+        assert np.array_equal(dec.decode_block(streams, off, g), np.asarray(bases)), f"block {g} did not round-trip"
 
 
 def test_device_and_host_entry_points_agree():
