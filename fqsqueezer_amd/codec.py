@@ -48,6 +48,9 @@ def _load(path: str):
     lib.fqsx_dna_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.fqsx_dna_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.fqsx_dna_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.fqsx_qual_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.fqsx_qual_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.fqsx_qual_destroy.argtypes = [C.c_void_p]
     lib.fqsx_meta_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
     lib.fqsx_meta_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.fqsx_meta_destroy.argtypes = [C.c_void_p]
@@ -169,6 +172,40 @@ class MetaCodec:
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._lib.fqsx_meta_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class QualCodec:
+    """Quality-stream encoder on the GPU (fqsx_qual_*)."""
+
+    def __init__(self, header: bytes, device: int = 0, lib_path: Optional[str] = None):
+        self._lib = load_library(lib_path)
+        self.T = header[4]
+        self._h = C.c_void_p()
+        rc = self._lib.fqsx_qual_create(bytes(header), device, C.byref(self._h))
+        if rc:
+            raise FqsxError(f"fqsx_qual_create: {rc}: {self._lib.fqsx_last_error().decode()}")
+        self._streams = (C.c_void_p * self.T)()
+        self._lens = (C.c_uint64 * self.T)()
+
+    def encode_block(self, quals: np.ndarray, read_off: np.ndarray) -> List[bytes]:
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        rc = self._lib.fqsx_qual_encode_block(self._h, quals.ctypes.data, read_off.ctypes.data, len(read_off) - 1,
+                                              self._streams, self._lens)
+        if rc:
+            raise FqsxError(f"fqsx_qual_encode_block: {rc}: {self._lib.fqsx_last_error().decode()}")
+        return [C.string_at(self._streams[w], self._lens[w]) if self._lens[w] else b"" for w in range(self.T)]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.fqsx_qual_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -12,6 +12,7 @@
 // with kernel boundaries in place of CBarrier.  Built with hipcc for gfx950; the FQSX_EMU
 // build (tests/emu only) runs the same kernels as plain loops for debugging without a GPU.
 #include "fqsx_dev.h"
+#include "fqsx_qual.h"
 #include "../../include/fqsx.h"
 
 #include <algorithm>
@@ -880,6 +881,200 @@ int fqsx_dna_set_profiling(fqsx_dna *c, int enable) {
 int fqsx_dna_kernel_times(fqsx_dna *c, double out[6]) {
   if (!c || !out) return FQSX_E_ARG;
   for (int i = 0; i < 3; ++i) { out[i] = c->k_ms[i]; out[3 + i] = (double)c->k_n[i]; }
+  return FQSX_OK;
+}
+
+}  // extern "C"
+
+// =======================================================================================
+// quality stream
+FQ_KERNEL64 void k_qual_encode(QualCfg cfg, u32 n_reads) {
+  FQ_SHARED u8 lds_q[4096];
+  qual_encode_body(cfg, lds_q, FQ_BLOCK, n_reads);
+}
+FQ_KERNEL void k_qual_rehash(const u64 *o, u64 ocap_mask, u64 *n, u64 ncap_mask, u32 T, u32 slot_u64) {
+  const u64 ocap = ocap_mask + 1, total = ocap * T;
+#ifndef FQSX_EMU
+  const u64 gstride = (u64)gridDim.x * blockDim.x;
+  for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gstride) {
+#else
+  for (u64 g = 0; g < total; ++g) {
+#endif
+    const u64 *src = o + g * slot_u64;
+    const u64 key = src[0];
+    if (key == ~0ull) continue;
+    const u32 w = (u32)(g / ocap);
+    u64 *b = n + (u64)w * (ncap_mask + 1) * slot_u64;
+    u64 h = q_hash(key) & ncap_mask;
+    for (;;) {
+      u64 *p = b + h * slot_u64;
+      if (p[0] == ~0ull && atomic_cas64(&p[0], ~0ull, key) == ~0ull) {
+        for (u32 i = 1; i < slot_u64; ++i) p[i] = src[i];
+        break;
+      }
+      h = (h + 1) & ncap_mask;
+    }
+  }
+}
+
+struct fqsx_qual {
+  QualCfg cfg;
+  u32 T;
+  int device;
+  u64 cap, out_cap, q_cap, off_cap;
+  u8 *d_q;
+  u64 *d_off;
+  fqsx_dna mem;   // allocation bookkeeping / stream (reuses the helpers above)
+  std::vector<u32> h_filled;
+  std::vector<u64> h_lens;
+  std::vector<u8> h_out;
+};
+
+extern "C" {
+
+void fqsx_qual_destroy(fqsx_qual *q) {
+  if (!q) return;
+  fqsx_dna *c = &q->mem;
+#ifndef FQSX_EMU
+  (void)hipSetDevice(q->device);
+  (void)hipStreamSynchronize(c->stream);
+#endif
+  std::vector<void *> a = c->allocs;
+  for (void *p : a) dfree(c, p);
+#ifndef FQSX_EMU
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+#endif
+  delete q;
+}
+
+int fqsx_qual_create(const uint8_t *h, int device, fqsx_qual **out) {
+  if (!h || !out || h[0] != 'K' || h[1] != 'C' || h[2] != 'S' || h[3] != 'D' || h[4] == 0 || h[6] > 3) {
+    g_err = "malformed header or quality_mode none";
+    return FQSX_E_ARG;
+  }
+#ifndef FQSX_EMU
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available (libfqsx has no CPU path)"; return FQSX_E_NO_DEVICE; }
+  if (device < 0 || device >= ndev) { g_err = "bad device ordinal"; return FQSX_E_ARG; }
+  HIPCHK(hipSetDevice(device));
+#endif
+  fqsx_qual *q = new fqsx_qual();
+  q->T = h[4];
+  q->device = device;
+  fqsx_dna *c = &q->mem;
+  c->T = q->T; c->device = device; c->profiling = false;
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamCreate(&c->stream));
+  HIPCHK(hipEventCreate(&c->ev0));
+  HIPCHK(hipEventCreate(&c->ev1));
+#endif
+  QualCfg &cfg = q->cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.T = q->T;
+  cfg.mode = h[6];
+  // Init + adjust_quality_map_*, quality.cpp:32-149
+  auto band = [&](int a, int b, u8 v) { for (int i = a; i < b; ++i) cfg.fwd[i] = v; };
+  const u32 thr = h[8];
+  if (cfg.mode == 0) { cfg.n_sym = 96; cfg.bits = 6; cfg.nctx = 2; for (int i = 0; i < 96; ++i) cfg.fwd[i] = (u8)i; }
+  else if (cfg.mode == 1) { cfg.n_sym = 8; cfg.bits = 4; cfg.nctx = 6; band(0, 2, 0); band(2, 10, 1); band(10, 20, 2); band(20, 25, 3); band(25, 30, 4); band(30, 35, 5); band(35, 40, 6); band(40, 96, 7); }
+  else if (cfg.mode == 2) { cfg.n_sym = 4; cfg.bits = 3; cfg.nctx = 9; band(0, 2, 0); band(2, 15, 1); band(15, 31, 2); band(31, 96, 3); }
+  else { cfg.n_sym = 2; cfg.bits = 2; cfg.nctx = 10; band(0, (int)std::min(thr, 96u), 0); band((int)std::min(thr, 96u), 96, 1); }
+  cfg.ctx_mask = (1ull << (cfg.bits * cfg.nctx)) - 1ull;
+  cfg.slot_u64 = 1 + (cfg.n_sym + 1 + 3) / 4;
+  q->cap = 1u << 12;
+  q->out_cap = q->q_cap = q->off_cap = 0;
+  q->d_q = nullptr; q->d_off = nullptr;
+  int rc;
+  void *p = nullptr;
+  auto fail = [&](int r) { fqsx_qual_destroy(q); return r; };
+  if ((rc = dalloc(c, &p, q->cap * q->T * cfg.slot_u64 * sizeof(u64), false))) return fail(rc);
+  cfg.tab = (u64 *)p;
+#ifndef FQSX_EMU
+  HIPCHK(hipMemsetAsync(cfg.tab, 0xff, q->cap * q->T * cfg.slot_u64 * sizeof(u64), c->stream));
+#else
+  memset(cfg.tab, 0xff, q->cap * q->T * cfg.slot_u64 * sizeof(u64));
+#endif
+  cfg.cap_mask = q->cap - 1;
+  if ((rc = dalloc(c, &p, q->T * sizeof(u32), true))) return fail(rc);
+  cfg.filled = (u32 *)p;
+  if ((rc = dalloc(c, &p, q->T * sizeof(u64), true))) return fail(rc);
+  cfg.lens = (u64 *)p;
+  if ((rc = dalloc(c, &p, 16, true))) return fail(rc);
+  cfg.err = (u32 *)p;
+  q->h_filled.assign(q->T, 0);
+  q->h_lens.assign(q->T, 0);
+  *out = q;
+  return FQSX_OK;
+}
+
+int fqsx_qual_encode_block(fqsx_qual *q, const uint8_t *quals, const uint64_t *off, uint32_t n_reads, const uint8_t **streams,
+                           uint64_t *lens) {
+  if (!q || !quals || !off || !streams || !lens) { g_err = "null argument"; return FQSX_E_ARG; }
+  fqsx_dna *c = &q->mem;
+  QualCfg &cfg = q->cfg;
+  const u32 T = q->T;
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(q->device));
+#endif
+  int rc;
+  void *p = nullptr;
+  u64 max_w = 0;
+  for (u32 t = 0; t < T; ++t) {
+    u64 first = (u64)t * n_reads / T, last = ((u64)t + 1) * n_reads / T;
+    if (t) first &= ~1ull;
+    if (t + 1 < T) last &= ~1ull;
+    max_w = std::max(max_w, off[last] - off[first]);
+  }
+  // context table: every symbol can create one context
+  if ((rc = d2h_sync(c, q->h_filled.data(), cfg.filled, T * sizeof(u32)))) return rc;
+  u64 need = 0;
+  for (u32 t = 0; t < T; ++t) need = std::max<u64>(need, (u64)q->h_filled[t] + max_w + 64);
+  if (need * 2 > q->cap) {
+    const u64 ncap = pow2_at_least(need * 2);
+    if ((rc = dalloc(c, &p, ncap * T * cfg.slot_u64 * sizeof(u64), false))) return rc;
+#ifndef FQSX_EMU
+    HIPCHK(hipMemsetAsync(p, 0xff, ncap * T * cfg.slot_u64 * sizeof(u64), c->stream));
+#else
+    memset(p, 0xff, ncap * T * cfg.slot_u64 * sizeof(u64));
+#endif
+    LAUNCH(c, 2, k_qual_rehash, REHASH_GRID, 256, (const u64 *)cfg.tab, cfg.cap_mask, (u64 *)p, ncap - 1, T, cfg.slot_u64);
+#ifndef FQSX_EMU
+    HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+    dfree(c, cfg.tab);
+    cfg.tab = (u64 *)p;
+    cfg.cap_mask = ncap - 1;
+    q->cap = ncap;
+  }
+  const u64 need_out = max_w * 2 + 4096, nq = off[n_reads] + 64, no = ((u64)n_reads + 1) * sizeof(u64);
+  if (need_out > q->out_cap) {
+    dfree(c, cfg.out);
+    if ((rc = dalloc(c, &p, need_out * T, false))) return rc;
+    cfg.out = (u8 *)p; cfg.out_cap = q->out_cap = need_out;
+  }
+  if (nq > q->q_cap) { dfree(c, q->d_q); if ((rc = dalloc(c, &p, nq + nq / 4, false))) return rc; q->d_q = (u8 *)p; q->q_cap = nq + nq / 4; }
+  if (no > q->off_cap) { dfree(c, q->d_off); if ((rc = dalloc(c, &p, no + no / 4, false))) return rc; q->d_off = (u64 *)p; q->off_cap = no + no / 4; }
+  if ((rc = h2d(c, q->d_q, quals, off[n_reads]))) return rc;
+  if ((rc = h2d(c, q->d_off, off, no))) return rc;
+  cfg.quals = q->d_q;
+  cfg.off = q->d_off;
+  LAUNCH(c, 0, k_qual_encode, T, 64, cfg, n_reads);
+  if ((rc = d2h_sync(c, q->h_lens.data(), cfg.lens, T * sizeof(u64)))) return rc;
+  u32 err = 0;
+  if ((rc = d2h_sync(c, &err, cfg.err, sizeof(u32)))) return rc;
+  if (err) { g_err = "device error " + std::to_string(err) + " in the quality kernel"; return FQSX_E_DEVICE; }
+  u64 total = 0;
+  for (u32 t = 0; t < T; ++t) total += q->h_lens[t];
+  q->h_out.resize(total ? total : 1);
+  u64 pos = 0;
+  for (u32 t = 0; t < T; ++t) {
+    if ((rc = d2h_sync(c, q->h_out.data() + pos, cfg.out + (u64)t * cfg.out_cap, q->h_lens[t]))) return rc;
+    streams[t] = q->h_out.data() + pos;
+    lens[t] = q->h_lens[t];
+    pos += q->h_lens[t];
+  }
   return FQSX_OK;
 }
 

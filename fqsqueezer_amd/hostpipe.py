@@ -338,3 +338,24 @@ def block_arrays_pe(rec1: Records, rec2: Records, idx: np.ndarray) -> Tuple[np.n
     off = np.zeros(len(parts) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(x) for x in parts])
     return np.frombuffer(b"".join(parts), dtype=np.uint8), off
+
+
+def qual_arrays(rec: Records, idx: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Concatenated quality bytes + n+1 offsets of one block (same shape as block_arrays)."""
+    if isinstance(rec.qual, np.ndarray):
+        L = rec.qual.shape[1]
+        return np.ascontiguousarray(rec.qual[idx]).reshape(-1), np.arange(len(idx) + 1, dtype=np.uint64) * np.uint64(L)
+    parts = [rec.qual[int(i)] for i in idx]
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(p) for p in parts])
+    return np.frombuffer(b"".join(parts), dtype=np.uint8), off
+
+
+def qual_arrays_pe(rec1: Records, rec2: Records, idx: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    parts = []
+    for i in idx:
+        parts.append(rec1.qual_bytes(int(i)))
+        parts.append(rec2.qual_bytes(int(i)))
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    return np.frombuffer(b"".join(parts), dtype=np.uint8), off

@@ -85,6 +85,16 @@ int fqsx_dna_stats(fqsx_dna *, uint64_t out[48]);
 int fqsx_dna_set_profiling(fqsx_dna *, int enable);
 int fqsx_dna_kernel_times(fqsx_dna *, double out[6]);
 
+/* Quality stream on the GPU: replaces CQualityCompressor::Init / Compress for all T
+ * workers of a block (fqs/quality.h:43-50, fqs/quality.cpp:32-71,152-175; called from fqs/application.cpp:641).
+ * quality_mode and quality_thr come from the header bytes 6 and 8; quality_mode none is rejected (nothing
+ * to code).  quals = concatenated quality strings of the block's reads (mates interleaved for paired data). */
+typedef struct fqsx_qual fqsx_qual;
+int fqsx_qual_create(const uint8_t *header17, int device, fqsx_qual **out);
+int fqsx_qual_encode_block(fqsx_qual *, const uint8_t *quals, const uint64_t *read_off, uint32_t n_reads,
+                           const uint8_t **streams, uint64_t *lens);
+void fqsx_qual_destroy(fqsx_qual *);
+
 /* Host-side (CPU) read-length stream that accompanies every DNA stream in the container
  * (CMetaCompressor::CompressReadLen, fqs/meta.cpp:48-113; one symbol per read, not part of the hot path).
  * Same worker partition as the DNA path; streams valid until the next call. */

@@ -1364,6 +1364,64 @@ struct Worker {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------
+// Quality stream (next row N1): CQualityCompressor, quality.cpp:32-222
+struct QualWorker {
+  u32 qmode = 4, n_sym = 0, bits = 0, nctx = 0;
+  u64 ctx_mask = 0;
+  u32 fwd[96];
+  std::vector<u64> keys;            // open-addressed context map: key -> model index (context_hm.h semantics)
+  std::vector<u32> midx;
+  std::vector<std::vector<u32>> st; // stats per model
+  std::vector<u32> tot;
+  u64 hmask = 0;
+  RangeEnc rc;
+  void init(u32 mode, u32 thr) {    // Init + adjust_quality_map_*, quality.cpp:32-149
+    qmode = mode;
+    for (int i = 0; i < 96; ++i) fwd[i] = 0;
+    auto band = [&](int a, int b, u32 v) { for (int i = a; i < b; ++i) fwd[i] = v; };
+    if (mode == 0) { n_sym = 96; bits = 6; nctx = 2; for (int i = 0; i < 96; ++i) fwd[i] = i; }
+    else if (mode == 1) { n_sym = 8; bits = 4; nctx = 6; band(0, 2, 0); band(2, 10, 1); band(10, 20, 2); band(20, 25, 3); band(25, 30, 4); band(30, 35, 5); band(35, 40, 6); band(40, 96, 7); }
+    else if (mode == 2) { n_sym = 4; bits = 3; nctx = 9; band(0, 2, 0); band(2, 15, 1); band(15, 31, 2); band(31, 96, 3); }
+    else if (mode == 3) { n_sym = 2; bits = 2; nctx = 10; band(0, (int)thr, 0); band((int)thr, 96, 1); }
+    ctx_mask = (1ull << (bits * nctx)) - 1ull;
+    keys.assign(1u << 12, ~0ull); midx.assign(1u << 12, 0); hmask = keys.size() - 1;
+  }
+  u32 model_of(u64 ctx) {           // find_rc_context, quality.cpp:218-226
+    for (u64 h = murmur64(ctx) & hmask;; h = (h + 1) & hmask) {
+      if (keys[h] == ctx) return midx[h];
+      if (keys[h] == ~0ull) {
+        if ((st.size() + 1) * 2 > keys.size()) {
+          std::vector<u64> ok; std::vector<u32> om;
+          ok.swap(keys); om.swap(midx);
+          keys.assign(ok.size() * 2, ~0ull); midx.assign(ok.size() * 2, 0); hmask = keys.size() - 1;
+          for (size_t i = 0; i < ok.size(); ++i)
+            if (ok[i] != ~0ull) { u64 q = murmur64(ok[i]) & hmask; while (keys[q] != ~0ull) q = (q + 1) & hmask; keys[q] = ok[i]; midx[q] = om[i]; }
+          return model_of(ctx);
+        }
+        keys[h] = ctx; midx[h] = (u32)st.size();
+        st.emplace_back(n_sym, 1u); tot.push_back(n_sym);
+        return midx[h];
+      }
+    }
+  }
+  void compress(const u8 *q, u32 size) {  // Compress, quality.cpp:152-175; model: CSimpleModel adder 1, max_total 2^15
+    if (qmode == 4) return;
+    u64 ctx = ctx_mask;
+    for (u32 i = 0; i < size; ++i) {
+      u32 m = model_of(ctx), x = fwd[q[i] - 33], left = 0;
+      std::vector<u32> &s = st[m];
+      for (u32 j = 0; j < x; ++j) left += s[j];
+      rc.encode(s[x], left, tot[m]);
+      s[x] += 1; tot[m] += 1;
+      while (tot[m] >= (1u << 15)) { tot[m] = 0; for (auto &v : s) { v = (v + 1) / 2; tot[m] += v; } }
+      u64 my = ctx + (1ull << 48), t = (ctx << bits) + x;   // update_context, quality.cpp:209-215
+      ctx = (my & ~ctx_mask) + (t & ctx_mask);
+    }
+  }
+};
+struct fqo_qual { u32 T; std::vector<QualWorker> w; };
+
 struct fqo_codec {
   Shared sh;
   std::vector<Worker *> w;
@@ -1469,6 +1527,34 @@ void fqo_counters(fqo_codec *c, uint64_t o[8]) {
   const Counters &k = c->sh.cnt;
   o[0] = k.probes; o[1] = k.slots; o[2] = k.inserts; o[3] = k.siv_words;
   o[4] = k.ctx; o[5] = k.coded; o[6] = k.lprobes; o[7] = k.linserts;
+}
+
+fqo_qual *fqo_qual_create(const uint8_t *h) {
+  if (!h || h[0] != 'K' || h[4] == 0 || h[6] > 4) return nullptr;
+  fqo_qual *q = new fqo_qual;
+  q->T = h[4];
+  q->w.resize(q->T);
+  for (auto &w : q->w) w.init(h[6], h[8]);
+  return q;
+}
+void fqo_qual_destroy(fqo_qual *q) { delete q; }
+int fqo_qual_encode_block(fqo_qual *q, const uint8_t *quals, const uint64_t *off, uint32_t n_reads) {
+  const u64 T = q->T;
+  for (u64 t = 0; t < T; ++t) {
+    u64 first = t * n_reads / T, last = (t + 1) * n_reads / T;  // reads_block.h:197-214
+    if (t) first &= ~1ull;
+    if (t + 1 < T) last &= ~1ull;
+    QualWorker &w = q->w[t];
+    w.rc.out.clear();
+    w.rc.start();
+    for (u64 i = first; i < last; ++i) w.compress(quals + off[i], (u32)(off[i + 1] - off[i]));
+    w.rc.end();
+  }
+  return 0;
+}
+const uint8_t *fqo_qual_stream(fqo_qual *q, uint32_t worker, uint64_t *len) {
+  *len = q->w[worker].rc.out.size();
+  return q->w[worker].rc.out.data();
 }
 
 void fqo_kat_mt19937(uint32_t seed, uint32_t n, uint32_t *out) {

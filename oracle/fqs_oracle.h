@@ -51,6 +51,14 @@ int fqo_decode_block(fqo_codec *, const uint8_t *const *streams, const uint64_t 
  * [7] local inserts */
 void fqo_counters(fqo_codec *, uint64_t out[8]);
 
+/* Quality stream (CQualityCompressor, quality.cpp:152-175): same header bytes
+ * (quality_mode = byte 6, quality_thr = byte 8), same worker partition, no synchronisation points. */
+typedef struct fqo_qual fqo_qual;
+fqo_qual *fqo_qual_create(const uint8_t *header17);
+void fqo_qual_destroy(fqo_qual *);
+int fqo_qual_encode_block(fqo_qual *, const uint8_t *quals, const uint64_t *read_off, uint32_t n_reads);
+const uint8_t *fqo_qual_stream(fqo_qual *, uint32_t worker, uint64_t *len);
+
 /* Known-answer helpers for unit tests */
 void fqo_kat_mt19937(uint32_t seed, uint32_t n, uint32_t *out);
 void fqo_kat_cinc(uint32_t thr, uint32_t mult, uint32_t maxv, uint32_t n,

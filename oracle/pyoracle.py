@@ -38,6 +38,12 @@ def lib():
         _lib.fqo_stream.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
         _lib.fqo_decode_block.restype = C.c_int
         _lib.fqo_decode_block.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        _lib.fqo_qual_create.restype = C.c_void_p
+        _lib.fqo_qual_create.argtypes = [C.c_char_p]
+        _lib.fqo_qual_destroy.argtypes = [C.c_void_p]
+        _lib.fqo_qual_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        _lib.fqo_qual_stream.restype = C.POINTER(C.c_uint8)
+        _lib.fqo_qual_stream.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
         _lib.fqo_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _lib.fqo_kat_mt19937.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         _lib.fqo_kat_cinc.argtypes = [C.c_uint32] * 4 + [C.c_void_p] * 3
@@ -91,3 +97,28 @@ class OracleCodec:
 
     def __del__(self):
         self.close()
+
+
+class OracleQual:
+    """Quality-stream restatement (same call shape as fqsqueezer_amd.codec.QualCodec)."""
+
+    def __init__(self, header: bytes):
+        self.T = header[4]
+        self._h = lib().fqo_qual_create(bytes(header))
+        if not self._h:
+            raise ValueError("oracle: unsupported header")
+
+    def encode_block(self, quals: np.ndarray, read_off: np.ndarray):
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        lib().fqo_qual_encode_block(self._h, quals.ctypes.data, read_off.ctypes.data, len(read_off) - 1)
+        out, n = [], C.c_uint64()
+        for w in range(self.T):
+            p = lib().fqo_qual_stream(self._h, w, C.byref(n))
+            out.append(bytes(C.cast(p, C.POINTER(C.c_uint8 * n.value)).contents) if n.value else b"")
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().fqo_qual_destroy(self._h)
+            self._h = None

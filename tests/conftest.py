@@ -148,3 +148,26 @@ def check_decode_fqs(make_codec, rec, fqs_name):
         out = codec.decode_block([ref.streams[w][hp.STREAM_DNA] for w in range(header[4])], off, g)
         assert np.array_equal(np.frombuffer(bytes(out), dtype=np.uint8), np.asarray(bases)), f"{fqs_name}: block {g} decoded wrongly"
     return codec
+
+
+def check_quality_digest(make_codec, json_name):
+    from fqsqueezer_amd import hostpipe as hp
+    d = json.load(open(os.path.join(GOLD, json_name)))
+    header = bytes.fromhex(d["header"])
+    codec = make_codec(header)
+    if d.get("paired"):
+        r1, r2 = c5_records()
+        blks = hp.form_blocks_pe(r1, r2, "pe_sorted")
+        arrays = lambda idx: hp.qual_arrays_pe(r1, r2, idx)
+    else:
+        rec = c1_records()
+        blks = hp.form_blocks(rec, "se_original")
+        arrays = lambda idx: hp.qual_arrays(rec, idx)
+    assert len(blks) == d["n_blocks"]
+    for g, (idx, ref) in enumerate(zip(blks, d["blocks"])):
+        q, off = arrays(idx)
+        streams = codec.encode_block(q, off)
+        h = hashlib.sha256()
+        for s in streams:
+            h.update(s)
+        assert sum(len(s) for s in streams) == ref["bytes"] and h.hexdigest() == ref["sha256"], f"{json_name}: block {g} quality stream differs"

@@ -10,6 +10,7 @@ Fixtures (data only -- inputs are re-generated deterministically by fqsqueezer_a
   c5_pe4k_{o,s}_t{1,4}.fqs  4000 pairs x 100bp (fragments 300-600), G=60kbp, seed 5, `-p`, -gs 1 (paired-end path)
   c6_20k_gs300_s_t2.json    20k x 100bp, G=1Mbp, seed 6, -gs 300 (k = 12/17/21/26: 4 GiB p-mer vector, 256-way partial look-ups)
   c7_mixedlen_{o,s}_t3.fqs  1500 reads of 20-31 / 60-199 / 4200-5999 bp with N runs, G=40kbp, seed 7, -gs 1
+  c8_qual_{o,8,4,2}_t4.json, c8_qual_pe8_t3.json   per-block SHA-256 of the QUALITY streams (all four quality modes; PE)
   c3_50k150_s_t8.json       50k x 150bp, G=250kbp, seed 3, -om s -gs 8 (150 bp metric shape)
 Usage: python tools/make_golden.py [--work /tmp/w] [--only c1|c2|c3]
 """
@@ -104,6 +105,32 @@ def main():
                 f.write(i + b"\n" + sq + b"\n+\n" + q + b"\n")
         for om in "os":
             run_ref(fq, os.path.join(GOLD, f"c7_mixedlen_{om}_t3.fqs"), om, 3, 1, a.work)
+    if a.only in ("", "c8"):   # quality streams (-qm o/8/4/2 on c1; -qm 8 on the c5 pairs): per-block SHA-256 of the quality streams
+        def qdigest(path, meta):
+            header, blocks = hp.parse_fqs(open(path, "rb").read())
+            d = dict(meta, header=header.hex(), n_blocks=len(blocks), blocks=[])
+            for b in blocks:
+                h = hashlib.sha256()
+                n = 0
+                for st in b.streams:
+                    h.update(st[hp.STREAM_QUALITY])
+                    n += len(st[hp.STREAM_QUALITY])
+                d["blocks"].append({"n_reads": b.n_reads, "sha256": h.hexdigest(), "bytes": n})
+            return d
+        fq = os.path.join(a.work, "c1.fq")
+        for qm in ("o", "8", "4", "2"):
+            out = os.path.join(a.work, f"q1_{qm}_t4.fqs")
+            if not os.path.exists(out):
+                subprocess.check_call([REF, "e", "-s", "-om", "o", "-t", "4", "-gs", "1", "-qm", qm] + (["-qt", "25"] if qm == "2" else []) +
+                                      ["-im", "n", "-v", "0", "-tmp", os.path.join(a.work, "tmpq_"), "-out", out, fq], stdout=subprocess.DEVNULL)
+            json.dump(qdigest(out, {"input": "c1 (10k x 100bp, seed 1)", "qm": qm, "om": "o", "threads": 4}),
+                      open(os.path.join(GOLD, f"c8_qual_{qm}_t4.json"), "w"))
+        out = os.path.join(a.work, "q5_8_t3.fqs")
+        if not os.path.exists(out):
+            subprocess.check_call([REF, "e", "-p", "-om", "s", "-t", "3", "-gs", "1", "-qm", "8", "-im", "n", "-v", "0", "-tmp", os.path.join(a.work, "tmpq_"),
+                                   "-out", out, os.path.join(a.work, "c5_1.fq"), os.path.join(a.work, "c5_2.fq")], stdout=subprocess.DEVNULL)
+        json.dump(qdigest(out, {"input": "c5 (4000 pairs, seed 5)", "qm": "8", "om": "s", "threads": 3, "paired": True}),
+                  open(os.path.join(GOLD, "c8_qual_pe8_t3.json"), "w"))
     if a.only in ("", "c3"):
         fq = os.path.join(a.work, "c3.fq")
         if not os.path.exists(fq):
