@@ -78,8 +78,14 @@ FQ_KERNEL64 void k_part_scan(DevCfg cfg, u32 kind) { part_scan_body(cfg, kind, F
 FQ_KERNEL64 void k_part_dstoff(DevCfg cfg, u32 *demand /*[2][T]+1*/) {
   part_dstoff_body(cfg, FQ_BLOCK);
   // per-owner demand of the coming insert phase (s- and b-mers) + the device error word
+  // per-owner demand of the coming insert phase (s- and b-mers), current occupancy, and the device error word:
+  // everything the host needs for its growth decision in one transfer
   if (FQ_BLOCK != MAIL_P)
-    for (u32 d = FQ_LANE; d < cfg.T; d += FQ_WAVE) demand[(FQ_BLOCK == MAIL_S ? 0 : cfg.T) + d] = cfg.mail[FQ_BLOCK].dst_tot[d];
+    for (u32 d = FQ_LANE; d < cfg.T; d += FQ_WAVE) {
+      const u32 o = (FQ_BLOCK == MAIL_S ? 0 : cfg.T) + d;
+      demand[o] = cfg.mail[FQ_BLOCK].dst_tot[d];
+      demand[2 * cfg.T + 1 + o] = (FQ_BLOCK == MAIL_S ? cfg.g_s : cfg.g_b).filled[d];
+    }
   if (FQ_BLOCK == 0 && FQ_LANE == 0) demand[2 * cfg.T] = *cfg.err;
 }
 FQ_KERNEL64 void k_part_scatter(DevCfg cfg, u32 kind) {
@@ -557,7 +563,7 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
     for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_count, T * cfg.mail[k].n_tiles, 64, cfg, k);
     for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_scan, T, 64, cfg, k);
     LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand);
-    if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, (2 * T + 1) * sizeof(u32)))) return rc;
+    if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, (4 * T + 1) * sizeof(u32)))) return rc;
     if (c->h_demand[2 * T]) {
       g_err = "device error " + std::to_string(c->h_demand[2 * T]) + " in encode kernel";
       return FQSX_E_DEVICE;
@@ -565,9 +571,8 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
     for (int which = 0; which < 2; ++which) {
       KTab &t = which ? cfg.g_b : cfg.g_s;
       u64 &cap = which ? c->gb_cap : c->gs_cap;
-      if ((rc = d2h_sync(c, c->h_filled.data(), t.filled, T * sizeof(u32)))) return rc;
       u64 need = 0;
-      for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_filled[o] + c->h_demand[which * T + o]);
+      for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_demand[2 * T + 1 + which * T + o] + c->h_demand[which * T + o]);
       if (need * 2 > cap && (rc = grow_global(c, t, cap, pow2_at_least(need * 2 + 2)))) return rc;
     }
     if (c->paired) {  // pair table: size for the exact per-owner demand, then insert
@@ -731,11 +736,11 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   }
   if ((rc = dalloc(c, &p, sizeof(u32) * 4, true))) return rc;
   cfg.err = (u32 *)p;
-  if ((rc = dalloc(c, &p, (2 * (u64)T + 1) * sizeof(u32), true))) return rc;
+  if ((rc = dalloc(c, &p, (4 * (u64)T + 1) * sizeof(u32), true))) return rc;
   c->d_demand = (u32 *)p;
   if ((rc = dalloc(c, &p, ((u64)T + 64) * sizeof(u64), true))) return rc;
   c->d_lens = (u64 *)p;
-  c->h_demand.assign(2 * T + 1, 0);
+  c->h_demand.assign(4 * T + 1, 0);
   c->h_filled.assign(T, 0);
   c->h_lens.assign(T + 64, 0);
 #ifndef FQSX_EMU
