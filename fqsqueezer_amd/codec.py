@@ -54,6 +54,10 @@ def _load(path: str):
     lib.fqsx_meta_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
     lib.fqsx_meta_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.fqsx_meta_destroy.argtypes = [C.c_void_p]
+    lib.fqsx_meta_encode_block_pe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.fqsx_id_create.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.fqsx_id_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.fqsx_id_destroy.argtypes = [C.c_void_p]
     lib.fqsx_last_error.restype = C.c_char_p
     lib.fqsx_version.restype = C.c_char_p
     return lib
@@ -163,15 +167,48 @@ class MetaCodec:
         self._streams = (C.c_void_p * threads)()
         self._lens = (C.c_uint64 * threads)()
 
-    def encode_block(self, read_len: np.ndarray) -> List[bytes]:
+    def encode_block(self, read_len: np.ndarray, paired: bool = False) -> List[bytes]:
         read_len = np.ascontiguousarray(read_len, dtype=np.uint32)
-        if self._lib.fqsx_meta_encode_block(self._h, read_len.ctypes.data, len(read_len), self._streams, self._lens):
+        if self._lib.fqsx_meta_encode_block_pe(self._h, read_len.ctypes.data, len(read_len), int(paired), self._streams, self._lens):
             raise FqsxError("fqsx_meta_encode_block failed")
         return [C.string_at(self._streams[w], self._lens[w]) for w in range(self.T)]
 
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._lib.fqsx_meta_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class IdCodec:
+    """Host-side read-id stream of the container (fqsx_id_*; header byte 7 = id mode)."""
+
+    def __init__(self, header: bytes, lib_path: Optional[str] = None):
+        self._lib = load_library(lib_path)
+        self.T = header[4]
+        self._h = C.c_void_p()
+        if self._lib.fqsx_id_create(bytes(header), C.byref(self._h)):
+            raise FqsxError("fqsx_id_create failed")
+        self._streams = (C.c_void_p * self.T)()
+        self._lens = (C.c_uint64 * self.T)()
+
+    def encode_block(self, ids: np.ndarray, id_off: np.ndarray, paired: bool = False) -> List[bytes]:
+        ids = np.ascontiguousarray(ids, dtype=np.uint8)
+        id_off = np.ascontiguousarray(id_off, dtype=np.uint64)
+        rc = self._lib.fqsx_id_encode_block(self._h, ids.ctypes.data, id_off.ctypes.data, len(id_off) - 1, int(paired),
+                                            self._streams, self._lens)
+        if rc:
+            raise FqsxError(f"fqsx_id_encode_block: {rc}")
+        return [C.string_at(self._streams[w], self._lens[w]) for w in range(self.T)]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.fqsx_id_destroy(self._h)
             self._h = None
 
     def __del__(self):

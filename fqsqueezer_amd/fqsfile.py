@@ -1,6 +1,7 @@
-"""Write a complete `.fqs` file (DNA-only modes: `-qm n -im n`) around the GPU DNA streams, readable by
-the reference decompressor `fqs d`.  Host plumbing: block formation, worker offsets, the meta stream
-and the container; the DNA streams come from fqsqueezer_amd.codec.DnaCodec."""
+"""Write a complete `.fqs` file around the GPU streams, readable by the reference decompressor `fqs d` and
+byte-identical to what `fqs e -t <threads>` writes for the same input and modes.  Host plumbing: block
+formation, worker offsets, the container, the meta and id streams (host C++ helpers,
+csrc/fqsx_host.cpp); the DNA and quality streams come from the GPU (codec.DnaCodec / codec.QualCodec)."""
 from __future__ import annotations
 
 from typing import Optional
@@ -8,27 +9,78 @@ from typing import Optional
 import numpy as np
 
 from . import hostpipe as hp
-from .codec import DnaCodec, MetaCodec
+from .codec import DnaCodec, IdCodec, MetaCodec, QualCodec
+
+
+def _encode(header: bytes, blocks, arrays, sizes_of, paired: bool, device: int, lib_path: Optional[str]) -> bytes:
+    threads = header[4]
+    stored = hp.stored_streams(header)
+    dna = DnaCodec(header, device=device, lib_path=lib_path)
+    meta = MetaCodec(threads, lib_path=lib_path)
+    idc = IdCodec(header, lib_path=lib_path) if hp.STREAM_ID in stored else None
+    qual = QualCodec(header, device=device, lib_path=lib_path) if hp.STREAM_QUALITY in stored else None
+    out = []
+    try:
+        for g, idx in enumerate(blocks):
+            bases, off, ids, id_off, quals = arrays(idx)
+            n = len(off) - 1
+            st = {hp.STREAM_DNA: dna.encode_block(bases, off, g),
+                  hp.STREAM_META: meta.encode_block(np.diff(off.astype(np.int64)).astype(np.uint32), paired)}
+            if idc is not None:
+                st[hp.STREAM_ID] = idc.encode_block(ids, id_off, paired)
+            if qual is not None:
+                st[hp.STREAM_QUALITY] = qual.encode_block(quals, off)
+            cs = np.concatenate([[0], np.cumsum(sizes_of(idx))])
+            blk = hp.FqsBlock(n)
+            for w, (first, _) in enumerate(hp.partition_for_workers(n, threads)):
+                blk.offsets.append(int(cs[first]) if n else 0)   # application.cpp:716
+                blk.streams.append({k: v[w] for k, v in st.items()})
+            out.append(blk)
+    finally:
+        dna.close()
+        meta.close()
+        if idc is not None:
+            idc.close()
+        if qual is not None:
+            qual.close()
+    return hp.write_fqs(header, out)
 
 
 def compress_records(rec: hp.Records, threads: int, order: str = "s", genome_size_mbp: int = 3100, device: int = 0,
-                     lib_path: Optional[str] = None) -> bytes:
+                     lib_path: Optional[str] = None, quality_mode: str = "none", id_mode: str = "none",
+                     quality_thr: int = 20) -> bytes:
+    """`fqs e -s -om <order> -t <threads> -gs <g> -qm <..> -im <..>` on single-end records."""
     mode = "se_sorted" if order == "s" else "se_original"
-    header = hp.make_header(threads, mode, genome_size_mbp, "none", "none")
-    dna = DnaCodec(header, device=device, lib_path=lib_path)
-    meta = MetaCodec(threads, lib_path=lib_path)
+    header = hp.make_header(threads, mode, genome_size_mbp, quality_mode, id_mode, quality_thr)
+    full = quality_mode != "none" or id_mode != "none"
     sizes = rec.record_sizes()
-    out = []
-    for g, idx in enumerate(hp.form_blocks(rec, mode)):
+
+    def arrays(idx):
         bases, off = hp.block_arrays(rec, idx)
-        d = dna.encode_block(bases, off, g)
-        m = meta.encode_block(np.diff(off.astype(np.int64)).astype(np.uint32))
-        cs = np.concatenate([[0], np.cumsum(sizes[idx])])
-        blk = hp.FqsBlock(len(idx))
-        for w, (first, _) in enumerate(hp.partition_for_workers(len(idx), threads)):
-            blk.offsets.append(int(cs[first]) if len(idx) else 0)
-            blk.streams.append({hp.STREAM_META: m[w], hp.STREAM_DNA: d[w]})
-        out.append(blk)
-    dna.close()
-    meta.close()
-    return hp.write_fqs(header, out)
+        ids, id_off = hp.id_arrays(rec, idx) if id_mode != "none" else (None, None)
+        quals = hp.qual_arrays(rec, idx)[0] if quality_mode != "none" else None
+        return bases, off, ids, id_off, quals
+
+    return _encode(header, hp.form_blocks(rec, mode, exact_ties=full), arrays, lambda idx: sizes[idx], False, device, lib_path)
+
+
+def compress_records_pe(rec1: hp.Records, rec2: hp.Records, threads: int, order: str = "s", genome_size_mbp: int = 3100,
+                        device: int = 0, lib_path: Optional[str] = None, quality_mode: str = "none", id_mode: str = "none",
+                        quality_thr: int = 20) -> bytes:
+    """`fqs e -p ...` on two mate files (records interleaved mate 1 / mate 2 inside a block)."""
+    mode = "pe_sorted" if order == "s" else "pe_original"
+    header = hp.make_header(threads, mode, genome_size_mbp, quality_mode, id_mode, quality_thr)
+    s1, s2 = rec1.record_sizes(), rec2.record_sizes()
+
+    def arrays(idx):
+        bases, off = hp.block_arrays_pe(rec1, rec2, idx)
+        ids, id_off = hp.id_arrays_pe(rec1, rec2, idx) if id_mode != "none" else (None, None)
+        quals = hp.qual_arrays_pe(rec1, rec2, idx)[0] if quality_mode != "none" else None
+        return bases, off, ids, id_off, quals
+
+    def sizes_of(idx):
+        z = np.empty(2 * len(idx), dtype=np.int64)
+        z[0::2], z[1::2] = s1[idx], s2[idx]
+        return z
+
+    return _encode(header, hp.form_blocks_pe(rec1, rec2, mode), arrays, sizes_of, True, device, lib_path)

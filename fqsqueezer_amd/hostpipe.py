@@ -135,14 +135,19 @@ def sorted_order(rec: Records) -> List[np.ndarray]:
     return [np.asarray(x, dtype=np.int64) for x in out]
 
 
-def form_blocks(rec: Records, dna_mode: str = "se_sorted") -> List[np.ndarray]:
+def form_blocks(rec: Records, dna_mode: str = "se_sorted", exact_ties: bool = False) -> List[np.ndarray]:
     """Partition the input into reads blocks exactly as the reference's reader
     does (CReadsBlock::Read, reads_block.h:119-139): records are appended until
     fewer than 102400 bytes of the 16 MiB buffer remain.  In sorted mode every
     non-empty bin is a separate input file (compress_se_files, application.cpp:538-569).
+    exact_ties: order reads with identical DNA exactly as the reference's std::sort does (matters only for
+    the id / quality / meta streams, whose records follow the DNA order).
     Returns index arrays (into `rec`), one per block, in file order."""
     sizes = rec.record_sizes()
-    groups = sorted_order(rec) if dna_mode == "se_sorted" else [np.arange(len(rec), dtype=np.int64)]
+    if dna_mode == "se_sorted":
+        groups = sorted_order_exact(rec) if exact_ties else sorted_order(rec)
+    else:
+        groups = [np.arange(len(rec), dtype=np.int64)]
     blocks: List[np.ndarray] = []
     for g in groups:
         cs = np.cumsum(sizes[g])
@@ -278,7 +283,7 @@ def _host_lib():
     lib = os.path.join(here, "libfqsx_host.so")
     src = os.path.join(here, "csrc", "fqsx_host.cpp")
     if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", lib])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", src, "-o", lib])
     h = C.CDLL(lib)
     h.fqsx_sort_bin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     return h
@@ -348,6 +353,24 @@ def qual_arrays(rec: Records, idx: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     parts = [rec.qual[int(i)] for i in idx]
     off = np.zeros(len(parts) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(p) for p in parts])
+    return np.frombuffer(b"".join(parts), dtype=np.uint8), off
+
+
+def id_arrays(rec: Records, idx: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Concatenated id lines (each with its EOL, as read_desc_t::id_len counts it) + n+1 offsets of one block."""
+    parts = [rec.ids[int(i)] + b"\n" for i in idx]
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(p) for p in parts])
+    return np.frombuffer(b"".join(parts), dtype=np.uint8), off
+
+
+def id_arrays_pe(rec1: Records, rec2: Records, idx: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    parts = []
+    for i in idx:
+        parts.append(rec1.ids[int(i)] + b"\n")
+        parts.append(rec2.ids[int(i)] + b"\n")
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in parts])
     return np.frombuffer(b"".join(parts), dtype=np.uint8), off
 
 

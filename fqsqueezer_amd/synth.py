@@ -52,6 +52,51 @@ def read_id(i: int, mate: int = 1) -> bytes:
     return b"@SRR000001.%d %d/%d" % (i + 1, i + 1, mate)
 
 
+def synth_ids_varied(n: int, seed: int, mate: int = 0) -> list:
+    """Illumina-style ids that exercise the id coder's branches: numeric fields with small / 2- / 3- / 4- / 8-byte
+    positive and negative deltas, literal fields that change with and without a length change, 11+-digit digit
+    runs (literal by rule), occasional format changes (token structure differs -> plain coding), several
+    instrument names.  mate = 0: no mate suffix; 1 / 2: ' <mate>:N:0:<index>' (not 'typical' PE ids) -- every 7th
+    pair instead ends in '/1' or '/2' (typical)."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x1D5))
+    instr = [b"@HWI-ST1234", b"@M00123", b"@NB501234", b"@A00987"]
+    cells = [b"C0ABCACXX", b"H7LKJBGXY", b"000000000-AB12C", b"HW2YFDSXX"]
+    out = []
+    x = y = 1000
+    big = 5_000_000_000
+    for i in range(n):
+        r = rng.integers(0, 1000)
+        if r < 30:
+            x = int(rng.integers(1, 30000)); y = int(rng.integers(1, 200000))
+        elif r < 400:
+            y += int(rng.integers(-1, 2))
+        elif r < 800:
+            y += int(rng.integers(-150, 300))
+        else:
+            y = int(rng.integers(1, 20_000_000))
+        if r % 97 == 0:
+            big = int(rng.integers(1, 9_999_999_999))
+        elif r % 13 == 0:
+            big += int(rng.integers(-70000, 70000))
+        big = max(1, big)
+        ins = instr[(i // 700) % 4 if r > 5 else int(rng.integers(0, 4))]
+        cell = cells[(i // 1900) % 4]
+        lane = 1 + (i // 500) % 8
+        if r in (7, 8, 9):      # a different format altogether
+            body = b"@read_%d length=%d" % (i, 100 + r)
+        elif r in (10, 11):     # 11+ digits: literal by rule; separators only
+            body = b"%s:%012d::%d" % (ins, big * 7, y)
+        else:
+            body = b"%s:%d:%s:%d:%d:%d:%d %d" % (ins, 100 + (i // 3000), cell, lane, 1101 + (i // 250) % 16, x, y, big)
+        if mate:
+            if i % 7 == 3:
+                body += b"/%d" % mate
+            else:
+                body += b" %d:N:0:%s" % (mate, b"ATCACG" if (i // 1000) % 2 == 0 else b"TTAGGCA")
+        out.append(body)
+    return out
+
+
 def write_fastq(path: str, reads: np.ndarray, quals: np.ndarray | None = None,
                 seed: int = 0, mate: int = 1) -> None:
     n, L = reads.shape

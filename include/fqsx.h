@@ -107,6 +107,19 @@ int fqsx_meta_encode_block_pe(fqsx_meta *, const uint32_t *read_len, uint32_t n_
                               const uint8_t **streams, uint64_t *lens);
 void fqsx_meta_destroy(fqsx_meta *);
 
+/* Read-id stream (host CPU by design: string tokeniser + delta coder).  Replaces
+ * CIdCompressor::Init / ResetReadPrev / Compress / CompressPE for all T workers of one block (fqs/id.h:152-164,
+ * id.cpp:138-184; application.cpp:600-601,625,635,1165).  header17: T = byte 4, id_mode = byte 7 (0 lossless,
+ * 1 instrument, 2 none).  ids = concatenated id lines each including its '\n'; id_off = n_reads+1 offsets;
+ * paired != 0: reads alternate mate 1 / mate 2.  Streams are callee-owned until the next call.
+ * FQSX_E_ARG for bytes >= 128 in an id (the reference indexes 128-symbol models with them) and, in instrument
+ * mode, for an id without any of '.', ' ', ':' (the reference then overwrites the first base). */
+typedef struct fqsx_id fqsx_id;
+int fqsx_id_create(const uint8_t *header17, fqsx_id **out);
+int fqsx_id_encode_block(fqsx_id *, const uint8_t *ids, const uint64_t *id_off, uint32_t n_reads, int paired,
+                         const uint8_t **streams, uint64_t *lens);
+void fqsx_id_destroy(fqsx_id *);
+
 /* Host-side read order inside one bin of `fqs e -om s`: std::sort with the comparator of
  * CSortedFASTQFile::sort_reads (fqs/io.h:499-528) applied to reads idx_in[0..n) (indices into off[]),
  * result in idx_out.  Same libstdc++ algorithm on the same initial order = same order of equal reads. */

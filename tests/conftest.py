@@ -99,6 +99,43 @@ def check_against_digest(make_codec, json_name, max_blocks=None):
     return codec
 
 
+def c10_records():
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.synth import synth_ids_varied, synth_quals, synth_reads
+    return hp.Records(synth_ids_varied(3000, 10), synth_reads(3000, 100, 80000, 10), synth_quals(3000, 100, 10))
+
+
+def c11_records():
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.synth import synth_ids_varied, synth_pairs, synth_quals
+    r1, r2 = synth_pairs(2000, 100, 60000, 11)
+    return (hp.Records(synth_ids_varied(2000, 11, 1), r1, synth_quals(2000, 100, 11)),
+            hp.Records(synth_ids_varied(2000, 11, 2), r2, synth_quals(2000, 100, 12)))
+
+
+QM = {"o": "lossless", "8": "illumina_8", "4": "illumina_4", "2": "binary", "n": "none"}
+IM = {"o": "lossless", "i": "instrument", "n": "none"}
+
+
+def check_full_file_digest(data: bytes, json_name: str):
+    """Complete .fqs file vs the digest of the reference's file: every stream of every block, then the whole file."""
+    from fqsqueezer_amd import hostpipe as hp
+    d = json.load(open(os.path.join(GOLD, json_name)))
+    header, blocks = hp.parse_fqs(data)
+    assert header.hex() == d["header"]
+    assert len(blocks) == d["n_blocks"]
+    names = {hp.STREAM_META: "meta", hp.STREAM_ID: "id", hp.STREAM_DNA: "dna", hp.STREAM_QUALITY: "quality"}
+    for g, (b, ref) in enumerate(zip(blocks, d["blocks"])):
+        assert b.n_reads == ref["n_reads"]
+        for sid in hp.stored_streams(header):
+            h = hashlib.sha256()
+            for st in b.streams:
+                h.update(st[sid])
+            assert h.hexdigest() == ref[str(sid)], f"{json_name}: block {g}: {names[sid]} stream differs from the reference"
+    assert len(data) == d["file_bytes"]
+    assert hashlib.sha256(data).hexdigest() == d["file_sha256"]
+
+
 def c5_records():
     from fqsqueezer_amd import hostpipe as hp
     from fqsqueezer_amd.synth import read_id, synth_pairs, synth_quals

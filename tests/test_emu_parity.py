@@ -45,6 +45,12 @@ def test_emu_matches_reference_large_k_geometry():
     check_against_digest(emu, "c6_20k_gs300_s_t2.json")
 
 
+def test_emu_matches_reference_default_geometry():
+    """-gs 3100 (the reference's default, BASELINE configs[3]): k = 13/18/21/27, 16 GiB p-mer vector (untouched pages stay
+    unmapped), partial look-ups of up to 1024 trials."""
+    check_against_digest(emu, "c9_20k150_gs3100_s_t2.json")
+
+
 @pytest.mark.parametrize("name,recs", [("c1_10k_o_t4.fqs", c1_records), ("c1_10k_s_t4.fqs", c1_records), ("c4_ragged_s_t3.fqs", c4_records),
                                        ("c7_mixedlen_o_t3.fqs", c7_records), ("c7_mixedlen_s_t3.fqs", c7_records),
                                        ("c5_pe4k_o_t4.fqs", c5_records), ("c5_pe4k_s_t4.fqs", c5_records)])

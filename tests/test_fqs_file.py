@@ -6,9 +6,9 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import EMU_LIB, GOLD, ROOT, c1_records, c4_records
+from conftest import EMU_LIB, GOLD, IM, QM, ROOT, c1_records, c4_records, c10_records, c11_records, check_full_file_digest
 from fqsqueezer_amd import hostpipe as hp
-from fqsqueezer_amd.fqsfile import compress_records
+from fqsqueezer_amd.fqsfile import compress_records, compress_records_pe
 
 REF = os.path.join(ROOT, "oracle", "_ref", "fqs-1.1")
 
@@ -31,6 +31,27 @@ def test_file_identical_to_reference_original_order(built, name, rec_fn, T, gs):
     assert data == open(os.path.join(GOLD, name), "rb").read()
 
 
+def test_default_mode_file_identical_to_reference(built):
+    """-qm o -im o: ids, qualities, read lengths and DNA -- the whole file byte for byte."""
+    data = compress_records(c10_records(), 3, "o", 1, lib_path=EMU_LIB, quality_mode="lossless", id_mode="lossless")
+    assert data == open(os.path.join(GOLD, "c10_full_o_t3.fqs"), "rb").read()
+
+
+FULL_SE = [("c10_full_s_i8_t4.json", "s", "8", "i", 4), ("c10_full_s_oo_t2.json", "s", "o", "o", 2), ("c10_full_o_i2_t5.json", "o", "2", "i", 5)]
+FULL_PE = [("c11_pe_full_s_o4_t3.json", "s", "4", "o", 3), ("c11_pe_full_o_io_t2.json", "o", "o", "i", 2)]
+
+
+@pytest.mark.parametrize("name,om,qm,im,T", FULL_SE)
+def test_full_mode_files_match_reference_digests(built, name, om, qm, im, T):
+    check_full_file_digest(compress_records(c10_records(), T, om, 1, lib_path=EMU_LIB, quality_mode=QM[qm], id_mode=IM[im]), name)
+
+
+@pytest.mark.parametrize("name,om,qm,im,T", FULL_PE)
+def test_full_mode_paired_files_match_reference_digests(built, name, om, qm, im, T):
+    r1, r2 = c11_records()
+    check_full_file_digest(compress_records_pe(r1, r2, T, om, 1, lib_path=EMU_LIB, quality_mode=QM[qm], id_mode=IM[im]), name)
+
+
 @pytest.mark.skipif(not os.path.exists(REF), reason="reference binary not built")
 @pytest.mark.parametrize("order", ["o", "s"])
 def test_reference_decoder_reads_our_file(built, tmp_path, order):
@@ -42,6 +63,17 @@ def test_reference_decoder_reads_our_file(built, tmp_path, order):
     else:
         want = [rec.seq[int(i)] for i in np.concatenate(hp.sorted_order(rec))]
     assert got[:len(want)] == want
+
+
+@pytest.mark.gpu
+def test_gpu_full_mode_files_identical_to_reference():
+    data = compress_records(c10_records(), 3, "o", 1, quality_mode="lossless", id_mode="lossless")
+    assert data == open(os.path.join(GOLD, "c10_full_o_t3.fqs"), "rb").read()
+    name, om, qm, im, T = FULL_SE[0]
+    check_full_file_digest(compress_records(c10_records(), T, om, 1, quality_mode=QM[qm], id_mode=IM[im]), name)
+    name, om, qm, im, T = FULL_PE[0]
+    r1, r2 = c11_records()
+    check_full_file_digest(compress_records_pe(r1, r2, T, om, 1, quality_mode=QM[qm], id_mode=IM[im]), name)
 
 
 @pytest.mark.gpu

@@ -32,6 +32,11 @@ def test_oracle_matches_reference_large_k_geometry():
     check_against_digest(OracleCodec, "c6_20k_gs300_s_t2.json")
 
 
+@pytest.mark.slow
+def test_oracle_matches_reference_default_geometry():
+    check_against_digest(OracleCodec, "c9_20k150_gs3100_s_t2.json")   # ~100 s: the p-mer sweep covers 4^18 fields per worker
+
+
 def test_oracle_matches_reference_150bp():
     check_against_digest(OracleCodec, "c3_50k150_s_t8.json")
 

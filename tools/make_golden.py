@@ -9,8 +9,13 @@ Fixtures (data only -- inputs are re-generated deterministically by fqsqueezer_a
   c4_ragged_{o,s}_t3.fqs   3000 ragged reads (30-160 bp, N runs, duplicates), G=60kbp, seed 4, -gs 1
   c5_pe4k_{o,s}_t{1,4}.fqs  4000 pairs x 100bp (fragments 300-600), G=60kbp, seed 5, `-p`, -gs 1 (paired-end path)
   c6_20k_gs300_s_t2.json    20k x 100bp, G=1Mbp, seed 6, -gs 300 (k = 12/17/21/26: 4 GiB p-mer vector, 256-way partial look-ups)
+  c9_20k150_gs3100_s_t2.json  20k x 150bp, G=200kbp, seed 9, DEFAULT -gs 3100 (k = 13/18/21/27: 16 GiB p-mer vector, up to 1024-way
+                            partial look-ups; the reference needs ~45 GiB and ~10 min for it)
   c7_mixedlen_{o,s}_t3.fqs  1500 reads of 20-31 / 60-199 / 4200-5999 bp with N runs, G=40kbp, seed 7, -gs 1
   c8_qual_{o,8,4,2}_t4.json, c8_qual_pe8_t3.json   per-block SHA-256 of the QUALITY streams (all four quality modes; PE)
+  c10_full_*.fqs/.json     3000 x 100bp (G=80kbp, seed 10) with varied Illumina-style ids: complete default-mode files
+                            (-qm o -im o) and digests of all four streams for -om s with -im i -qm 8 / -im o -qm o
+  c11_pe_full_*.json        2000 pairs (G=60kbp, seed 11), varied ids incl. typical and atypical mate ids, -p, full modes
   c3_50k150_s_t8.json       50k x 150bp, G=250kbp, seed 3, -om s -gs 8 (150 bp metric shape)
 Usage: python tools/make_golden.py [--work /tmp/w] [--only c1|c2|c3]
 """
@@ -96,6 +101,14 @@ def main():
         run_ref(fq, out, "s", 2, 300, a.work)
         meta = {"reads": 20000, "len": 100, "genome": 1000000, "seed": 6, "gs": 300, "om": "s", "threads": 2}
         json.dump(digest(out, meta), open(os.path.join(GOLD, "c6_20k_gs300_s_t2.json"), "w"))
+    if a.only == "c9":   # default geometry: only on request (45 GiB, 10 min)
+        fq = os.path.join(a.work, "c9.fq")
+        if not os.path.exists(fq):
+            write_fastq(fq, synth_reads(20000, 150, 200000, 9), seed=9)
+        out = os.path.join(a.work, "c9_s_t2.fqs")
+        run_ref(fq, out, "s", 2, 3100, a.work)
+        meta = {"reads": 20000, "len": 150, "genome": 200000, "seed": 9, "gs": 3100, "om": "s", "threads": 2}
+        json.dump(digest(out, meta), open(os.path.join(GOLD, "c9_20k150_gs3100_s_t2.json"), "w"))
     if a.only in ("", "c7"):
         from fqsqueezer_amd.synth import synth_mixed_lengths
         ids, seqs, quals = synth_mixed_lengths()
@@ -131,6 +144,51 @@ def main():
                                    "-out", out, os.path.join(a.work, "c5_1.fq"), os.path.join(a.work, "c5_2.fq")], stdout=subprocess.DEVNULL)
         json.dump(qdigest(out, {"input": "c5 (4000 pairs, seed 5)", "qm": "8", "om": "s", "threads": 3, "paired": True}),
                   open(os.path.join(GOLD, "c8_qual_pe8_t3.json"), "w"))
+    if a.only in ("", "c10"):   # complete files in full modes: ids (host coder), qualities, meta, DNA
+        from fqsqueezer_amd.synth import synth_ids_varied, synth_pairs, synth_quals
+
+        def write_fq(path, ids, reads, quals):
+            with open(path, "wb") as f:
+                for i in range(len(ids)):
+                    f.write(ids[i] + b"\n" + reads[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n")
+
+        def fdigest(path, meta):
+            data = open(path, "rb").read()
+            header, blocks = hp.parse_fqs(data)
+            d = dict(meta, header=header.hex(), n_blocks=len(blocks), file_sha256=hashlib.sha256(data).hexdigest(), file_bytes=len(data), blocks=[])
+            for b in blocks:
+                e = {"n_reads": b.n_reads}
+                for sid in hp.stored_streams(header):
+                    h = hashlib.sha256()
+                    for st in b.streams:
+                        h.update(st[sid])
+                    e[str(sid)] = h.hexdigest()
+                d["blocks"].append(e)
+            return d
+
+        n = 3000
+        fq = os.path.join(a.work, "c10.fq")
+        write_fq(fq, synth_ids_varied(n, 10), synth_reads(n, 100, 80000, 10), synth_quals(n, 100, 10))
+        out = os.path.join(GOLD, "c10_full_o_t3.fqs")
+        subprocess.check_call([REF, "e", "-s", "-om", "o", "-t", "3", "-gs", "1", "-qm", "o", "-im", "o", "-v", "0",
+                               "-tmp", os.path.join(a.work, "tmpf_"), "-out", out, fq], stdout=subprocess.DEVNULL)
+        for tag, om, qm, im, t in (("s_i8_t4", "s", "8", "i", 4), ("s_oo_t2", "s", "o", "o", 2), ("o_i2_t5", "o", "2", "i", 5)):
+            out = os.path.join(a.work, f"c10_{tag}.fqs")
+            subprocess.check_call([REF, "e", "-s", "-om", om, "-t", str(t), "-gs", "1", "-qm", qm, "-im", im, "-v", "0",
+                                   "-tmp", os.path.join(a.work, "tmpf_"), "-out", out, fq], stdout=subprocess.DEVNULL)
+            json.dump(fdigest(out, {"input": "c10 (3000 x 100bp, G=80kbp, seed 10, synth_ids_varied)", "om": om, "qm": qm, "im": im, "threads": t}),
+                      open(os.path.join(GOLD, f"c10_full_{tag}.json"), "w"))
+        np_ = 2000
+        r1, r2 = synth_pairs(np_, 100, 60000, 11)
+        f1, f2 = os.path.join(a.work, "c11_1.fq"), os.path.join(a.work, "c11_2.fq")
+        write_fq(f1, synth_ids_varied(np_, 11, 1), r1, synth_quals(np_, 100, 11))
+        write_fq(f2, synth_ids_varied(np_, 11, 2), r2, synth_quals(np_, 100, 12))
+        for tag, om, qm, im, t in (("s_o4_t3", "s", "4", "o", 3), ("o_io_t2", "o", "o", "i", 2)):
+            out = os.path.join(a.work, f"c11_{tag}.fqs")
+            subprocess.check_call([REF, "e", "-p", "-om", om, "-t", str(t), "-gs", "1", "-qm", qm, "-im", im, "-v", "0",
+                                   "-tmp", os.path.join(a.work, "tmpf_"), "-out", out, f1, f2], stdout=subprocess.DEVNULL)
+            json.dump(fdigest(out, {"input": "c11 (2000 pairs x 100bp, G=60kbp, seed 11, synth_ids_varied mates 1/2)", "om": om, "qm": qm, "im": im,
+                                    "threads": t, "paired": True}), open(os.path.join(GOLD, f"c11_pe_full_{tag}.json"), "w"))
     if a.only in ("", "c3"):
         fq = os.path.join(a.work, "c3.fq")
         if not os.path.exists(fq):
