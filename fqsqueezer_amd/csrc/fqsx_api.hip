@@ -520,6 +520,9 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
   {
     u64 need = 0;
     for (u32 t = 0; t < T; ++t) need = std::max<u64>(need, (u64)c->h_filled[t] + 2 * wbases[t] + 64);
+#ifdef FQSX_TIMING
+    if (generation % 64 == 63) fprintf(stderr, "[timing] block %u: ctx slots used by worker 0: %u, capacity %llu\n", generation, c->h_filled[0], (unsigned long long)c->ctx_cap);
+#endif
     if (need * 2 > c->ctx_cap && (rc = grow_ctx(c, pow2_at_least(need * 2)))) return rc;
   }
   cfg.bases = d_bases;

@@ -508,7 +508,14 @@ FQ_DEV u64 siv_range_sum(Wk &w, u64 start, u64 end) {
   w.st[ST_SIV_WORDS] += w1 - w0 + 1;
   return wave_sum64(r);
 }
-// #{ i in (lo,hi) : field(i) == flag }  -- the p-mer rank sweep of compress_prefix_sorted, dna.cpp:600-605
+// #{ i in (lo,hi) : field(i) == flag }  -- the p-mer rank sweep of compress_prefix_sorted, dna.cpp:600-605.
+// Pure streaming: every word of [w0,w1] is counted unmasked with eight independent 16-byte loads per lane in
+// flight (8 KiB per wave iteration; a lone wave is latency-bound, so bytes in flight are what sets its rate),
+// then the fields outside (lo,hi) in the two end words are taken off again.
+FQ_DEV u64 siv_eq_count(u64 d, u64 rep) {
+  d ^= rep;
+  return popc64(~(d | (d >> 1)) & 0x5555555555555555ULL);
+}
 FQ_DEV u64 siv_count_equal(Wk &w, u64 lo, u64 hi, u64 flag) {
   u64 start = lo + 1;
   if (start >= hi) return 0;
@@ -518,26 +525,37 @@ FQ_DEV u64 siv_count_equal(Wk &w, u64 lo, u64 hi, u64 flag) {
   const u64 m0 = ~0ull << (2 * (start & 31));
   const u64 m1 = (hi & 31) ? ~(~0ull << (2 * (hi & 31))) : ~0ull;
   u64 r = 0;
-  u64 x = w0 + FQ_LANE;
-  // four independent 512-byte wave loads in flight per iteration (the sweep is pure streaming)
-  for (; x + 3 * FQ_WAVE <= w1; x += 4 * FQ_WAVE) {
-    u64 d0 = sv[x], d1 = sv[x + FQ_WAVE], d2 = sv[x + 2 * FQ_WAVE], d3 = sv[x + 3 * FQ_WAVE];
-    d0 ^= rep; d1 ^= rep; d2 ^= rep; d3 ^= rep;
-    u64 e0 = ~(d0 | (d0 >> 1)) & 0x5555555555555555ULL, e1 = ~(d1 | (d1 >> 1)) & 0x5555555555555555ULL;
-    u64 e2 = ~(d2 | (d2 >> 1)) & 0x5555555555555555ULL, e3 = ~(d3 | (d3 >> 1)) & 0x5555555555555555ULL;
-    if (x == w0) e0 &= m0;
-    if (x + 3 * FQ_WAVE == w1) e3 &= m1;
-    r += popc64(e0) + popc64(e1) + popc64(e2) + popc64(e3);
+  u64 x = w0;
+  const u64 end = w1 + 1;
+  if ((x & 1) && x < end) {  // align to 16 bytes
+    if (FQ_LANE == 0) r += siv_eq_count(sv[x], rep);
+    ++x;
   }
-  for (; x <= w1; x += FQ_WAVE) {
-    u64 d = sv[x] ^ rep;
-    u64 eq = ~(d | (d >> 1)) & 0x5555555555555555ULL;
-    if (x == w0) eq &= m0;
-    if (x == w1) eq &= m1;
-    r += popc64(eq);
+  struct alignas(16) W2 { u64 a, b; };
+  const W2 *sv2 = (const W2 *)(sv + x);   // x is even: 16-byte aligned (the vector itself is page aligned)
+  const u64 pairs = (end - x) >> 1;
+  u64 q = FQ_LANE;
+  for (; q + 7 * FQ_WAVE < pairs; q += 8 * FQ_WAVE) {
+    W2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = sv2[q + k * FQ_WAVE];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += siv_eq_count(v[k].a, rep) + siv_eq_count(v[k].b, rep);
   }
+  for (; q < pairs; q += FQ_WAVE) {
+    W2 v = sv2[q];
+    r += siv_eq_count(v.a, rep) + siv_eq_count(v.b, rep);
+  }
+  x += 2 * pairs;
+  if (x < end && FQ_LANE == 0) r += siv_eq_count(sv[x], rep);   // odd tail word
+  r = wave_sum64(r);
+  // fields of the end words that lie outside (lo,hi)
+  u64 d0 = sv[w0] ^ rep, d1 = sv[w1] ^ rep;
+  u64 e0 = ~(d0 | (d0 >> 1)) & 0x5555555555555555ULL, e1 = ~(d1 | (d1 >> 1)) & 0x5555555555555555ULL;
+  if (w0 == w1) r -= popc64(e0 & ~(m0 & m1));
+  else r -= popc64(e0 & ~m0) + popc64(e1 & ~m1);
   w.st[ST_SIV_WORDS] += w1 - w0 + 1;
-  return wave_sum64(r);
+  return r;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -546,17 +564,26 @@ FQ_DEV void rc_put(Wk &w, u8 b) {
   if (w.enc.len < w.enc.cap) w.enc.out[w.enc.len] = b; else w.err = FQSX_ERR_OUT_OVERFLOW;
   ++w.enc.len;
 }
-// exact range / tot for tot < 2^16 without the 64-bit software divide: high word by 32-bit
-// division, the remaining < 2^48 dividend in fp64 with a +-1 fix-up (sub_rc.h:63)
+// exact range / tot for tot < 2^16 without the 64-bit software divide or an IEEE fp64 division: hardware
+// reciprocal (~26 bits) + one Newton step (~52 bits), high word and the remaining < 2^48 dividend each by one fp64
+// multiply with a +-1 fix-up (sub_rc.h:63).  tools/ubench checks it against u64 division on 1.3e9 operands.
 FQ_DEV u64 div_u64_small(u64 x, u32 d) {
-  const double rd = 1.0 / (double)d;
-  u32 hi = (u32)(x >> 32), lo = (u32)x;
+  const double dd = (double)d;
+#ifndef FQSX_EMU
+  const double r0 = __builtin_amdgcn_rcp(dd);
+  const double rd = __builtin_fma(r0, __builtin_fma(-dd, r0, 1.0), r0);
+#else
+  const double rd = 1.0 / dd;
+#endif
+  const u32 hi = (u32)(x >> 32), lo = (u32)x;
   u32 qh = (u32)((double)hi * rd);
   u32 ph = qh * d;
   if (ph > hi) { --qh; ph -= d; } else if (hi - ph >= d) { ++qh; ph += d; }
-  u64 rem = ((u64)(hi - ph) << 32) | lo;   // < d * 2^32 <= 2^48
-  u64 q = (u64)((double)rem * rd);
-  u64 prod = q * d;
+  const u32 r1 = hi - ph;                                                        // < d
+  const double remd = __builtin_fma((double)r1, 4294967296.0, (double)lo);      // exact: < 2^48
+  u32 q = (u32)(remd * rd);                                                      // rem / d < 2^32
+  const u64 rem = ((u64)r1 << 32) | lo;
+  const u64 prod = (u64)q * d;
   if (prod > rem) --q;
   else if (rem - prod >= d) ++q;
   return ((u64)qh << 32) + q;
@@ -652,6 +679,9 @@ FQ_DEV u32 ctx_find(Wk &w, u32 tag, u64 key, Slot4 &s) {
   for (u64 n = 0; n <= w.cfg->ctx_cap_mask; ++n) {
     const u64 *p = (const u64 *)__builtin_assume_aligned(b + 4 * h, 32);
     u64 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];  // one 32-byte slot, fetched in one round trip
+#ifndef FQSX_EMU
+    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));   // ... which the compiler would otherwise split by sinking the key load below the tag test
+#endif
     w.st[ST_CTX] += 1;
     u32 tg = slot_tag(q1);
     if (!tg) return FQSX_NIL;
