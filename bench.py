@@ -48,10 +48,11 @@ def main() -> None:
     ap.add_argument("--genome", type=int, default=5_000_000)
     ap.add_argument("--gs", type=int, default=5)
     ap.add_argument("--threads", type=int, default=64, help="logical workers T (header byte, <=255)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=200_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the extra host-buffer (PCIe-inclusive) pass")
     ap.add_argument("--no-t255", action="store_true", help="skip the extra pass with 255 workers")
+    ap.add_argument("--concurrent", type=int, default=4, help="extra pass: this many codec instances at once (0/1 = skip)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,6 +167,34 @@ def main() -> None:
         t255 = {"value": round(n_bases / dt / 1e6, 4), "unit": "Mbases/s", "bits_per_base": round(8.0 * nb / n_bases, 5),
                 "note": "same file with header T=255 (valid .fqs, decodable by fqs d; not producible by the reference CLI)"}
 
+    # K independent codec instances at once on this GPU (own tables, own stream, one host thread each): one file with
+    # T = 64 occupies 64 of the 256 CUs, so a GPU has room for several files.  Extra information, not `value`.
+    conc = None
+    if world == 1 and a.concurrent > 1:
+        import threading
+        outs = [0] * a.concurrent
+
+        def run(k):
+            c = DnaCodec(header, device=local_rank)
+            nb = 0
+            for g, (d_b, d_o, off) in enumerate(dev_blocks):
+                nb += c.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g, collect=False)
+            outs[k] = nb
+            c.close()
+
+        th = [threading.Thread(target=run, args=(k,)) for k in range(a.concurrent)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        conc = {"instances": a.concurrent, "value": round(a.concurrent * n_bases / dt / 1e6, 4), "unit": "Mbases/s",
+                "identical_output": len(set(outs)) == 1 and outs[0] == dna_bytes,
+                "note": "independent compressions of the workload file running concurrently on one GPU (aggregate rate)"}
+
     # HBM traffic of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/traffic.json), if recorded
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -189,7 +218,7 @@ def main() -> None:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2+rank), -om s -gs {a.gs} -qm n -im n",
                    "workers_T": a.threads, "blocks": len(blocks), "per_gpu": "one independent file per GPU"},
-        "bits_per_base": round(8.0 * dna_bytes / n_bases, 5), "pcie_inclusive_mbases_s": pcie, "workers_255": t255,
+        "bits_per_base": round(8.0 * dna_bytes / n_bases, 5), "pcie_inclusive_mbases_s": pcie, "workers_255": t255, "concurrent_files": conc,
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
@@ -199,25 +228,36 @@ def main() -> None:
 
 
 def cpu_baseline(a, hp, reads, rec):
-    """Times the unmodified reference (oracle/_ref/fqs-1.1, built by oracle/Makefile) on the first
-    `cpu_sample_reads` reads of the same synthetic file; falls back to the oracle restatement."""
+    """Times the unmodified reference (oracle/_ref/fqs-1.1, built by oracle/Makefile) on the first `cpu_sample_reads`
+    reads of the same synthetic file (default: the whole workload, ~35 s at -t 64) and, to expose its fixed start-up
+    (table allocation, ~18 s at -t 64), on a 1000-read file with the same command line; falls back to the oracle
+    restatement when the binary is absent."""
     from fqsqueezer_amd.synth import write_fastq
     n = min(a.cpu_sample_reads, a.reads)
     ref = os.path.join(ROOT, "oracle", "_ref", "fqs-1.1")
     cores = os.cpu_count() or 1
     if os.path.exists(ref):
-        t = max(1, min(64, cores))
-        with tempfile.TemporaryDirectory(prefix="fqsx_bench_") as td:
-            fq = os.path.join(td, "s.fq")
-            write_fastq(fq, reads[:n], rec.qual[:n])
+        t = max(1, min(a.threads, 64, cores))
+
+        def run(fq, td):
             cmd = [ref, "e", "-s", "-om", "s", "-t", str(t), "-gs", str(a.gs), "-qm", "n", "-im", "n", "-v", "0",
                    "-tmp", os.path.join(td, "tmp_"), "-out", os.path.join(td, "o.fqs"), fq]
             t0 = time.perf_counter()
             subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            dt = time.perf_counter() - t0
+            return time.perf_counter() - t0
+
+        with tempfile.TemporaryDirectory(prefix="fqsx_bench_") as td:
+            fq, tiny = os.path.join(td, "s.fq"), os.path.join(td, "t.fq")
+            write_fastq(fq, reads[:n], rec.qual[:n])
+            write_fastq(tiny, reads[:1000], rec.qual[:1000])
+            st = run(tiny, td)
+            dt = run(fq, td)
         return {"value": round(n * a.len / dt / 1e6, 4), "unit": "Mbases/s", "cores": t, "kind": "reference",
+                "post_startup_value": round(n * a.len / max(dt - st, 1e-9) / 1e6, 4), "startup_s": round(st, 2),
                 "sample": f"first {n} reads of the workload file, `fqs-1.1 e -s -om s -t {t} -gs {a.gs} -qm n -im n`, "
-                          f"whole-process wall {dt:.1f}s (includes its binning/sort pre-pass); host has {cores} logical CPUs"}
+                          f"whole-process wall {dt:.1f}s (includes its binning/sort pre-pass and {st:.1f}s of start-up measured "
+                          f"on a 1000-read file; post_startup_value excludes the latter); host has {cores} logical CPUs; "
+                          f"same -t as the GPU run's T, i.e. the same bitstream"}
     from oracle.pyoracle import OracleCodec
     sub = hp.Records(rec.ids[:n], reads[:n], rec.qual[:n])
     oc = OracleCodec(hp.make_header(a.threads, "se_sorted", a.gs))
