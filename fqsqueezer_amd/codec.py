@@ -58,6 +58,7 @@ def _load(path: str):
     lib.fqsx_id_create.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     lib.fqsx_id_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.fqsx_id_destroy.argtypes = [C.c_void_p]
+    lib.fqsx_sort_order.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     lib.fqsx_last_error.restype = C.c_char_p
     lib.fqsx_version.restype = C.c_char_p
     return lib
@@ -183,6 +184,21 @@ class MetaCodec:
             self.close()
         except Exception:
             pass
+
+
+def sort_order(bases: np.ndarray, read_off: np.ndarray, device: int = 0, lib_path: Optional[str] = None) -> List[np.ndarray]:
+    """Read order of `fqs e -om s` (fqsx_sort_order: GPU radix sort + ranks, host replay of std::sort per bin).
+    Returns one index array per non-empty bin, in bin order -- the same shape hostpipe.sorted_order_exact returns."""
+    lib = load_library(lib_path)
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+    n = len(read_off) - 1
+    order = np.empty(max(n, 1), dtype=np.uint32)
+    bins = np.zeros(257, dtype=np.uint32)
+    rc = lib.fqsx_sort_order(bases.ctypes.data, read_off.ctypes.data, n, device, order.ctypes.data, bins.ctypes.data)
+    if rc:
+        raise FqsxError(f"fqsx_sort_order: {rc}: {lib.fqsx_last_error().decode()}")
+    return [order[bins[b]:bins[b + 1]].astype(np.int64) for b in range(256) if bins[b + 1] > bins[b]]
 
 
 class IdCodec:

@@ -1087,3 +1087,143 @@ int fqsx_qual_encode_block(fqsx_qual *q, const uint8_t *quals, const uint64_t *o
 }
 
 }  // extern "C"
+
+// =======================================================================================================
+// Read ordering of sorted mode: GPU radix sort + dense ranks, host replay of std::sort
+// =======================================================================================================
+#include "fqsx_sort.h"
+
+FQ_KERNEL64 void k_sort_info(SortCfg c) {
+  FQ_SHARED u32 lds[64 * 10];
+  sort_info_body(c, FQ_BLOCK, lds);
+}
+FQ_KERNEL64 void k_sort_iota(SortCfg c) { sort_iota_body(c, FQ_BLOCK); }
+FQ_KERNEL64 void k_sort_count(SortCfg c) {
+  FQ_SHARED u32 hist[256];
+  sort_count_body(c, FQ_BLOCK, hist);
+}
+FQ_KERNEL64 void k_sort_scan(SortCfg c) { sort_scan_body(c, FQ_BLOCK); }
+FQ_KERNEL64 void k_sort_dstoff(SortCfg c) { sort_dstoff_body(c); }
+FQ_KERNEL64 void k_sort_scatter(SortCfg c) {
+  FQ_SHARED u32 cursor[256];
+  FQ_SHARED u32 ld[64];
+  sort_scatter_body(c, FQ_BLOCK, cursor, ld);
+}
+FQ_KERNEL64 void k_sort_flags(SortCfg c) { sort_flags_body(c, FQ_BLOCK); }
+FQ_KERNEL64 void k_sort_rank(SortCfg c) { sort_rank_body(c); }
+
+static int sort_rank_impl(fqsx_dna *c, const u8 *bases, const u64 *off, u32 n, std::vector<u32> &rank, u32 *passes_out) {
+  int rc;
+  void *p = nullptr;
+  SortCfg s;
+  memset(&s, 0, sizeof(s));
+  s.n = n;
+  s.n_tiles = (n + FQSX_SORT_TILE - 1) / FQSX_SORT_TILE;
+  const u64 nb = off[n];
+  if ((rc = dalloc(c, &p, nb ? nb : 8, false))) return rc;
+  u8 *d_bases = (u8 *)p;
+  if ((rc = dalloc(c, &p, ((u64)n + 1) * sizeof(u64), false))) return rc;
+  u64 *d_off = (u64 *)p;
+  if ((rc = h2d(c, d_bases, bases, nb))) return rc;
+  if ((rc = h2d(c, d_off, off, ((u64)n + 1) * sizeof(u64)))) return rc;
+  s.bases = d_bases; s.off = d_off;
+  if ((rc = dalloc(c, &p, (u64)n * 4, false))) return rc; s.perm_in = (u32 *)p;
+  if ((rc = dalloc(c, &p, (u64)n * 4, false))) return rc; s.perm_out = (u32 *)p;
+  if ((rc = dalloc(c, &p, (u64)s.n_tiles * 256 * 4, false))) return rc; s.tile_hist = (u32 *)p;
+  if ((rc = dalloc(c, &p, 256 * 4, false))) return rc; s.dig_tot = (u32 *)p;
+  if ((rc = dalloc(c, &p, 257 * 4, false))) return rc; s.dig_off = (u32 *)p;
+  if ((rc = dalloc(c, &p, (u64)n * 4, false))) return rc; s.flags = (u32 *)p;
+  if ((rc = dalloc(c, &p, (u64)n * 4, false))) return rc; s.rank = (u32 *)p;
+  if ((rc = dalloc(c, &p, (u64)s.n_tiles * 10 * 4, false))) return rc; s.info = (u32 *)p;
+  LAUNCH(c, 2, k_sort_info, s.n_tiles, 64, s);
+  LAUNCH(c, 2, k_sort_iota, s.n_tiles, 64, s);
+  std::vector<u32> info((u64)s.n_tiles * 10);
+  if ((rc = d2h_sync(c, info.data(), s.info, info.size() * 4))) return rc;
+  u32 mn = 0xffffffffu, mx = 0, set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (u32 t = 0; t < s.n_tiles; ++t) {
+    mn = std::min(mn, info[(u64)t * 10]);
+    mx = std::max(mx, info[(u64)t * 10 + 1]);
+    for (u32 k = 0; k < 8; ++k) set[k] |= info[(u64)t * 10 + 2 + k];
+  }
+  // raw-byte tie-break (io.h:518-526): only bytes outside A/C/G can differ between reads equal under N->T
+  u32 n_other = 0;
+  for (u32 b = 0; b < 256; ++b)
+    if ((set[b >> 5] >> (b & 31)) & 1) s.raw_code[b] = (u8)(++n_other);
+  u32 passes = 0;
+  auto pass = [&](u32 kind, u32 arg) -> int {
+    s.kind = kind; s.arg = arg;
+    LAUNCH(c, 2, k_sort_count, s.n_tiles, 64, s);
+    LAUNCH(c, 2, k_sort_scan, 256, 64, s);
+    LAUNCH(c, 2, k_sort_dstoff, 1, 64, s);
+    LAUNCH(c, 2, k_sort_scatter, s.n_tiles, 64, s);
+    std::swap(s.perm_in, s.perm_out);
+    ++passes;
+    return FQSX_OK;
+  };
+  // least significant key first
+  if (n_other >= 2) {
+    s.raw_bits = n_other <= 3 ? 2 : n_other <= 15 ? 4 : 8;
+    const u32 per = 8 / s.raw_bits;
+    for (u32 b = (mx + per - 1) / per; b-- > 0;) if ((rc = pass(SORT_RAW, b))) return rc;
+  }
+  if (mn != mx)
+    for (u32 k = 0; k < 4 && (mx >> (8 * k)); ++k) if ((rc = pass(SORT_LEN, k))) return rc;
+  for (u32 b = (mx + 3) / 4; b-- > 0;) if ((rc = pass(SORT_NT, b))) return rc;
+  LAUNCH(c, 2, k_sort_flags, s.n_tiles, 64, s);
+  LAUNCH(c, 2, k_sort_rank, 1, 64, s);
+  rank.resize(n);
+  if ((rc = d2h_sync(c, rank.data(), s.rank, (u64)n * 4))) return rc;
+  if (passes_out) *passes_out = passes;
+  return FQSX_OK;
+}
+
+extern "C" int fqsx_sort_order(const uint8_t *bases, const uint64_t *read_off, uint32_t n_reads, int device, uint32_t *order_out,
+                               uint32_t *bin_start /*[257]*/) {
+  if (!bases || !read_off || !order_out || !bin_start) { g_err = "null argument"; return FQSX_E_ARG; }
+  for (u32 b = 0; b <= 256; ++b) bin_start[b] = 0;
+  if (n_reads == 0) return FQSX_OK;
+#ifndef FQSX_EMU
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available (libfqsx has no CPU path)"; return FQSX_E_NO_DEVICE; }
+  if (device < 0 || device >= ndev) { g_err = "bad device ordinal"; return FQSX_E_ARG; }
+  HIPCHK(hipSetDevice(device));
+#endif
+  fqsx_dna mem;
+  fqsx_dna *c = &mem;
+  c->T = 1; c->device = device; c->profiling = false;
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamCreate(&c->stream));
+#endif
+  std::vector<u32> rank;
+  int rc = sort_rank_impl(c, bases, read_off, n_reads, rank, nullptr);
+#ifndef FQSX_EMU
+  (void)hipStreamSynchronize(c->stream);
+#endif
+  std::vector<void *> a = c->allocs;
+  for (void *p : a) dfree(c, p);
+#ifndef FQSX_EMU
+  (void)hipStreamDestroy(c->stream);
+#endif
+  if (rc) return rc;
+  // bins in input order (preprocess_se, application.cpp:383-391: a position past the read counts as code 3 there
+  // because it lands on the line feed), then libstdc++'s std::sort per bin on the ranks
+  auto nt = [](u8 ch) -> u32 { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u; };
+  std::vector<u32> bin(n_reads);
+  for (u32 r = 0; r < n_reads; ++r) {
+    const u64 b = read_off[r];
+    const u32 len = (u32)(read_off[r + 1] - b);
+    u32 id = 0;
+    for (u32 i = 0; i < 4; ++i) id = (id << 2) | (i < len ? nt(bases[b + i]) : 3u);
+    bin[r] = id;
+    ++bin_start[id + 1];
+  }
+  for (u32 b = 0; b < 256; ++b) bin_start[b + 1] += bin_start[b];
+  std::vector<u32> cur(bin_start, bin_start + 256);
+  std::vector<std::pair<u32, u32>> v(n_reads);   // (rank, read), grouped by bin, input order inside a bin
+  for (u32 r = 0; r < n_reads; ++r) v[cur[bin[r]]++] = std::make_pair(rank[r], r);
+  for (u32 b = 0; b < 256; ++b)
+    std::sort(v.begin() + bin_start[b], v.begin() + bin_start[b + 1],
+              [](const std::pair<u32, u32> &x, const std::pair<u32, u32> &y) { return x.first < y.first; });
+  for (u32 i = 0; i < n_reads; ++i) order_out[i] = v[i].second;
+  return FQSX_OK;
+}

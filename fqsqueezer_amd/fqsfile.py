@@ -9,7 +9,13 @@ from typing import Optional
 import numpy as np
 
 from . import hostpipe as hp
-from .codec import DnaCodec, IdCodec, MetaCodec, QualCodec
+from .codec import DnaCodec, IdCodec, MetaCodec, QualCodec, sort_order
+
+
+def _gpu_groups(rec: hp.Records, device: int, lib_path: Optional[str]):
+    """Sorted-mode read order from the GPU pre-pass (bins + per-bin order incl. the reference's order of equal reads)."""
+    bases, off = hp.block_arrays(rec, np.arange(len(rec), dtype=np.int64))
+    return sort_order(bases, off, device=device, lib_path=lib_path)
 
 
 def _encode(header: bytes, blocks, arrays, sizes_of, paired: bool, device: int, lib_path: Optional[str]) -> bytes:
@@ -52,7 +58,6 @@ def compress_records(rec: hp.Records, threads: int, order: str = "s", genome_siz
     """`fqs e -s -om <order> -t <threads> -gs <g> -qm <..> -im <..>` on single-end records."""
     mode = "se_sorted" if order == "s" else "se_original"
     header = hp.make_header(threads, mode, genome_size_mbp, quality_mode, id_mode, quality_thr)
-    full = quality_mode != "none" or id_mode != "none"
     sizes = rec.record_sizes()
 
     def arrays(idx):
@@ -61,7 +66,8 @@ def compress_records(rec: hp.Records, threads: int, order: str = "s", genome_siz
         quals = hp.qual_arrays(rec, idx)[0] if quality_mode != "none" else None
         return bases, off, ids, id_off, quals
 
-    return _encode(header, hp.form_blocks(rec, mode, exact_ties=full), arrays, lambda idx: sizes[idx], False, device, lib_path)
+    groups = _gpu_groups(rec, device, lib_path) if mode == "se_sorted" else None
+    return _encode(header, hp.form_blocks(rec, mode, groups=groups), arrays, lambda idx: sizes[idx], False, device, lib_path)
 
 
 def compress_records_pe(rec1: hp.Records, rec2: hp.Records, threads: int, order: str = "s", genome_size_mbp: int = 3100,
@@ -83,4 +89,5 @@ def compress_records_pe(rec1: hp.Records, rec2: hp.Records, threads: int, order:
         z[0::2], z[1::2] = s1[idx], s2[idx]
         return z
 
-    return _encode(header, hp.form_blocks_pe(rec1, rec2, mode), arrays, sizes_of, True, device, lib_path)
+    groups = _gpu_groups(rec1, device, lib_path) if mode == "pe_sorted" else None   # mates follow mate 1's order, io.h:541-550
+    return _encode(header, hp.form_blocks_pe(rec1, rec2, mode, groups=groups), arrays, sizes_of, True, device, lib_path)

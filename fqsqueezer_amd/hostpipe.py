@@ -135,16 +135,20 @@ def sorted_order(rec: Records) -> List[np.ndarray]:
     return [np.asarray(x, dtype=np.int64) for x in out]
 
 
-def form_blocks(rec: Records, dna_mode: str = "se_sorted", exact_ties: bool = False) -> List[np.ndarray]:
+def form_blocks(rec: Records, dna_mode: str = "se_sorted", exact_ties: bool = False,
+                groups: "List[np.ndarray] | None" = None) -> List[np.ndarray]:
     """Partition the input into reads blocks exactly as the reference's reader
     does (CReadsBlock::Read, reads_block.h:119-139): records are appended until
     fewer than 102400 bytes of the 16 MiB buffer remain.  In sorted mode every
     non-empty bin is a separate input file (compress_se_files, application.cpp:538-569).
     exact_ties: order reads with identical DNA exactly as the reference's std::sort does (matters only for
     the id / quality / meta streams, whose records follow the DNA order).
+    groups: precomputed per-bin read order (e.g. from codec.sort_order, the GPU pre-pass).
     Returns index arrays (into `rec`), one per block, in file order."""
     sizes = rec.record_sizes()
-    if dna_mode == "se_sorted":
+    if groups is not None:
+        pass
+    elif dna_mode == "se_sorted":
         groups = sorted_order_exact(rec) if exact_ties else sorted_order(rec)
     else:
         groups = [np.arange(len(rec), dtype=np.int64)]
@@ -315,12 +319,13 @@ def sorted_order_exact(rec: Records) -> List[np.ndarray]:
     return out
 
 
-def form_blocks_pe(rec1: Records, rec2: Records, dna_mode: str = "pe_sorted") -> List[np.ndarray]:
+def form_blocks_pe(rec1: Records, rec2: Records, dna_mode: str = "pe_sorted", groups: "List[np.ndarray] | None" = None) -> List[np.ndarray]:
     """Blocks of *pair* indices (CReadsBlock::Read(f1,f2), reads_block.h:141-166: pairs are appended
     until fewer than 2*102400 bytes remain; sorted mode: one input file pair per non-empty bin, mates
     follow mate 1's order, io.h:541-550)."""
     sizes = rec1.record_sizes() + rec2.record_sizes()
-    groups = sorted_order_exact(rec1) if dna_mode == "pe_sorted" else [np.arange(len(rec1), dtype=np.int64)]
+    if groups is None:
+        groups = sorted_order_exact(rec1) if dna_mode == "pe_sorted" else [np.arange(len(rec1), dtype=np.int64)]
     blocks: List[np.ndarray] = []
     for g in groups:
         cs = np.cumsum(sizes[g])

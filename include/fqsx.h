@@ -120,6 +120,15 @@ int fqsx_id_encode_block(fqsx_id *, const uint8_t *ids, const uint64_t *id_off, 
                          const uint8_t **streams, uint64_t *lens);
 void fqsx_id_destroy(fqsx_id *);
 
+/* Read order of `fqs e -om s` with the string work on the GPU.  Replaces preprocess_se
+ * (fqs/application.cpp:349-412: 256 bins by the first four bases, N->T) plus CSortedFASTQFile::sort_reads on every
+ * bin (fqs/io.h:499-528).  The GPU radix-sorts the reads by the comparator's keys and gives every read a dense
+ * rank; the host then runs the same libstdc++ std::sort per bin on the ranks, which reproduces the reference's
+ * order of reads that compare equal (ids and qualities follow it).  order_out[n_reads] = read indices, bin after
+ * bin; bin_start[257] = offsets of the bins inside order_out. */
+int fqsx_sort_order(const uint8_t *bases, const uint64_t *read_off, uint32_t n_reads, int device,
+                    uint32_t *order_out, uint32_t *bin_start);
+
 /* Host-side read order inside one bin of `fqs e -om s`: std::sort with the comparator of
  * CSortedFASTQFile::sort_reads (fqs/io.h:499-528) applied to reads idx_in[0..n) (indices into off[]),
  * result in idx_out.  Same libstdc++ algorithm on the same initial order = same order of equal reads. */
