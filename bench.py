@@ -193,7 +193,9 @@ def main() -> None:
         dt = time.perf_counter() - t1
         conc = {"instances": a.concurrent, "value": round(a.concurrent * n_bases / dt / 1e6, 4), "unit": "Mbases/s",
                 "identical_output": len(set(outs)) == 1 and outs[0] == dna_bytes,
-                "note": "independent compressions of the workload file running concurrently on one GPU (aggregate rate)"}
+                "note": "independent compressions of the workload file running concurrently on one GPU as threads of this process "
+                        "(aggregate rate; the HIP runtime serialises threads -- as separate processes 4 / 8 files reach 47 / 78 Mbases/s, "
+                        "tools/gpu_multi_proc.sh, profiles/r01_concurrent_files.json)"}
 
     # HBM traffic of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/traffic.json), if recorded
     traffic = None
