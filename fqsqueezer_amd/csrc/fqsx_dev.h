@@ -31,6 +31,12 @@ struct WgShared {
   u64 pv_b[FQSX_SPEC], pv_s[FQSX_SPEC], pv_pd[FQSX_SPEC], pv_pr[FQSX_SPEC];
   u8 pv_flag[FQSX_SPEC];       // PV_* bits
   u64 lev_tmp[10];             // level keys of a position coded outside the fast path
+  // fast_run: per-position results of the lane-parallel context search / model stage
+  u32 fr_idx[64], fr_c0[64], fr_thr[64], fr_vis[64];   // final slot, its counter, threshold to re-validate (or ~0), slots visited
+  u64 fr_q1[64], fr_q2[64], fr_q3[64];                 // the final slot's counter|tag|total and statistics at run start
+  u64 fr_same[64];                                     // lanes of the run that end in the same slot
+  u32 fr_f[64], fr_c[64], fr_t[64];                    // range-coder triple of the position
+  u8 fr_lvl[64], fr_bad[64];
   u8 r2c[FQSX_RD_LDS];         // paired-end: codes of the second mate
   u64 pe_cand[512];            // paired-end: candidate partner b-mers (value | count << 2k)
   u64 pe_top[64];
@@ -1556,6 +1562,195 @@ FQ_DEV u64 letters_before(Wk &w, const u8 *p, u32 i, u32 size, u32 hist_start) {
   return ctx;
 }
 
+// ---------------------------------------------------------------------------------------
+// A run of consecutive positions settled by stage P (level bmer, counts and rank known), coded with the context
+// search and the model arithmetic LANE-PARALLEL, one position per lane, under three assumptions that are then
+// validated in position order: (1) the starting level (int)(avg + 0.49) stays what it is at the run's start,
+// (2) no context is created, (3) no counter comparison of the search flips and no model rescales because of the
+// run's own earlier positions.  Counters and model statistics only grow by one use per position, so the state a
+// position sees is (state at run start) + (uses by earlier positions of the run that end in the same slot),
+// which a few ballots give.  The first position that breaks an assumption ends the run there; it (and only it)
+// goes through the sequential find_leveled / slot_encode.  What stays serial is what has to be: the fp64 average
+// (two dependent operations per position) and the range coder (one division per position).
+// Returns the number of positions coded (0: the first position needs the sequential routine).
+struct RoHit { u32 idx, counter; u64 q1, q2, q3; bool present; };
+FQ_DEV RoHit ctx_probe_ro(Wk &w, u32 tag, u64 key, u32 &vis) {
+  RoHit r;
+  r.present = false; r.idx = FQSX_NIL; r.counter = 0; r.q1 = r.q2 = r.q3 = 0;
+  const u64 *b = ctx_base(w);
+  u64 h = ctx_hash(w, tag, key);
+  for (u64 n = 0; n <= w.cfg->ctx_cap_mask; ++n) {
+    const u64 *p = (const u64 *)__builtin_assume_aligned(b + 4 * h, 32);
+    const u64 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    ++vis;
+    const u32 tg = slot_tag(q1);
+    if (!tg) return r;
+    if (tg == tag && q0 == key) { r.present = true; r.idx = (u32)h; r.counter = (u32)q1; r.q1 = q1; r.q2 = q2; r.q3 = q3; return r; }
+    h = (h + 1) & w.cfg->ctx_cap_mask;
+  }
+  return r;
+}
+FQ_DEV u32 fast_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
+  WgShared *sm = w.sm;
+  const int s0 = (int)(w.avg_code + 0.49);
+  const u32 n_levels = 7;
+  u64 Z = 0, BAD = 0, SM[5] = {0, 0, 0, 0, 0};
+  FQ_SYNC();
+  // ---- stage S: read-only search per position against the table as it is now
+  for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
+    const bool act = t < len;
+    const u32 r = act ? sm->sp_rsym[j0 + t] : 5u;
+#if FQ_WAVE > 1
+    Z = wave_ballot(r == 0);
+    for (u32 x = 0; x < 5; ++x) SM[x] = wave_ballot(r == x);
+#else
+    Z |= (u64)(r == 0) << t;
+    for (u32 x = 0; x < 5; ++x) SM[x] |= (u64)(r == x) << t;
+#endif
+  }
+  for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
+    bool bad = t >= len;
+    u32 fin = FQSX_NIL, c0 = 0, thr = ~0u, vis = 0, lvl = 0;
+    u64 q1 = 0, q2 = 0, q3 = 0;
+    if (!bad) {
+      // r_sym history before this position: the run's earlier ranks, then the incoming history (dna.cpp:664-671)
+      const u32 hist = t >= 8 ? popc64((Z >> (t - 8)) & 0xffull) : popc64(Z & ((1ull << t) - 1ull)) + popc64(ctx_r_sym & ((1ull << (8 - t)) - 1ull));
+      const u64 rs = (u64)hist << SH_RSYM;
+      const u64 *lev = sm->sp_key[j0 + t];
+      RoHit h = ctx_probe_ro(w, 1, LEVKEY(s0), vis);
+      int i = s0;
+      if (h.present) {
+        if (h.counter < code_thr(s0)) thr = code_thr(s0);
+        else {
+          RoHit last = h;
+          for (i = s0 + 1; i < (int)n_levels; ++i) {
+            RoHit q = ctx_probe_ro(w, 1, LEVKEY(i), vis);
+            if (!q.present) break;
+            last = q;
+            if (q.counter < code_thr(i)) { thr = code_thr(i); break; }
+          }
+          if (thr == ~0u) {          // every level from s0 up to i-1 is full
+            --i;
+            if (i + 1 < (int)n_levels) bad = true;   // the deepest one would be cloned: sequential routine
+          }
+          h = last;
+        }
+      } else {
+        for (i = s0 - 1; i >= 0; --i) {
+          h = ctx_probe_ro(w, 1, LEVKEY(i), vis);
+          if (h.present) break;
+        }
+        if (i < 0) bad = true;       // level 0 would be created from the template
+        else if (h.counter >= code_thr(i)) { if (i + 1 < (int)n_levels) bad = true; }   // clone
+        else thr = code_thr(i);
+      }
+      if (!bad) { fin = h.idx; c0 = h.counter; q1 = h.q1; q2 = h.q2; q3 = h.q3; lvl = (u32)i; }
+    }
+    sm->fr_idx[t] = fin; sm->fr_c0[t] = c0; sm->fr_thr[t] = thr; sm->fr_vis[t] = vis; sm->fr_lvl[t] = (u8)lvl;
+    sm->fr_q1[t] = q1; sm->fr_q2[t] = q2; sm->fr_q3[t] = q3;
+    sm->fr_bad[t] = bad ? 1 : 0;
+  }
+  FQ_SYNC();
+  // ---- lanes that end in the same slot
+#if FQ_WAVE > 1
+  {
+    const u32 t = FQ_LANE;
+    const u32 mine = sm->fr_idx[t];
+    const bool ok = !sm->fr_bad[t];
+    u64 rem = wave_ballot(ok), same = 0;
+    while (rem) {
+      const u32 lead = ctz64(rem);
+      const u32 li = wave_bcast32(mine, lead);
+      const u64 g = wave_ballot(ok && mine == li);
+      if (ok && mine == li) same = g;
+      rem &= ~g;
+    }
+    sm->fr_same[t] = same;
+  }
+#else
+  for (u32 t = 0; t < 64; ++t) {
+    u64 same = 0;
+    if (!sm->fr_bad[t])
+      for (u32 u = 0; u < 64; ++u) same |= (u64)(!sm->fr_bad[u] && sm->fr_idx[u] == sm->fr_idx[t]) << u;
+    sm->fr_same[t] = same;
+  }
+#endif
+  FQ_SYNC();
+  // ---- validation of assumption (3) and the model arithmetic, per position
+  for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
+    bool bad = sm->fr_bad[t] != 0;
+    u32 f = 0, c = 0, tot = 0;
+    if (!bad) {
+      const u64 below = sm->fr_same[t] & ((1ull << t) - 1ull);
+      const u32 occ = popc64(below);
+      const u32 thr = sm->fr_thr[t];
+      if (thr != ~0u && sm->fr_c0[t] + occ >= thr) bad = true;           // an earlier position of the run filled the context
+      tot = (u32)(sm->fr_q1[t] >> 48) + 4 * occ;
+      if (tot + 4 >= (1u << 15)) bad = true;                              // this use rescales the model (rc.h:186-197)
+      const u64 q2 = sm->fr_q2[t], q3 = sm->fr_q3[t];
+      u32 st[5] = {(u32)(q2 & 0xffff), (u32)((q2 >> 16) & 0xffff), (u32)((q2 >> 32) & 0xffff), (u32)(q2 >> 48), (u32)(q3 & 0xffff)};
+      const u32 r = sm->sp_rsym[j0 + t];
+      for (u32 x = 0; x < 5; ++x) {
+        st[x] += 4 * popc64(below & SM[x]);
+        if (x < r) c += st[x];
+      }
+      f = st[r];
+    }
+    sm->fr_f[t] = f; sm->fr_c[t] = c; sm->fr_t[t] = tot;
+#if FQ_WAVE > 1
+    BAD = wave_ballot(bad);
+#else
+    BAD |= (u64)bad << t;
+#endif
+  }
+  FQ_SYNC();
+  u32 L = BAD ? ctz64(BAD) : 64u;
+  // ---- assumption (1) and the running average, in position order
+  {
+    double avg = w.avg_code;
+    u32 t = 0;
+    for (; t < L; ++t) {
+      if ((int)(avg + 0.49) != s0) break;
+      avg = ema_update(avg, (double)sm->fr_lvl[t]);
+    }
+    L = t;
+    if (L == 0) return 0;
+    w.avg_code = avg;
+  }
+  // ---- commit: the last position of every slot writes the slot's counter and statistics
+  const u64 within = L >= 64 ? ~0ull : (1ull << L) - 1ull;
+  u32 vis_sum = 0;
+  FQ_SYNC_MEM();
+  for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
+    u32 vis = 0;
+    if (t < L) {
+      vis = sm->fr_vis[t];
+      const u64 grp = sm->fr_same[t] & within;
+      if ((grp >> t) == 1ull) {       // no later position of the run ends here
+        const u32 r = sm->sp_rsym[j0 + t];
+        const u64 q2 = sm->fr_q2[t], q3 = sm->fr_q3[t];
+        u32 st[5] = {(u32)(q2 & 0xffff), (u32)((q2 >> 16) & 0xffff), (u32)((q2 >> 32) & 0xffff), (u32)(q2 >> 48), (u32)(q3 & 0xffff)};
+        for (u32 x = 0; x < 5; ++x) st[x] += 4 * popc64(grp & SM[x]);
+        (void)r;
+        const u32 uses = popc64(grp);
+        const u64 tot = (sm->fr_q1[t] >> 48) + 4ull * uses;
+        u64 *p = ctx_base(w) + 4 * (u64)sm->fr_idx[t];
+        p[1] = (sm->fr_q1[t] & 0x0000ffff00000000ULL) | (tot << 48) | (u64)(sm->fr_c0[t] + uses);
+        p[2] = (u64)st[0] | ((u64)st[1] << 16) | ((u64)st[2] << 32) | ((u64)st[3] << 48);
+        p[3] = (q3 & ~0xffffULL) | st[4];
+      }
+    }
+    vis_sum += vis;
+  }
+  FQ_SYNC_MEM();
+  w.st[ST_CTX] += wave_sum32(vis_sum);
+  // ---- the range coder, in position order
+  for (u32 t = 0; t < L; ++t) rc_encode(w, sm->fr_f[t], sm->fr_c[t], sm->fr_t[t]);
+  // r_sym history after the run
+  for (u32 t = 0; t < L; ++t) ctx_r_sym = ((ctx_r_sym << 1) + ((Z >> t) & 1ull)) & 0xff;
+  return L;
+}
+
 // compress_suffix, dna.cpp:674-877, as chunks of stage P (parallel) -> stage C (the serial loop below:
 // context look-up + range coding, plus the complete reference logic for positions P could not
 // settle) -> stage Q (parallel mailbox appends)
@@ -1570,6 +1765,15 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
     speculate(w, p, size, i, n, reversed);
     TM_END(w, TM_SPEC, t_sp);
     TM_COUNT(w, CN_CHUNK);
+    u64 Fm = 0, Rm = 0;   // positions settled by stage P; settled positions whose repair fires
+    for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
+      const bool f = t < n && sm->sp_flag[t] == 1, r = f && sm->sp_rep[t] != 0xff;
+#if FQ_WAVE > 1
+      Fm = wave_ballot(f); Rm = wave_ballot(r);
+#else
+      Fm |= (u64)f << t; Rm |= (u64)r << t;
+#endif
+    }
     u32 q_done = 0;   // chunk positions whose mailbox entries are already in the lists
     u32 w_pos = 0;    // w's k-mers = state before position w_pos of the chunk
     u32 m = 0;        // committed positions
@@ -1586,16 +1790,32 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       }
       TM_BEGIN(t_code);
       if (flag == 1) {
-        // fast path: level bmer; only the adaptive model and the range coder are serial
-        const u64 rs = (u64)popc64(ctx_r_sym) << SH_RSYM;
-        Slot4 s;
-        u32 idx = find_leveled(w, 1, sm->sp_key[j], rs, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
-        u32 r_sym = sm->sp_rsym[j];
-        if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
-        ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;
+        // fast path: level bmer.  A run of settled positions goes through fast_run (lane-parallel search and model
+        // arithmetic); the position that ends a run early takes the sequential routine.
+        const u64 fm = Fm >> j, rm = Rm >> j;
+        const u32 nf = ~fm ? ctz64(~fm) : 64u;                                  // consecutive settled positions from j
+        const u64 rr = nf >= 64 ? rm : rm & ((1ull << nf) - 1ull);
+        const u32 len = rr ? ctz64(rr) + 1 : nf;                                // a firing repair ends the run after its position
+        u32 L = fast_run(w, j, len, ctx_r_sym);
+        if (L == 0) {
+          const u64 rs = (u64)popc64(ctx_r_sym) << SH_RSYM;
+          Slot4 s;
+          u32 idx = find_leveled(w, 1, sm->sp_key[j], rs, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
+          u32 r_sym = sm->sp_rsym[j];
+          if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
+          ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;
+          L = 1;
+          TM_COUNT(w, CN_P2);
+        }
+        j += L - 1;   // the last position coded
+        const u32 pos = i + j;
+        const u32 sym = rd_sym(w, p, pos, size);
+        const u64 sym_k = sym == 4 ? 0 : sym;
         const u32 rep = sm->sp_rep[j];
         TM_END(w, TM_FAST, t_code);
-        TM_COUNT(w, CN_FAST);
+#ifdef FQSX_TIMING
+        w.tm[CN_FAST] += L;
+#endif
         if (rep != 0xff) {  // repair_kmers_existing fires (dna.cpp:362-369,856-863)
           load_state(w, j);
           replace_last_all(w, sym_k);
