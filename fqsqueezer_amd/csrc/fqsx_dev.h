@@ -21,7 +21,10 @@ struct WgShared {
   u64 sp_sdir[6][FQSX_SPEC];   // rolled k-mers after insert_zero: pm, sm, bm, pm_u, sm_u, bm_u
   u64 sp_src[6][FQSX_SPEC];
   u8 sp_scur[6][FQSX_SPEC];
-  u64 sp_key[FQSX_SPEC][7];    // context keys of the 7 levels (r_sym field left 0)
+  u64 sp_key[FQSX_SPEC][10];   // context keys of the position's symbol: 7 code levels (r_sym field left 0) or 10 letter levels
+  u8 sp_kind[FQSX_SPEC];       // how the position's symbol is coded: SK_* (set by stage P for settled positions, else by stage C)
+  u64 sp_cq[FQSX_SPEC];        // SK_RANK_PENDING: the four counts, 16 bits each
+  u8 sp_lvz[FQSX_SPEC];        // SK_RANK_PENDING: level | cor_zone << 4
   u32 sp_cnt[FQSX_SPEC];       // 4 x 8-bit counts
   u8 sp_flag[FQSX_SPEC];       // 0 slow path, 1 b-mer hit (fast path), 3 slow path with known global b-mer miss
   u8 sp_rsym[FQSX_SPEC];       // rank of the read's symbol under those counts
@@ -50,6 +53,7 @@ struct WgShared {
   u8 sx_flag[FQSX_SPEC];       // SX_* bits
 };
 enum { SX_VALID = 1, SX_LB = 2, SX_S = 4, SX_LS = 8 };
+enum { SK_NONE = 0, SK_RANK = 1, SK_LETTER = 2, SK_RANK_PENDING = 3, SK_LETTER_PENDING = 4 };
 enum { PV_B = 1, PV_S = 2, PV_P = 4, PV_PHID = 8, PV_PCAND = 16 };
 
 struct C4 { u32 c[4]; };
@@ -1480,6 +1484,7 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
       }
     }
     sm->sp_flag[j] = (u8)flag;
+    sm->sp_kind[j] = flag == 1 ? SK_RANK : SK_NONE;
     sm->sp_rep[j] = (u8)rep;
     // mailbox entries of this position (dna.cpp:818-852), k-mers after replace_last(sym)
     km_replace_last(pm, symk); km_replace_last(sk, symk); km_replace_last(bm, symk);
@@ -1563,16 +1568,17 @@ FQ_DEV u64 letters_before(Wk &w, const u8 *p, u32 i, u32 size, u32 hist_start) {
 }
 
 // ---------------------------------------------------------------------------------------
-// A run of consecutive positions settled by stage P (level bmer, counts and rank known), coded with the context
-// search and the model arithmetic LANE-PARALLEL, one position per lane, under three assumptions that are then
-// validated in position order: (1) the starting level (int)(avg + 0.49) stays what it is at the run's start,
-// (2) no context is created, (3) no counter comparison of the search flips and no model rescales because of the
-// run's own earlier positions.  Counters and model statistics only grow by one use per position, so the state a
-// position sees is (state at run start) + (uses by earlier positions of the run that end in the same slot),
-// which a few ballots give.  The first position that breaks an assumption ends the run there; it (and only it)
-// goes through the sequential find_leveled / slot_encode.  What stays serial is what has to be: the fp64 average
-// (two dependent operations per position) and the range coder (one division per position).
-// Returns the number of positions coded (0: the first position needs the sequential routine).
+// Stage C2: the symbols of a chunk's committed positions are coded AFTER stage C has resolved them all, because
+// nothing stage C decides depends on the context models or the coder.  code_keys finishes the level keys of the
+// positions stage P could not settle (lane-parallel), code_run then codes runs of consecutive positions with the
+// context search and the model arithmetic LANE-PARALLEL, one position per lane, under three assumptions that are
+// validated in position order: (1) the starting levels (int)(avg + 0.49) of the two hierarchies stay what they are
+// at the run's start, (2) no context is created, (3) no counter comparison of the search flips and no model rescales
+// because of the run's own earlier positions.  Counters and model statistics only grow by one use per position,
+// so the state a position sees is (state at run start) + (uses by earlier positions of the run that end in the
+// same slot), which a few ballots give.  The first position that breaks an assumption ends the run; it (and only
+// it) goes through the sequential find_leveled / slot_encode.  What stays serial is what has to be: the fp64
+// averages (two dependent operations per position) and the range coder (one division per position).
 struct RoHit { u32 idx, counter; u64 q1, q2, q3; bool present; };
 FQ_DEV RoHit ctx_probe_ro(Wk &w, u32 tag, u64 key, u32 &vis) {
   RoHit r;
@@ -1590,58 +1596,111 @@ FQ_DEV RoHit ctx_probe_ro(Wk &w, u32 tag, u64 key, u32 &vis) {
   }
   return r;
 }
-FQ_DEV u32 fast_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
+// level keys (and the rank) of the positions stage C resolved itself: rank-coded from counts, or plain letters
+FQ_DEV void code_keys(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reversed, u32 hist_start) {
   WgShared *sm = w.sm;
-  const int s0 = (int)(w.avg_code + 0.49);
-  const u32 n_levels = 7;
-  u64 Z = 0, BAD = 0, SM[5] = {0, 0, 0, 0, 0};
+  const DevCfg *cfg = w.cfg;
   FQ_SYNC();
-  // ---- stage S: read-only search per position against the table as it is now
+  for (u32 j = FQ_LANE; j < m; j += FQ_WAVE) {
+    const u32 kind = sm->sp_kind[j], pos = i0 + j, sym = rd_sym(w, p, pos, size);
+    if (kind == SK_RANK_PENDING) {
+      const u64 cq = sm->sp_cq[j];
+      C4 c;
+      c.c[0] = (u32)(cq & 0xffff); c.c[1] = (u32)((cq >> 16) & 0xffff); c.c[2] = (u32)((cq >> 32) & 0xffff); c.c[3] = (u32)(cq >> 48);
+      const u32 level = sm->sp_lvz[j] & 15u, cz = sm->sp_lvz[j] >> 4;
+      u64 lev[7];
+      if (!reversed) ctx_codes(lev, cfg, c, w.s_let, pos, level, cz, 0, size);
+      else ctx_codes(lev, cfg, c, w.s_let, size - pos - 1, level, cz, 0, ~0u);   // dna.cpp:750-752
+      for (u32 l = 0; l < 7; ++l) sm->sp_key[j][l] = lev[l];
+      sm->sp_rsym[j] = (u8)rank_sym(w, c, sym);
+      sm->sp_kind[j] = SK_RANK;
+    } else if (kind == SK_LETTER_PENDING) {
+      u64 lev[10];
+      ctx_letters_keys(lev, cfg, pos, letters_before(w, p, pos, size, hist_start), size);   // dna.cpp:520-528,776-785
+      for (u32 l = 0; l < 10; ++l) sm->sp_key[j][l] = lev[l];
+      sm->sp_rsym[j] = (u8)sym;
+      sm->sp_kind[j] = SK_LETTER;
+    }
+  }
+  FQ_SYNC();
+}
+// one position through the sequential routines
+FQ_DEV void code_one(Wk &w, u32 j, u64 &ctx_r_sym) {
+  WgShared *sm = w.sm;
+  const u32 sy = sm->sp_rsym[j];
+  Slot4 s;
+  if (sm->sp_kind[j] == SK_RANK) {
+    const u64 rs = (u64)popc64(ctx_r_sym) << SH_RSYM;
+    u32 idx = find_leveled(w, 1, sm->sp_key[j], rs, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
+    if (idx != FQSX_NIL) slot_encode(w, idx, s, sy);
+    ctx_r_sym = ((ctx_r_sym << 1) + (sy == 0 ? 1u : 0u)) & 0xff;   // update_ctx_r_sym, dna.cpp:664-671
+  } else {
+    u32 idx = find_leveled(w, 2, sm->sp_key[j], 0, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
+    if (idx != FQSX_NIL) slot_encode(w, idx, s, sy);
+    ctx_r_sym = (ctx_r_sym << 1) & 0xff;
+  }
+}
+// Returns the number of positions coded (0: position j0 needs the sequential routine).
+FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
+  WgShared *sm = w.sm;
+  const int s0c = (int)(w.avg_code + 0.49), s0l = (int)(w.avg_letters + 0.49);
+  u64 Z = 0, BAD = 0, KL = 0, SM[5] = {0, 0, 0, 0, 0};
+  FQ_SYNC_MEM();
+  // ---- per-symbol and per-kind masks of the run
   for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
     const bool act = t < len;
     const u32 r = act ? sm->sp_rsym[j0 + t] : 5u;
+    const bool letter = act && sm->sp_kind[j0 + t] == SK_LETTER;
 #if FQ_WAVE > 1
-    Z = wave_ballot(r == 0);
+    Z = wave_ballot(r == 0 && !letter);
+    KL = wave_ballot(letter);
     for (u32 x = 0; x < 5; ++x) SM[x] = wave_ballot(r == x);
 #else
-    Z |= (u64)(r == 0) << t;
+    Z |= (u64)(r == 0 && !letter) << t;
+    KL |= (u64)letter << t;
     for (u32 x = 0; x < 5; ++x) SM[x] |= (u64)(r == x) << t;
 #endif
   }
+  // ---- stage S: read-only search per position against the table as it is now
   for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
     bool bad = t >= len;
     u32 fin = FQSX_NIL, c0 = 0, thr = ~0u, vis = 0, lvl = 0;
     u64 q1 = 0, q2 = 0, q3 = 0;
     if (!bad) {
+      const bool letter = (KL >> t) & 1;
+      const u32 tag = letter ? 2u : 1u;
+      const int n_levels = letter ? 9 : 7, s0 = letter ? s0l : s0c;
       // r_sym history before this position: the run's earlier ranks, then the incoming history (dna.cpp:664-671)
       const u32 hist = t >= 8 ? popc64((Z >> (t - 8)) & 0xffull) : popc64(Z & ((1ull << t) - 1ull)) + popc64(ctx_r_sym & ((1ull << (8 - t)) - 1ull));
-      const u64 rs = (u64)hist << SH_RSYM;
+      const u64 rs = letter ? 0ull : (u64)hist << SH_RSYM;
       const u64 *lev = sm->sp_key[j0 + t];
-      RoHit h = ctx_probe_ro(w, 1, LEVKEY(s0), vis);
+      RoHit h = ctx_probe_ro(w, tag, LEVKEY(s0), vis);
       int i = s0;
       if (h.present) {
-        if (h.counter < code_thr(s0)) thr = code_thr(s0);
+        const u32 thr0 = letter ? letters_thr(s0) : code_thr(s0);   // only the first test uses the letters' own thresholds (dna.cpp:2244)
+        if (h.counter < thr0) thr = thr0;
         else {
           RoHit last = h;
-          for (i = s0 + 1; i < (int)n_levels; ++i) {
-            RoHit q = ctx_probe_ro(w, 1, LEVKEY(i), vis);
+          for (i = s0 + 1; i < n_levels; ++i) {
+            RoHit q = ctx_probe_ro(w, tag, LEVKEY(i), vis);
             if (!q.present) break;
             last = q;
             if (q.counter < code_thr(i)) { thr = code_thr(i); break; }
           }
           if (thr == ~0u) {          // every level from s0 up to i-1 is full
             --i;
-            if (i + 1 < (int)n_levels) bad = true;   // the deepest one would be cloned: sequential routine
+            if (last.counter >= code_thr(i) && i + 1 < n_levels) bad = true;   // the deepest one would be cloned: sequential routine
+            else if (last.counter < code_thr(i)) thr = code_thr(i);             // (letters: full by their own threshold only)
           }
           h = last;
         }
       } else {
         for (i = s0 - 1; i >= 0; --i) {
-          h = ctx_probe_ro(w, 1, LEVKEY(i), vis);
+          h = ctx_probe_ro(w, tag, LEVKEY(i), vis);
           if (h.present) break;
         }
         if (i < 0) bad = true;       // level 0 would be created from the template
-        else if (h.counter >= code_thr(i)) { if (i + 1 < (int)n_levels) bad = true; }   // clone
+        else if (h.counter >= code_thr(i)) { if (i + 1 < n_levels) bad = true; }   // clone
         else thr = code_thr(i);
       }
       if (!bad) { fin = h.idx; c0 = h.counter; q1 = h.q1; q2 = h.q2; q3 = h.q3; lvl = (u32)i; }
@@ -1705,33 +1764,36 @@ FQ_DEV u32 fast_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
   }
   FQ_SYNC();
   u32 L = BAD ? ctz64(BAD) : 64u;
-  // ---- assumption (1) and the running average, in position order
+  // ---- assumption (1) and the running averages, in position order
   {
-    double avg = w.avg_code;
+    double ac = w.avg_code, al = w.avg_letters;
     u32 t = 0;
     for (; t < L; ++t) {
-      if ((int)(avg + 0.49) != s0) break;
-      avg = ema_update(avg, (double)sm->fr_lvl[t]);
+      if ((KL >> t) & 1) {
+        if ((int)(al + 0.49) != s0l) break;
+        al = ema_update(al, (double)sm->fr_lvl[t]);
+      } else {
+        if ((int)(ac + 0.49) != s0c) break;
+        ac = ema_update(ac, (double)sm->fr_lvl[t]);
+      }
     }
     L = t;
     if (L == 0) return 0;
-    w.avg_code = avg;
+    w.avg_code = ac;
+    w.avg_letters = al;
   }
   // ---- commit: the last position of every slot writes the slot's counter and statistics
   const u64 within = L >= 64 ? ~0ull : (1ull << L) - 1ull;
   u32 vis_sum = 0;
-  FQ_SYNC_MEM();
   for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
     u32 vis = 0;
     if (t < L) {
       vis = sm->fr_vis[t];
       const u64 grp = sm->fr_same[t] & within;
       if ((grp >> t) == 1ull) {       // no later position of the run ends here
-        const u32 r = sm->sp_rsym[j0 + t];
         const u64 q2 = sm->fr_q2[t], q3 = sm->fr_q3[t];
         u32 st[5] = {(u32)(q2 & 0xffff), (u32)((q2 >> 16) & 0xffff), (u32)((q2 >> 32) & 0xffff), (u32)(q2 >> 48), (u32)(q3 & 0xffff)};
         for (u32 x = 0; x < 5; ++x) st[x] += 4 * popc64(grp & SM[x]);
-        (void)r;
         const u32 uses = popc64(grp);
         const u64 tot = (sm->fr_q1[t] >> 48) + 4ull * uses;
         u64 *p = ctx_base(w) + 4 * (u64)sm->fr_idx[t];
@@ -1746,9 +1808,25 @@ FQ_DEV u32 fast_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
   w.st[ST_CTX] += wave_sum32(vis_sum);
   // ---- the range coder, in position order
   for (u32 t = 0; t < L; ++t) rc_encode(w, sm->fr_f[t], sm->fr_c[t], sm->fr_t[t]);
-  // r_sym history after the run
+  // r_sym history after the run (a letter position shifts in a zero)
   for (u32 t = 0; t < L; ++t) ctx_r_sym = ((ctx_r_sym << 1) + ((Z >> t) & 1ull)) & 0xff;
   return L;
+}
+// all committed positions [0, m) of the chunk
+FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reversed, u32 hist_start, u64 &ctx_r_sym) {
+  if (m == 0) return;
+  TM_BEGIN(t_c2);
+  code_keys(w, p, size, i0, m, reversed, hist_start);
+  for (u32 j = 0; j < m && !w.err;) {
+    u32 L = code_run(w, j, m - j, ctx_r_sym);
+    if (L == 0) {
+      code_one(w, j, ctx_r_sym);
+      TM_COUNT(w, CN_P2);
+      L = 1;
+    }
+    j += L;
+  }
+  TM_END(w, TM_FAST, t_c2);
 }
 
 // compress_suffix, dna.cpp:674-877, as chunks of stage P (parallel) -> stage C (the serial loop below:
@@ -1790,31 +1868,19 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       }
       TM_BEGIN(t_code);
       if (flag == 1) {
-        // fast path: level bmer.  A run of settled positions goes through fast_run (lane-parallel search and model
-        // arithmetic); the position that ends a run early takes the sequential routine.
+        // settled by stage P (level bmer): nothing to resolve; skip the whole stretch of such positions up to the
+        // first one whose repair fires (their symbols are coded in stage C2, code_chunk)
         const u64 fm = Fm >> j, rm = Rm >> j;
         const u32 nf = ~fm ? ctz64(~fm) : 64u;                                  // consecutive settled positions from j
         const u64 rr = nf >= 64 ? rm : rm & ((1ull << nf) - 1ull);
-        const u32 len = rr ? ctz64(rr) + 1 : nf;                                // a firing repair ends the run after its position
-        u32 L = fast_run(w, j, len, ctx_r_sym);
-        if (L == 0) {
-          const u64 rs = (u64)popc64(ctx_r_sym) << SH_RSYM;
-          Slot4 s;
-          u32 idx = find_leveled(w, 1, sm->sp_key[j], rs, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
-          u32 r_sym = sm->sp_rsym[j];
-          if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
-          ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;
-          L = 1;
-          TM_COUNT(w, CN_P2);
-        }
-        j += L - 1;   // the last position coded
+        const u32 len = rr ? ctz64(rr) + 1 : nf;
+        j += len - 1;
         const u32 pos = i + j;
         const u32 sym = rd_sym(w, p, pos, size);
         const u64 sym_k = sym == 4 ? 0 : sym;
         const u32 rep = sm->sp_rep[j];
-        TM_END(w, TM_FAST, t_code);
 #ifdef FQSX_TIMING
-        w.tm[CN_FAST] += L;
+        w.tm[CN_FAST] += len;
 #endif
         if (rep != 0xff) {  // repair_kmers_existing fires (dna.cpp:362-369,856-863)
           load_state(w, j);
@@ -1896,28 +1962,28 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
             TM_END(w, TM_ROUGH, t_r);
           }
         }
+        TM_END(w, TM_SPRE, t_code);
+        TM_BEGIN(t_sc);
         // code the symbol (dna.cpp:737-801)
         if (level != LV_NONE && nrun_here < 2) {
           int cor_dist = level == LV_PMER ? (int)cfg->pmer : level == LV_SMER ? (int)cfg->smer : (int)cfg->bmer;
           int d = (int)pos - (int)w.cor_pos;
           u32 cor_zone = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
           if (rough) cor_zone = 3;
-          u64 lev[7];
-          if (!reversed) ctx_codes_wave(lev, cfg, counts, w.s_let, pos, level, cor_zone, ctx_r_sym, size);
-          else ctx_codes_wave(lev, cfg, counts, w.s_let, size - pos - 1, level, cor_zone, ctx_r_sym, ~0u);
           FQ_SYNC();
-          for (u32 l = 0; l < 7; ++l) sm->lev_tmp[l] = lev[l];
+          if (FQ_LANE == 0) {   // keys, rank and coding: stage C2
+            sm->sp_cq[j] = (u64)(counts.c[0] & 0xffff) | ((u64)(counts.c[1] & 0xffff) << 16) | ((u64)(counts.c[2] & 0xffff) << 32) | ((u64)(counts.c[3] & 0xffff) << 48);
+            sm->sp_lvz[j] = (u8)(level | (cor_zone << 4));
+            sm->sp_kind[j] = SK_RANK_PENDING;
+          }
           FQ_SYNC();
-          Slot4 s;
-          u32 idx = find_leveled(w, 1, sm->lev_tmp, 0, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
-          u32 r_sym = rank_sym(w, counts, sym);
-          if (idx != FQSX_NIL) slot_encode(w, idx, s, r_sym);
-          ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;  // update_ctx_r_sym, dna.cpp:664-671
         } else {
-          w.ctx_letters = letters_before(w, p, pos, size, hist_start);
-          code_letter(w, pos, sym, size);
-          ctx_r_sym = (ctx_r_sym << 1) & 0xff;
+          FQ_SYNC();
+          if (FQ_LANE == 0) sm->sp_kind[j] = SK_LETTER_PENDING;
+          FQ_SYNC();
         }
+        TM_END(w, TM_SCODE, t_sc);
+        TM_BEGIN(t_spo);
         // mailbox entries and context repair (dna.cpp:803-874)
         const bool lvl_sbm = level == LV_SMER || level == LV_BMER || level == LV_MIXED;
         if (loaded) {
@@ -1982,11 +2048,13 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
             }
           }
         }
+        TM_END(w, TM_SPOST, t_spo);
         TM_END(w, TM_SLOW, t_code);
       }
       m = j + 1;
     }
     if (dirty) TM_COUNT(w, CN_DIRTY);
+    code_chunk(w, p, size, i, m, reversed, hist_start, ctx_r_sym);
     flush_pushes(w, q_done, m);
     if (w_pos != m) {  // the last committed position went through the fast path: materialise its state
       const u32 sym = rd_sym(w, p, i + m - 1, size);
