@@ -577,14 +577,16 @@ FQ_DEV void rc_put(Wk &w, u8 b) {
 // exact range / tot for tot < 2^16 without the 64-bit software divide or an IEEE fp64 division: hardware
 // reciprocal (~26 bits) + one Newton step (~52 bits), high word and the remaining < 2^48 dividend each by one fp64
 // multiply with a +-1 fix-up (sub_rc.h:63).  tools/ubench checks it against u64 division on 1.3e9 operands.
-FQ_DEV u64 div_u64_small(u64 x, u32 d) {
+FQ_DEV double recip_u16(u32 d) {
   const double dd = (double)d;
 #ifndef FQSX_EMU
   const double r0 = __builtin_amdgcn_rcp(dd);
-  const double rd = __builtin_fma(r0, __builtin_fma(-dd, r0, 1.0), r0);
+  return __builtin_fma(r0, __builtin_fma(-dd, r0, 1.0), r0);
 #else
-  const double rd = 1.0 / dd;
+  return 1.0 / dd;
 #endif
+}
+FQ_DEV u64 div_u64_rd(u64 x, u32 d, double rd) {
   const u32 hi = (u32)(x >> 32), lo = (u32)x;
   u32 qh = (u32)((double)hi * rd);
   u32 ph = qh * d;
@@ -598,9 +600,11 @@ FQ_DEV u64 div_u64_small(u64 x, u32 d) {
   else if (rem - prod >= d) ++q;
   return ((u64)qh << 32) + q;
 }
-FQ_DEV void rc_encode(Wk &w, u32 freq, u32 cum, u32 tot) {
+FQ_DEV u64 div_u64_small(u64 x, u32 d) { return div_u64_rd(x, d, recip_u16(d)); }
+// rd = recip_u16(tot), computed off the serial chain where the caller can
+FQ_DEV void rc_encode_rd(Wk &w, u32 freq, u32 cum, u32 tot, double rd) {
   const u64 Top = 0x00ffffffffffffULL, M = 0xff00000000000000ULL;
-  u64 range = div_u64_small(w.enc.range, tot), low = w.enc.low;
+  u64 range = div_u64_rd(w.enc.range, tot, rd), low = w.enc.low;
   low += range * cum;
   range *= freq;
   while (range <= Top) {
@@ -613,6 +617,8 @@ FQ_DEV void rc_encode(Wk &w, u32 freq, u32 cum, u32 tot) {
   w.enc.range = range;
   w.st[ST_CODED] += 1;
 }
+
+FQ_DEV void rc_encode(Wk &w, u32 freq, u32 cum, u32 tot) { rc_encode_rd(w, freq, cum, tot, recip_u16(tot)); }
 
 // small direct-indexed adaptive model in HBM: N stats + total (CSimpleModel, rc.h:20-173; Encode rc.h:397-405)
 FQ_DEV void sm_encode(Wk &w, u16 *m, u32 n, u32 max_total, u32 x) {
@@ -1736,6 +1742,8 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
 #endif
   FQ_SYNC();
   // ---- validation of assumption (3) and the model arithmetic, per position
+  u32 lane_f = 0, lane_c = 0, lane_t = 1;       // GPU: the position's coder triple, reciprocal and average term stay in
+  double lane_rd = 0.0, lane_pl = 0.0;          // its lane's registers; the serial loops fetch them with v_readlane
   for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
     bool bad = sm->fr_bad[t] != 0;
     u32 f = 0, c = 0, tot = 0;
@@ -1755,10 +1763,13 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
       }
       f = st[r];
     }
-    sm->fr_f[t] = f; sm->fr_c[t] = c; sm->fr_t[t] = tot;
 #if FQ_WAVE > 1
+    lane_f = f; lane_c = c; lane_t = tot ? tot : 1u;
+    lane_rd = recip_u16(lane_t);
+    lane_pl = __dmul_rn(1.0 - 0.999, (double)sm->fr_lvl[t]);
     BAD = wave_ballot(bad);
 #else
+    sm->fr_f[t] = f; sm->fr_c[t] = c; sm->fr_t[t] = tot;
     BAD |= (u64)bad << t;
 #endif
   }
@@ -1769,6 +1780,17 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
     double ac = w.avg_code, al = w.avg_letters;
     u32 t = 0;
     for (; t < L; ++t) {
+#if FQ_WAVE > 1
+      // ema_update with its level term precomputed by the position's lane
+      const double pl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lane_pl), t), __builtin_amdgcn_readlane(__double2loint(lane_pl), t));
+      if ((KL >> t) & 1) {
+        if ((int)(al + 0.49) != s0l) break;
+        al = __dadd_rn(__dmul_rn(0.999, al), pl);
+      } else {
+        if ((int)(ac + 0.49) != s0c) break;
+        ac = __dadd_rn(__dmul_rn(0.999, ac), pl);
+      }
+#else
       if ((KL >> t) & 1) {
         if ((int)(al + 0.49) != s0l) break;
         al = ema_update(al, (double)sm->fr_lvl[t]);
@@ -1776,6 +1798,7 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
         if ((int)(ac + 0.49) != s0c) break;
         ac = ema_update(ac, (double)sm->fr_lvl[t]);
       }
+#endif
     }
     L = t;
     if (L == 0) return 0;
@@ -1807,7 +1830,15 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
   FQ_SYNC_MEM();
   w.st[ST_CTX] += wave_sum32(vis_sum);
   // ---- the range coder, in position order
+#if FQ_WAVE > 1
+  for (u32 t = 0; t < L; ++t) {
+    const double rd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lane_rd), t), __builtin_amdgcn_readlane(__double2loint(lane_rd), t));
+    rc_encode_rd(w, (u32)__builtin_amdgcn_readlane((int)lane_f, t), (u32)__builtin_amdgcn_readlane((int)lane_c, t),
+                 (u32)__builtin_amdgcn_readlane((int)lane_t, t), rd);
+  }
+#else
   for (u32 t = 0; t < L; ++t) rc_encode(w, sm->fr_f[t], sm->fr_c[t], sm->fr_t[t]);
+#endif
   // r_sym history after the run (a letter position shifts in a zero)
   for (u32 t = 0; t < L; ++t) ctx_r_sym = ((ctx_r_sym << 1) + ((Z >> t) & 1ull)) & 0xff;
   return L;
