@@ -264,19 +264,29 @@ FQ_DEV u64 tab_home(const KTab &t, u64 v) {
   u64 kern = (v >> 4) & ((1ull << (2 * t.k - 8)) - 1ull);
   return murmur64(kern) & t.cap_mask;
 }
-// one cluster scan: counts of the 4 sibling k-mers (_update_counts_full, ht_kmer.h:205-263)
-FQ_DEV void tab_scan(const KTab &t, u32 sub, u64 kmer_norm, bool is_dir, C4 &c, u64 &nslots) {
-  const u64 *s = t.slots + (u64)sub * t.stride;
+// one cluster scan: counts of the 4 sibling k-mers (_update_counts_full, ht_kmer.h:205-263), in two parts so that a
+// caller can have the first round trips of several independent scans in flight at once: tab_first issues the loads
+// of the first two slots, tab_rest consumes them and walks on while the cluster continues.
+struct TabIt { const u64 *s; u64 p, it0, it1; };
+FQ_DEV TabIt tab_first(const KTab &t, u32 sub, u64 kmer_norm) {
+  TabIt r;
+  r.s = t.slots + (u64)sub * t.stride;
+  r.p = tab_home(t, kmer_norm >> (64 - 2 * t.k));
+  r.it0 = r.s[r.p];
+  r.it1 = r.s[(r.p + 1) & t.cap_mask];
+  return r;
+}
+FQ_DEV void tab_rest(const KTab &t, const TabIt &f, u64 kmer_norm, bool is_dir, C4 &c, u64 &nslots) {
+  const u64 *s = f.s;
   const u32 k2 = 2 * t.k;
-  u64 v = kmer_norm >> (64 - k2);
-  u64 p = tab_home(t, v);
+  const u64 v = kmer_norm >> (64 - k2);
+  u64 p = f.p;
   const u64 cm = (1ull << t.cbits) - 1ull;
   const u64 lowmask = (1ull << (k2 - 2)) - 1ull;
   const u64 grp = is_dir ? (v >> 2) : (v & lowmask);
-  for (u64 n = 0; n <= t.cap_mask; n += 2) {
+  u64 it0 = f.it0, it1 = f.it1;
+  for (u64 n = 0;; n += 2) {
     // two consecutive slots per round trip (independent loads); most clusters end within them
-    const u64 p1 = (p + 1) & t.cap_mask;
-    const u64 it0 = s[p], it1 = s[p1];
     ++nslots;
     if (!it0) break;
     u64 iv = it0 >> t.cbits;
@@ -293,8 +303,15 @@ FQ_DEV void tab_scan(const KTab &t, u32 sub, u64 kmer_norm, bool is_dir, C4 &c, 
     } else {
       if ((iv & lowmask) == grp) c4_add(c, 3u - (u32)(iv >> (k2 - 2)), (u32)(it1 & cm));
     }
-    p = (p1 + 1) & t.cap_mask;
+    if (n + 2 > t.cap_mask) break;
+    p = (p + 2) & t.cap_mask;
+    it0 = s[p];
+    it1 = s[(p + 1) & t.cap_mask];
   }
+}
+FQ_DEV void tab_scan(const KTab &t, u32 sub, u64 kmer_norm, bool is_dir, C4 &c, u64 &nslots) {
+  const TabIt f = tab_first(t, sub, kmer_norm);
+  tab_rest(t, f, kmer_norm, is_dir, c, nslots);
 }
 // exact look-up (count(), ht_kmer.h:330-362,441-453)
 FQ_DEV u32 tab_count(const KTab &t, u32 sub, u64 kmer_norm, u64 &nslots) {
@@ -619,6 +636,31 @@ FQ_DEV void rc_encode_rd(Wk &w, u32 freq, u32 cum, u32 tot, double rd) {
 }
 
 FQ_DEV void rc_encode(Wk &w, u32 freq, u32 cum, u32 tot) { rc_encode_rd(w, freq, cum, tot, recip_u16(tot)); }
+// The same step with the division as an integer multiply-high by m = floor((2^64-1) / tot), 2 <= tot < 2^16 (computed
+// off the serial chain, one lane per position): for any range < 2^64, mulhi(range, m) is the quotient or one less.  Integer
+// only and wave-uniform, so the whole dependent chain of a position can run on the scalar unit.
+FQ_DEV u64 recip64_u16(u32 d) { return div_u64_rd(~0ull, d, recip_u16(d)); }
+FQ_DEV void rc_encode_m(Wk &w, u32 freq, u32 cum, u32 tot, u64 m) {
+  const u64 Top = 0x00ffffffffffffULL, M = 0xff00000000000000ULL;
+  u64 low = w.enc.low;
+#ifndef FQSX_EMU
+  u64 range = __umul64hi(w.enc.range, m);
+#else
+  u64 range = (u64)(((unsigned __int128)w.enc.range * m) >> 64);
+#endif
+  if (w.enc.range - range * tot >= tot) ++range;
+  low += range * cum;
+  range *= freq;
+  while (range <= Top) {
+    if ((low ^ (low + range)) & M) range = (low | Top) - low;
+    rc_put(w, (u8)(low >> 56));
+    low <<= 8;
+    range <<= 8;
+  }
+  w.enc.low = low;
+  w.enc.range = range;
+  w.st[ST_CODED] += 1;
+}
 
 // small direct-indexed adaptive model in HBM: N stats + total (CSimpleModel, rc.h:20-173; Encode rc.h:397-405)
 FQ_DEV void sm_encode(Wk &w, u16 *m, u32 n, u32 max_total, u32 x) {
@@ -1147,16 +1189,20 @@ FQ_DEV bool rough_p(Wk &w, C4 &counts) {  // find_counts_rough_p, dna.cpp:229-25
   w.st[ST_SIV_WORDS] += n;
   return c4_any(counts);
 }
-// find_counts_rough_s / _b, dna.cpp:257-330: Hamming-1 neighbourhood, probes batched, merges serial
-// probes of the Hamming-1 neighbourhood into the LDS batch; returns their number
+// find_counts_rough_s / _b, dna.cpp:257-330: Hamming-1 neighbourhood, probes batched, merges serial.
+// Of the 4 substitutions per position one is the k-mer itself, and every caller has just seen that k-mer miss in
+// this very table (find_counts probed it, or stage P did: the global tables do not change inside a kernel), so
+// that probe cannot contribute and is not issued: 3(k-1) probes, a single wave-wide round for k <= 22.  The
+// remaining probes keep the reference's (position, symbol) order.  Returns their number.
 FQ_DEV u32 rough_probe(Wk &w, const KTab &t, const KGeom &g, const Kmer &can) {
   WgShared *sm = w.sm;
-  const u32 n = 4 * (g.k - 1);
+  const u32 n = 3 * (g.k - 1);
   FQ_SYNC();
   for (u32 q = FQ_LANE; q < n; q += FQ_WAVE) {
-    u32 i = q >> 2;
-    u64 j = q & 3;
+    const u32 i = q / 3, r3 = q - 3 * i;
     u32 sh = 62 - 2 * i;
+    const u32 orig = (u32)((can.dir >> sh) & 3ull);
+    const u64 j = r3 + (r3 >= orig ? 1u : 0u);
     u64 d = (can.dir & ~(3ull << sh)) + (j << sh);
     sh = 64 - 2 * g.k + 2 * i;
     u64 r = (can.rc & ~(3ull << sh)) + ((3 - j) << sh);
@@ -1165,6 +1211,9 @@ FQ_DEV u32 rough_probe(Wk &w, const KTab &t, const KGeom &g, const Kmer &can) {
     sm->bk_dir[q] = nd ? 1 : 0;
   }
   batch_scan(w, t, true, n);
+  // the reference also issues the k-1 look-ups of the k-mer itself (a miss scans at least the empty slot)
+  w.st[ST_GPROBE] += g.k - 1;
+  w.st[ST_GSLOT] += g.k - 1;
   return n;
 }
 FQ_DEV bool rough_kt(Wk &w, const KTab &t, const KGeom &g, const Kmer &can, u32 rng, const Cinc &ci, C4 &counts) {
@@ -1436,7 +1485,20 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
     if (b_full) {
       bool nd = km_norm_dir(bm, cfg->gb);
       u64 key = nd ? bm.dir : bm.rc;
-      tab_scan(cfg->g_b, sb_owner(cfg, key), key, nd, c, ns);
+      // the rest of find_counts' cascade after a global b-mer miss (dna.cpp:478-499) -- local b, global s, local s
+      // -- applies in the common case of a full s-mer and no pending correction; its probes are independent of
+      // each other, so their first round trips are issued together with the b-mer's instead of one after another
+      const bool casc = bm.dir == bu.dir && sk.cur == cfg->gs.k;
+      const bool nds = km_norm_dir(sk, cfg->gs);
+      const u64 ks = nds ? sk.dir : sk.rc;
+      const TabIt fb = tab_first(cfg->g_b, sb_owner(cfg, key), key);
+      TabIt flb = fb, fs = fb, fls = fb;
+      if (casc) {
+        flb = tab_first(cfg->l_b, w.tid, key);
+        fs = tab_first(cfg->g_s, sb_owner(cfg, ks), ks);
+        fls = tab_first(cfg->l_s, w.tid, ks);
+      }
+      tab_rest(cfg->g_b, fb, key, nd, c, ns);
       ++np;
       if (c4_any(c)) {
         u32 sat = (c.c[0] == 63) + (c.c[1] == 63) + (c.c[2] == 63) + (c.c[3] == 63);
@@ -1454,30 +1516,27 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           rep = repair_decide(w, c, sym);
         }
       } else {
-        // global b-mer miss: rest of find_counts' cascade (dna.cpp:478-499) for the common case of a full
-        // s-mer and no pending correction; the local probes see the tables as of the last flush
+        // global b-mer miss; the local probes see the tables as of the last flush
         flag = 3;
         u32 xf = 0;
-        if (bm.dir == bu.dir && sk.cur == cfg->gs.k) {
+        if (casc) {
           xf = SX_VALID;
           C4 l;
           c4_zero(l);
-          tab_scan(cfg->l_b, w.tid, key, nd, l, nls);
+          tab_rest(cfg->l_b, flb, key, nd, l, nls);
           ++nlp;
           if (c4_any(l)) {
             xf |= SX_LB;
             sm->sx_lb[j] = l.c[0] | (l.c[1] << 8) | (l.c[2] << 16) | (l.c[3] << 24);
           } else {
-            const bool nds = km_norm_dir(sk, cfg->gs);
-            const u64 ks = nds ? sk.dir : sk.rc;
             c4_zero(l);
-            tab_scan(cfg->g_s, sb_owner(cfg, ks), ks, nds, l, ns);
+            tab_rest(cfg->g_s, fs, ks, nds, l, ns);
             ++np;
             if (c4_any(l)) {
               xf |= SX_S;
               sm->sx_s[j] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
             } else {
-              tab_scan(cfg->l_s, w.tid, ks, nds, l, nls);
+              tab_rest(cfg->l_s, fls, ks, nds, l, nls);
               ++nlp;
               if (c4_any(l)) {
                 xf |= SX_LS;
@@ -1652,6 +1711,7 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
   const int s0c = (int)(w.avg_code + 0.49), s0l = (int)(w.avg_letters + 0.49);
   u64 Z = 0, BAD = 0, KL = 0, SM[5] = {0, 0, 0, 0, 0};
   FQ_SYNC_MEM();
+  TM_BEGIN(t_s);
   // ---- per-symbol and per-kind masks of the run
   for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
     const bool act = t < len;
@@ -1716,6 +1776,8 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
     sm->fr_bad[t] = bad ? 1 : 0;
   }
   FQ_SYNC();
+  TM_END(w, TM_CR_S, t_s);
+  TM_BEGIN(t_mid);
   // ---- lanes that end in the same slot
 #if FQ_WAVE > 1
   {
@@ -1743,7 +1805,8 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
   FQ_SYNC();
   // ---- validation of assumption (3) and the model arithmetic, per position
   u32 lane_f = 0, lane_c = 0, lane_t = 1;       // GPU: the position's coder triple, reciprocal and average term stay in
-  double lane_rd = 0.0, lane_pl = 0.0;          // its lane's registers; the serial loops fetch them with v_readlane
+  double lane_pl = 0.0;                         // its lane's registers; the serial loops fetch them with v_readlane
+  u64 lane_m = 0;
   for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
     bool bad = sm->fr_bad[t] != 0;
     u32 f = 0, c = 0, tot = 0;
@@ -1765,7 +1828,7 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
     }
 #if FQ_WAVE > 1
     lane_f = f; lane_c = c; lane_t = tot ? tot : 1u;
-    lane_rd = recip_u16(lane_t);
+    lane_m = recip64_u16(lane_t);
     lane_pl = __dmul_rn(1.0 - 0.999, (double)sm->fr_lvl[t]);
     BAD = wave_ballot(bad);
 #else
@@ -1775,6 +1838,8 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
   }
   FQ_SYNC();
   u32 L = BAD ? ctz64(BAD) : 64u;
+  TM_END(w, TM_CR_MID, t_mid);
+  TM_BEGIN(t_avg);
   // ---- assumption (1) and the running averages, in position order
   {
     double ac = w.avg_code, al = w.avg_letters;
@@ -1801,10 +1866,12 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
 #endif
     }
     L = t;
+    TM_END(w, TM_CR_AVG, t_avg);
     if (L == 0) return 0;
     w.avg_code = ac;
     w.avg_letters = al;
   }
+  TM_BEGIN(t_rc);
   // ---- commit: the last position of every slot writes the slot's counter and statistics
   const u64 within = L >= 64 ? ~0ull : (1ull << L) - 1ull;
   u32 vis_sum = 0;
@@ -1832,15 +1899,16 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
   // ---- the range coder, in position order
 #if FQ_WAVE > 1
   for (u32 t = 0; t < L; ++t) {
-    const double rd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lane_rd), t), __builtin_amdgcn_readlane(__double2loint(lane_rd), t));
-    rc_encode_rd(w, (u32)__builtin_amdgcn_readlane((int)lane_f, t), (u32)__builtin_amdgcn_readlane((int)lane_c, t),
-                 (u32)__builtin_amdgcn_readlane((int)lane_t, t), rd);
+    const u64 m = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(lane_m >> 32), t) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)lane_m, t);
+    rc_encode_m(w, (u32)__builtin_amdgcn_readlane((int)lane_f, t), (u32)__builtin_amdgcn_readlane((int)lane_c, t),
+                (u32)__builtin_amdgcn_readlane((int)lane_t, t), m);
   }
 #else
   for (u32 t = 0; t < L; ++t) rc_encode(w, sm->fr_f[t], sm->fr_c[t], sm->fr_t[t]);
 #endif
   // r_sym history after the run (a letter position shifts in a zero)
   for (u32 t = 0; t < L; ++t) ctx_r_sym = ((ctx_r_sym << 1) + ((Z >> t) & 1ull)) & 0xff;
+  TM_END(w, TM_CR_RC, t_rc);
   return L;
 }
 // all committed positions [0, m) of the chunk
@@ -1848,6 +1916,7 @@ FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reverse
   if (m == 0) return;
   TM_BEGIN(t_c2);
   code_keys(w, p, size, i0, m, reversed, hist_start);
+  TM_END(w, TM_KEYS, t_c2);
   for (u32 j = 0; j < m && !w.err;) {
     u32 L = code_run(w, j, m - j, ctx_r_sym);
     if (L == 0) {
@@ -2269,90 +2338,81 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
 
 // lane-parallel insert of one mailbox chunk (<= 64 keys, all owned by `tid`) into a global
 // sub-table, RNG draws assigned in key order (InsertKmersToHT, dna.cpp:2426-2446; insert(),
-// ht_kmer.h:420-438).  Falls back to a serial pass when two keys of the batch interact.
+// ht_kmer.h:420-438).  Two keys of a batch interact when they target the same slot (the same key
+// twice, or two new keys racing for one empty slot): the batch is then applied in rounds, each round
+// taking the longest prefix of the remaining keys that is free of such pairs, and the rest probes
+// again after the round's stores -- exactly the sequential result, in 1-2 rounds instead of n steps.
 FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 tid, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
                          u64 &nslots, u32 &err) {
   (void)cfg;
   u64 *s = t.slots + (u64)tid * t.stride;
   const u64 cm = (1ull << t.cbits) - 1ull;
   const u32 lane = FQ_LANE;
-  u64 v = 0, pos = 0, item = 0;
-  bool act = lane < n, found = false;
-  if (act) {
-    v = keys[lane] >> (64 - 2 * t.k);
-    u64 p = tab_home(t, v);
-    for (u64 q = 0; q <= t.cap_mask; ++q) {
-      u64 it = s[p];
-      ++nslots;
-      if (!it) break;
-      if ((it >> t.cbits) == v) { found = true; item = it; break; }
-      p = (p + 1) & t.cap_mask;
-    }
-    pos = p;
-  }
-  // interaction test: two active lanes targeting the same slot (same key, or two new keys
-  // racing for one empty slot); a new key can also extend a cluster another lane scanned, but
-  // that lane then targets a different slot and stays correct
-  FQ_SYNC();
-  sm->bk_key[lane] = act ? pos : ~0ull;
-  FQ_SYNC();
-  bool clash = false;
-#if FQ_WAVE > 1
-  if (act)
-    for (u32 j = 0; j < n; ++j)
-      if (j != lane && sm->bk_key[j] == pos) clash = true;
-#endif
+  const u64 v = lane < n ? keys[lane] >> (64 - 2 * t.k) : 0;
+  const u64 home = tab_home(t, v);
   u32 filled = t.filled[tid];
-  u32 n_new = popc64(wave_ballot(act && !found));
-  if ((u64)(filled + n_new) * 10 >= (t.cap_mask + 1) * 9) { err = FQSX_ERR_GTAB_FULL; return; }
-  if (!wave_any(clash)) {
-    u32 cnt = (u32)(item & cm);
-    bool draw = act && found && cnt > ci.thr && cnt < ci.maxv;
-    u64 dm = wave_ballot(draw);
-    u32 my = popc64(dm & ((1ull << lane) - 1ull)), total = popc64(dm);
-    u32 idx = sm->mt_idx[rng];
-    u32 avail = idx >= 624 ? 0 : 624 - idx;
+  for (u32 done = 0; done < n;) {
+    u64 pos = 0, item = 0;
+    bool act = lane >= done && lane < n, found = false;
+    if (act) {
+      u64 p = home;
+      for (u64 q = 0; q <= t.cap_mask; ++q) {
+        u64 it = s[p];
+        ++nslots;
+        if (!it) break;
+        if ((it >> t.cbits) == v) { found = true; item = it; break; }
+        p = (p + 1) & t.cap_mask;
+      }
+      pos = p;
+    }
+    // a new key can also extend a cluster another lane scanned, but that lane then targets a
+    // different slot and stays correct
+    u32 lim = n;
+#if FQ_WAVE > 1
+    FQ_SYNC();
+    sm->bk_key[lane] = act ? pos : ~0ull;
+    FQ_SYNC();
+    bool clash = false;   // an earlier key of this round targets my slot
+    if (act)
+      for (u32 j = done; j < n; ++j)
+        if (j < lane && sm->bk_key[j] == pos) clash = true;
+    const u64 cl = wave_ballot(clash);
+    if (cl) lim = ctz64(cl);
+    act = act && lane < lim;
+#else
+    lim = done + 1;
+#endif
+    const u32 n_new = popc64(wave_ballot(act && !found));
+    if ((u64)(filled + n_new) * 10 >= (t.cap_mask + 1) * 9) { err = FQSX_ERR_GTAB_FULL; return; }
+    const u32 cnt = (u32)(item & cm);
+    const bool draw = act && found && cnt > ci.thr && cnt < ci.maxv;
+    const u64 dm = wave_ballot(draw);
     u32 r = 0;
-    if (draw && my < avail) r = mt_temper(sm->mt[rng][idx + my]);
-    if (total > avail) {
-      mt_twist(sm->mt[rng]);
-      if (draw && my >= avail) r = mt_temper(sm->mt[rng][my - avail]);
-      idx = total - avail;
-    } else
-      idx += total;
-    FQ_SYNC();
-    if (lane == 0) sm->mt_idx[rng] = idx;
-    FQ_SYNC();
+    if (dm) {
+      const u32 my = popc64(dm & ((1ull << lane) - 1ull)), total = popc64(dm);
+      u32 idx = sm->mt_idx[rng];
+      const u32 avail = idx >= 624 ? 0 : 624 - idx;
+      if (draw && my < avail) r = mt_temper(sm->mt[rng][idx + my]);
+      if (total > avail) {
+        mt_twist(sm->mt[rng]);
+        if (draw && my >= avail) r = mt_temper(sm->mt[rng][my - avail]);
+        idx = total - avail;
+      } else
+        idx += total;
+      FQ_SYNC();
+      if (lane == 0) sm->mt_idx[rng] = idx;
+      FQ_SYNC();
+    }
     if (act) {
       if (!found) s[pos] = (v << t.cbits) | 1ull;
       else if (cnt <= ci.thr) { if (cnt < (u32)cm) s[pos] = item + 1; }
       else if (draw && (r % (ci.mult * (cnt - ci.thr)) == 0)) s[pos] = item + 1;
     }
-    if (lane == 0) t.filled[tid] = filled + n_new;
-    FQ_SYNC_MEM();  // later batches of this wave read these slots from other lanes
-    return;
+    filled += n_new;
+    done = lim;
+    if (lane == 0 && done >= n) t.filled[tid] = filled;
+    FQ_SYNC_MEM();  // later rounds and batches of this wave read these slots from other lanes
   }
-  // serial fallback, in key order
-  FQ_SYNC_MEM();
-  for (u32 j = 0; j < n; ++j) {
-    u64 vj = keys[j] >> (64 - 2 * t.k);
-    u64 p = tab_home(t, vj);
-    for (u64 q = 0; q <= t.cap_mask; ++q) {
-      u64 it = s[p];
-      if (!it) {
-        s[p] = (vj << t.cbits) | 1ull;
-        t.filled[tid] = t.filled[tid] + 1;
-        break;
-      }
-      if ((it >> t.cbits) == vj) {
-        u32 cnt = (u32)(it & cm);
-        if (cnt < (u32)cm && cinc_inc1(sm, rng, ci, cnt) != cnt) s[p] = it + 1;
-        break;
-      }
-      p = (p + 1) & t.cap_mask;
-    }
-  }
-  FQ_SYNC_MEM();
 }
 
 // ---- stable partition of the mailbox lists by owner -----------------------------------------

@@ -29,6 +29,8 @@ cn["t_ctx_slot_load_s"] = st["timers"][23] * 1e-8  # n_p2 = context slot loads; 
 cn["slow: resolve counts s"] = st["timers"][26] * 1e-8
 cn["slow: keys+search+encode s"] = st["timers"][24] * 1e-8
 cn["slow: pushes+repairs s"] = st["timers"][25] * 1e-8
+for k, nm in enumerate(["code_run: S probes s", "code_run: same-slot+validate s", "code_run: avg loop s", "code_run: commit+rc s", "code_keys s"]):
+    cn[nm] = st["timers"][27 + k] * 1e-8
 tm = [x * 1e-8 for x in st["timers"][:10]]
 print(f"{n} reads T={T}: wall {dt:.2f}s  {n*100/dt/1e6:.2f} Mbases/s  kernels: {kt}")
 print("section seconds summed over workers:", {k: round(v, 3) for k, v in zip(names, tm)})
