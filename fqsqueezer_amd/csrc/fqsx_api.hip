@@ -34,10 +34,24 @@ extern "C" const char *fqsx_version(void) {
 
 // ---------------------------------------------------------------------------------------
 // kernels
+// One workgroup = one logical worker = two wavefronts: wave 0 resolves the worker's reads (k-mer tables, counts,
+// corrections, mailboxes) and queues every symbol in LDS, wave 1 codes them (context models + range coder).
+#ifndef FQSX_EMU
+FQ_KERNEL128 void k_encode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
+  FQ_SHARED WgShared sm;
+  if (threadIdx.x == 0) { sm.cq_tail = 0; sm.cq_head = 0; sm.cq_done = 0; }
+  FQ_WG_BARRIER();
+  if (FQ_WAVE_ID == 0) encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg, false, true);
+  else coder_segment_body(cfg, &sm, FQ_BLOCK, seg);
+}
+#define ENCODE_THREADS 128
+#else
 FQ_KERNEL64 void k_encode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
   FQ_SHARED WgShared sm;
   encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
 }
+#define ENCODE_THREADS 64
+#endif
 FQ_KERNEL64 void k_decode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
   FQ_SHARED WgShared sm;
   encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg, true);
@@ -561,7 +575,7 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
 
   for (u32 seg = 0; seg <= (u32)S; ++seg) {
     if (decode) LAUNCH(c, 0, k_decode_segment, T, 64, cfg, n_reads, (u32)S, seg);
-    else LAUNCH(c, 0, k_encode_segment, T, 64, cfg, n_reads, (u32)S, seg);
+    else LAUNCH(c, 0, k_encode_segment, T, ENCODE_THREADS, cfg, n_reads, (u32)S, seg);
     // size the global tables for this phase's inserts (exact per-owner demand)
     for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_count, T * cfg.mail[k].n_tiles, 64, cfg, k);
     for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_scan, T, 64, cfg, k);

@@ -51,9 +51,18 @@ struct WgShared {
   u64 sx_s[FQSX_SPEC];         // global s-mer counts, 4 x 16 bit
   u64 sx_ls[FQSX_SPEC];        // local s-mer counts, 4 x 16 bit
   u8 sx_flag[FQSX_SPEC];       // SX_* bits
+  // coding queue: every symbol of the worker's stream in stream order, as the context keys of a rank-/letter-coded
+  // position (SK_RANK / SK_LETTER) or as a finished (freq, cum, total) triple of a small direct-indexed model
+  // (SK_RAW: key[0] = freq | cum << 32, key[1] = total).  Filled by the wave that resolves the reads, drained by
+  // the coder (the same wave in the single-wave build, the workgroup's second wave in the encode kernel).
+  u64 cq_key[FQSX_CQ][10];
+  u8 cq_kind[FQSX_CQ];         // SK_* | SK_RESET
+  u8 cq_rsym[FQSX_CQ];
+  u32 cq_tail, cq_head, cq_done;   // entries published / consumed (free-running); producer finished
 };
 enum { SX_VALID = 1, SX_LB = 2, SX_S = 4, SX_LS = 8 };
-enum { SK_NONE = 0, SK_RANK = 1, SK_LETTER = 2, SK_RANK_PENDING = 3, SK_LETTER_PENDING = 4 };
+enum { SK_NONE = 0, SK_RANK = 1, SK_LETTER = 2, SK_RANK_PENDING = 3, SK_LETTER_PENDING = 4, SK_RAW = 5, SK_KIND_MASK = 7,
+       SK_RESET = 8 /* the r_sym history restarts at this entry (first symbol of a compress_suffix call, dna.cpp:676) */ };
 enum { PV_B = 1, PV_S = 2, PV_P = 4, PV_PHID = 8, PV_PCAND = 16 };
 
 struct C4 { u32 c[4]; };
@@ -81,6 +90,9 @@ struct Wk {
   u32 la[3];                            // list entries already applied to the local tables (b, s)
   u32 pq_n[2];                          // valid entries of the LDS mirror (b, s); ~0u = mirror overflowed
   bool lq_applied;                      // a local-table flush happened since the last stage P (its local probes are stale)
+  bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
+  u32 cq_tail, cq_head;                 // this wave's copy of its own queue index
+  u64 c_r_sym;                          // coder: ctx_r_sym, the last 8 rank-0 flags (dna.cpp:664-671)
   u64 st[ST_N];
   u64 tm[32];
   u32 err;
@@ -635,7 +647,37 @@ FQ_DEV void rc_encode_rd(Wk &w, u32 freq, u32 cum, u32 tot, double rd) {
   w.st[ST_CODED] += 1;
 }
 
-FQ_DEV void rc_encode(Wk &w, u32 freq, u32 cum, u32 tot) { rc_encode_rd(w, freq, cum, tot, recip_u16(tot)); }
+// producer side of the coding queue: wait until `need` more entries fit
+FQ_DEV bool cq_wait_space(Wk &w, u32 need) {
+  if (!w.piped) return true;
+  u32 spins = 0;
+  while (w.cq_tail - lds_load_acq(&w.sm->cq_head) + need > FQSX_CQ) {
+    fq_sleep();
+    if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; return false; }   // never spin forever on the GPU
+  }
+  return true;
+}
+FQ_DEV void cq_publish(Wk &w, u32 n) {
+  w.cq_tail += n;
+  if (w.piped) lds_store_rel(&w.sm->cq_tail, w.cq_tail);
+}
+// A symbol of a small direct-indexed model: coded right here, or (two-wave kernel) handed to the coder wave as a
+// finished triple so that it keeps its place in the stream.
+FQ_DEV void rc_encode(Wk &w, u32 freq, u32 cum, u32 tot) {
+  if (!w.piped) { rc_encode_rd(w, freq, cum, tot, recip_u16(tot)); return; }
+  if (!cq_wait_space(w, 1)) return;
+  WgShared *sm = w.sm;
+  const u32 e = w.cq_tail & (FQSX_CQ - 1);
+  FQ_SYNC();
+  if (FQ_LANE == 0) {
+    sm->cq_key[e][0] = (u64)freq | ((u64)cum << 32);
+    sm->cq_key[e][1] = tot;
+    sm->cq_kind[e] = SK_RAW;
+    sm->cq_rsym[e] = 5;
+  }
+  FQ_SYNC();
+  cq_publish(w, 1);
+}
 // The same step with the division as an integer multiply-high by m = floor((2^64-1) / tot), 2 <= tot < 2^16 (computed
 // off the serial chain, one lane per position): for any range < 2^64, mulhi(range, m) is the quotient or one less.  Integer
 // only and wave-uniform, so the whole dependent chain of a position can run on the scalar unit.
@@ -1315,6 +1357,19 @@ FQ_DEV bool repair_missing(Wk &w, u32 pos) {  // repair_kmers_missing, dna.cpp:3
 FQ_DEV void code_letter(Wk &w, u32 pos, u32 sym, u32 read_len) {  // dna.cpp:520-528,776-785
   u64 lev[10];
   ctx_letters_keys(lev, w.cfg, pos, w.ctx_letters, read_len);
+  if (w.piped) {   // the coder wave owns the context models
+    if (!cq_wait_space(w, 1)) return;
+    const u32 e = w.cq_tail & (FQSX_CQ - 1);
+    FQ_SYNC();
+    if (FQ_LANE == 0) {
+      for (u32 l = 0; l < 10; ++l) w.sm->cq_key[e][l] = lev[l];
+      w.sm->cq_kind[e] = SK_LETTER;
+      w.sm->cq_rsym[e] = (u8)sym;
+    }
+    FQ_SYNC();
+    cq_publish(w, 1);
+    return;
+  }
   FQ_SYNC();
   for (u32 l = 0; l < 10; ++l) w.sm->lev_tmp[l] = lev[l];
   FQ_SYNC();
@@ -1689,41 +1744,57 @@ FQ_DEV void code_keys(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reversed
   }
   FQ_SYNC();
 }
-// one position through the sequential routines
-FQ_DEV void code_one(Wk &w, u32 j, u64 &ctx_r_sym) {
+// one queue entry through the sequential routines
+FQ_DEV void code_one(Wk &w, u32 j) {
   WgShared *sm = w.sm;
-  const u32 sy = sm->sp_rsym[j];
+  const u32 e = j & (FQSX_CQ - 1);
+  const u32 kd = sm->cq_kind[e], kind = kd & SK_KIND_MASK;
+  const u32 sy = sm->cq_rsym[e];
+  if (kd & SK_RESET) w.c_r_sym = 0;
   Slot4 s;
-  if (sm->sp_kind[j] == SK_RANK) {
-    const u64 rs = (u64)popc64(ctx_r_sym) << SH_RSYM;
-    u32 idx = find_leveled(w, 1, sm->sp_key[j], rs, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
+  if (kind == SK_RANK) {
+    const u64 rs = (u64)popc64(w.c_r_sym) << SH_RSYM;
+    u32 idx = find_leveled(w, 1, sm->cq_key[e], rs, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
     if (idx != FQSX_NIL) slot_encode(w, idx, s, sy);
-    ctx_r_sym = ((ctx_r_sym << 1) + (sy == 0 ? 1u : 0u)) & 0xff;   // update_ctx_r_sym, dna.cpp:664-671
+    w.c_r_sym = ((w.c_r_sym << 1) + (sy == 0 ? 1u : 0u)) & 0xff;   // update_ctx_r_sym, dna.cpp:664-671
+  } else if (kind == SK_LETTER) {
+    u32 idx = find_leveled(w, 2, sm->cq_key[e], 0, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
+    if (idx != FQSX_NIL) slot_encode(w, idx, s, sy);
+    w.c_r_sym = (w.c_r_sym << 1) & 0xff;
   } else {
-    u32 idx = find_leveled(w, 2, sm->sp_key[j], 0, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
-    if (idx != FQSX_NIL) slot_encode(w, idx, s, sy);
-    ctx_r_sym = (ctx_r_sym << 1) & 0xff;
+    const u64 k0 = sm->cq_key[e][0];
+    const u32 tot = (u32)sm->cq_key[e][1];
+    rc_encode_rd(w, (u32)k0, (u32)(k0 >> 32), tot, recip_u16(tot));
+    w.c_r_sym = (w.c_r_sym << 1) & 0xff;   // (always followed by an SK_RESET entry before the next rank)
   }
 }
 // Returns the number of positions coded (0: position j0 needs the sequential routine).
-FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
+FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len) {
   WgShared *sm = w.sm;
   const int s0c = (int)(w.avg_code + 0.49), s0l = (int)(w.avg_letters + 0.49);
-  u64 Z = 0, BAD = 0, KL = 0, SM[5] = {0, 0, 0, 0, 0};
+  const u64 ctx_r_sym = w.c_r_sym;
+  u64 Z = 0, BAD = 0, KL = 0, KR = 0, RS = 0, SM[5] = {0, 0, 0, 0, 0};
   FQ_SYNC_MEM();
   TM_BEGIN(t_s);
-  // ---- per-symbol and per-kind masks of the run
+  // ---- per-symbol and per-kind masks of the run (queue entries j0 .. j0+len-1)
+#define CQE(t) ((j0 + (t)) & (FQSX_CQ - 1))
   for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
     const bool act = t < len;
-    const u32 r = act ? sm->sp_rsym[j0 + t] : 5u;
-    const bool letter = act && sm->sp_kind[j0 + t] == SK_LETTER;
+    const u32 kd = act ? sm->cq_kind[CQE(t)] : 0u, kind = kd & SK_KIND_MASK;
+    const bool letter = kind == SK_LETTER, raw = kind == SK_RAW;
+    const u32 r = act && !raw ? sm->cq_rsym[CQE(t)] : 5u;
+    const bool reset = (kd & SK_RESET) != 0;
 #if FQ_WAVE > 1
-    Z = wave_ballot(r == 0 && !letter);
+    Z = wave_ballot(r == 0 && kind == SK_RANK);
     KL = wave_ballot(letter);
+    KR = wave_ballot(raw);
+    RS = wave_ballot(reset);
     for (u32 x = 0; x < 5; ++x) SM[x] = wave_ballot(r == x);
 #else
-    Z |= (u64)(r == 0 && !letter) << t;
+    Z |= (u64)(r == 0 && kind == SK_RANK) << t;
     KL |= (u64)letter << t;
+    KR |= (u64)raw << t;
+    RS |= (u64)reset << t;
     for (u32 x = 0; x < 5; ++x) SM[x] |= (u64)(r == x) << t;
 #endif
   }
@@ -1732,14 +1803,25 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
     bool bad = t >= len;
     u32 fin = FQSX_NIL, c0 = 0, thr = ~0u, vis = 0, lvl = 0;
     u64 q1 = 0, q2 = 0, q3 = 0;
-    if (!bad) {
+    const bool raw = (KR >> t) & 1;
+    if (!bad && !raw) {
       const bool letter = (KL >> t) & 1;
       const u32 tag = letter ? 2u : 1u;
       const int n_levels = letter ? 9 : 7, s0 = letter ? s0l : s0c;
-      // r_sym history before this position: the run's earlier ranks, then the incoming history (dna.cpp:664-671)
-      const u32 hist = t >= 8 ? popc64((Z >> (t - 8)) & 0xffull) : popc64(Z & ((1ull << t) - 1ull)) + popc64(ctx_r_sym & ((1ull << (8 - t)) - 1ull));
+      // r_sym history before this position (dna.cpp:664-671): the rank-0 flags of the up to 8 entries before it,
+      // back to the last restart; the incoming history fills the rest of the window if the run has no restart so far
+      const u64 rs_le = RS & (t >= 63 ? ~0ull : (2ull << t) - 1ull);
+      u32 lo = t >= 8 ? t - 8 : 0u;
+      bool incoming = t < 8;
+      if (rs_le) {
+        const u32 rp = 63u - (u32)__builtin_clzll(rs_le);
+        if (rp > lo) lo = rp;
+        incoming = false;
+      }
+      u32 hist = popc64((Z >> lo) & ((1ull << (t - lo)) - 1ull));
+      if (incoming) hist += popc64(ctx_r_sym & ((1ull << (8 - t)) - 1ull));
       const u64 rs = letter ? 0ull : (u64)hist << SH_RSYM;
-      const u64 *lev = sm->sp_key[j0 + t];
+      const u64 *lev = sm->cq_key[CQE(t)];
       RoHit h = ctx_probe_ro(w, tag, LEVKEY(s0), vis);
       int i = s0;
       if (h.present) {
@@ -1783,7 +1865,7 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
   {
     const u32 t = FQ_LANE;
     const u32 mine = sm->fr_idx[t];
-    const bool ok = !sm->fr_bad[t];
+    const bool ok = !sm->fr_bad[t] && !((KR >> t) & 1);
     u64 rem = wave_ballot(ok), same = 0;
     while (rem) {
       const u32 lead = ctz64(rem);
@@ -1797,8 +1879,8 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
 #else
   for (u32 t = 0; t < 64; ++t) {
     u64 same = 0;
-    if (!sm->fr_bad[t])
-      for (u32 u = 0; u < 64; ++u) same |= (u64)(!sm->fr_bad[u] && sm->fr_idx[u] == sm->fr_idx[t]) << u;
+    if (!sm->fr_bad[t] && !((KR >> t) & 1))
+      for (u32 u = 0; u < 64; ++u) same |= (u64)(!sm->fr_bad[u] && !((KR >> u) & 1) && sm->fr_idx[u] == sm->fr_idx[t]) << u;
     sm->fr_same[t] = same;
   }
 #endif
@@ -1810,7 +1892,10 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
   for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
     bool bad = sm->fr_bad[t] != 0;
     u32 f = 0, c = 0, tot = 0;
-    if (!bad) {
+    if (!bad && ((KR >> t) & 1)) {        // finished triple
+      const u64 k0 = sm->cq_key[CQE(t)][0];
+      f = (u32)k0; c = (u32)(k0 >> 32); tot = (u32)sm->cq_key[CQE(t)][1];
+    } else if (!bad) {
       const u64 below = sm->fr_same[t] & ((1ull << t) - 1ull);
       const u32 occ = popc64(below);
       const u32 thr = sm->fr_thr[t];
@@ -1819,7 +1904,7 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
       if (tot + 4 >= (1u << 15)) bad = true;                              // this use rescales the model (rc.h:186-197)
       const u64 q2 = sm->fr_q2[t], q3 = sm->fr_q3[t];
       u32 st[5] = {(u32)(q2 & 0xffff), (u32)((q2 >> 16) & 0xffff), (u32)((q2 >> 32) & 0xffff), (u32)(q2 >> 48), (u32)(q3 & 0xffff)};
-      const u32 r = sm->sp_rsym[j0 + t];
+      const u32 r = sm->cq_rsym[CQE(t)];
       for (u32 x = 0; x < 5; ++x) {
         st[x] += 4 * popc64(below & SM[x]);
         if (x < r) c += st[x];
@@ -1847,6 +1932,7 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
     for (; t < L; ++t) {
 #if FQ_WAVE > 1
       // ema_update with its level term precomputed by the position's lane
+      if ((KR >> t) & 1) continue;
       const double pl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lane_pl), t), __builtin_amdgcn_readlane(__double2loint(lane_pl), t));
       if ((KL >> t) & 1) {
         if ((int)(al + 0.49) != s0l) break;
@@ -1856,6 +1942,7 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
         ac = __dadd_rn(__dmul_rn(0.999, ac), pl);
       }
 #else
+      if ((KR >> t) & 1) continue;
       if ((KL >> t) & 1) {
         if ((int)(al + 0.49) != s0l) break;
         al = ema_update(al, (double)sm->fr_lvl[t]);
@@ -1907,26 +1994,51 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len, u64 &ctx_r_sym) {
   for (u32 t = 0; t < L; ++t) rc_encode(w, sm->fr_f[t], sm->fr_c[t], sm->fr_t[t]);
 #endif
   // r_sym history after the run (a letter position shifts in a zero)
-  for (u32 t = 0; t < L; ++t) ctx_r_sym = ((ctx_r_sym << 1) + ((Z >> t) & 1ull)) & 0xff;
+  {
+    u64 h = ctx_r_sym;
+    for (u32 t = 0; t < L; ++t) {
+      if ((RS >> t) & 1ull) h = 0;
+      h = ((h << 1) + ((Z >> t) & 1ull)) & 0xff;
+    }
+    w.c_r_sym = h;
+  }
+#undef CQE
   TM_END(w, TM_CR_RC, t_rc);
   return L;
 }
-// all committed positions [0, m) of the chunk
-FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reversed, u32 hist_start, u64 &ctx_r_sym) {
+// the coder: entries [head, tail) of the queue, in order
+FQ_DEV u32 cq_process(Wk &w, u32 head, u32 avail) {
+  u32 L = code_run(w, head, avail < 64 ? avail : 64);
+  if (L == 0) {
+    code_one(w, head);
+    TM_COUNT(w, CN_P2);
+    L = 1;
+  }
+  return L;
+}
+// all committed positions [0, m) of the chunk go to the coding queue; the single-wave build codes them right away
+FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reversed, u32 hist_start, bool &first) {
   if (m == 0) return;
   TM_BEGIN(t_c2);
+  WgShared *sm = w.sm;
   code_keys(w, p, size, i0, m, reversed, hist_start);
   TM_END(w, TM_KEYS, t_c2);
-  for (u32 j = 0; j < m && !w.err;) {
-    u32 L = code_run(w, j, m - j, ctx_r_sym);
-    if (L == 0) {
-      code_one(w, j, ctx_r_sym);
-      TM_COUNT(w, CN_P2);
-      L = 1;
-    }
-    j += L;
+  if (!cq_wait_space(w, m)) return;
+  for (u32 j = FQ_LANE; j < m; j += FQ_WAVE) {
+    const u32 e = (w.cq_tail + j) & (FQSX_CQ - 1);
+    const u32 kind = sm->sp_kind[j];
+    const u32 nk = kind == SK_LETTER ? 10u : 7u;
+    for (u32 l = 0; l < nk; ++l) sm->cq_key[e][l] = sm->sp_key[j][l];
+    sm->cq_kind[e] = (u8)(kind | (first && j == 0 ? SK_RESET : 0u));
+    sm->cq_rsym[e] = sm->sp_rsym[j];
   }
-  TM_END(w, TM_FAST, t_c2);
+  FQ_SYNC();
+  first = false;
+  cq_publish(w, m);
+  if (!w.piped) {
+    while (w.cq_head != w.cq_tail && !w.err) w.cq_head += cq_process(w, w.cq_head, w.cq_tail - w.cq_head);
+    TM_END(w, TM_FAST, t_c2);
+  }
 }
 
 // compress_suffix, dna.cpp:674-877, as chunks of stage P (parallel) -> stage C (the serial loop below:
@@ -1935,7 +2047,7 @@ FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reverse
 FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_pos = 0, bool reversed = false, u32 hist_start = 0) {
   const DevCfg *cfg = w.cfg;
   WgShared *sm = w.sm;
-  u64 ctx_r_sym = 0;
+  bool first = true;   // the r_sym history starts empty (dna.cpp:676)
   u32 i = start_pos ? start_pos : original_order ? cfg->prefix : cfg->pmer;
   while (i < size && !w.err) {
     const u32 n = size - i < FQSX_SPEC ? size - i : FQSX_SPEC;
@@ -2154,7 +2266,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       m = j + 1;
     }
     if (dirty) TM_COUNT(w, CN_DIRTY);
-    code_chunk(w, p, size, i, m, reversed, hist_start, ctx_r_sym);
+    code_chunk(w, p, size, i, m, reversed, hist_start, first);
     flush_pushes(w, q_done, m);
     if (w_pos != m) {  // the last committed position went through the fast path: materialise its state
       const u32 sym = rd_sym(w, p, i + m - 1, size);
@@ -2215,7 +2327,10 @@ FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev
 // kernel bodies
 
 // worker `tid` codes its reads of segment `seg` (application.cpp:610-656)
-FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, bool decode = false) {
+// The coder wave of the two-wave encode kernel: drains the coding queue while the other wave of the workgroup
+// resolves the reads.  Nothing the resolving wave decides depends on the context models, the level averages or the
+// range coder, so this wave owns them (and the worker's output stream) outright; the hand-off is the LDS queue.
+FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg) {
   Wk w;
   w.cfg = &cfg;
   w.sm = sm;
@@ -2223,6 +2338,55 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   WState *ws = cfg.ws + tid;
   w.ws = ws;
   w.err = 0;
+  w.piped = false;   // this wave codes directly
+  w.cq_head = w.cq_tail = 0;
+  w.c_r_sym = 0;
+  for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
+  for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
+  if (seg == 0) { w.enc.low = 0; w.enc.range = 0xff00000000000000ULL; w.enc.len = 0; }   // application.cpp:624-628
+  else { w.enc.low = ws->rc_low; w.enc.range = ws->rc_range; w.enc.len = ws->out_len; }
+  w.enc.cap = cfg.out_cap; w.enc.out = cfg.out + (u64)tid * cfg.out_cap;
+  w.avg_code = ws->avg_code; w.avg_letters = ws->avg_letters;
+  u32 head = 0, spins = 0;
+  for (;;) {
+    const u32 done = lds_load_acq(&sm->cq_done);   // read before the tail: once set, the tail is final
+    const u32 tail = lds_load_acq(&sm->cq_tail);
+    if (tail != head) {
+      TM_BEGIN(t_c);
+      head += cq_process(w, head, tail - head);
+      FQ_SYNC();
+      lds_store_rel(&sm->cq_head, head);
+      TM_END(w, TM_FAST, t_c);
+      spins = 0;
+    } else if (done) break;
+    else {
+      fq_sleep();
+      if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+    }
+  }
+  ws->rc_low = w.enc.low; ws->rc_range = w.enc.range; ws->out_len = w.enc.len;
+  ws->avg_code = w.avg_code; ws->avg_letters = w.avg_letters;
+  if (FQ_LANE == 0) {
+    for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
+#ifdef FQSX_TIMING
+    for (u32 i = 0; i < 32; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
+#endif
+  }
+  if (w.err) *cfg.err = w.err;
+}
+
+// piped: this wave is the resolving half of a two-wave worker (see coder_segment_body)
+FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, bool decode = false, bool piped = false) {
+  Wk w;
+  w.cfg = &cfg;
+  w.sm = sm;
+  w.tid = tid;
+  WState *ws = cfg.ws + tid;
+  w.ws = ws;
+  w.err = 0;
+  w.piped = piped;
+  w.cq_head = w.cq_tail = 0;
+  w.c_r_sym = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
   for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
   TM_BEGIN(t_total);
@@ -2233,9 +2397,11 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   if (tid + 1 < T) last &= ~1ull;
   if (seg == 0) {  // application.cpp:624-628
     ws->cursor = (u32)first;
-    ws->rc_low = 0;
-    ws->rc_range = 0xff00000000000000ULL;
-    ws->out_len = 0;
+    if (!piped) {   // (the coder wave initialises its own coder)
+      ws->rc_low = 0;
+      ws->rc_range = 0xff00000000000000ULL;
+      ws->out_len = 0;
+    }
     ws->dec_pos = ~0ull;   // decoder: stream not started yet
   }
   const bool paired = cfg.mode >= 2;
@@ -2318,14 +2484,27 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   // (entries still pending for the local tables need not be applied: ClearKmersToHT empties them next)
 
   // store state
+  if (piped) {   // everything is queued: let the coder wave finish
+    FQ_SYNC();
+    lds_store_rel(&sm->cq_done, 1u);
+  }
   ws->cursor = (u32)cur;
-  ws->rc_low = w.enc.low; ws->rc_range = w.enc.range; ws->out_len = w.enc.len;
-  ws->avg_code = w.avg_code; ws->avg_letters = w.avg_letters;
+  if (!piped) {
+    ws->rc_low = w.enc.low; ws->rc_range = w.enc.range; ws->out_len = w.enc.len;
+    ws->avg_code = w.avg_code; ws->avg_letters = w.avg_letters;
+  }
   for (u32 i = 0; i < 4; ++i) ws->s_letters[i] = w.s_let[i];
   ws->hidden_updates = w.hidden;
   TM_END(w, TM_TOTAL, t_total);
-  for (u32 i = 0; i < ST_N; ++i) ws->stat[i] += w.st[i];
-  for (u32 i = 0; i < 32; ++i) ws->stat[16 + i] += w.tm[i];
+  if (!piped) {
+    for (u32 i = 0; i < ST_N; ++i) ws->stat[i] += w.st[i];
+    for (u32 i = 0; i < 32; ++i) ws->stat[16 + i] += w.tm[i];
+  } else if (FQ_LANE == 0) {   // the coder wave adds to the same counters
+    for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
+#ifdef FQSX_TIMING
+    for (u32 i = 0; i < 32; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
+#endif
+  }
   FQ_SYNC();
   for (u32 g = 0; g < 4; ++g) {
     for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) ws->mt[g][i] = sm->mt[g][i];

@@ -16,6 +16,7 @@
 #define FQSX_NIL 0xffffffffu
 #define FQSX_RD_LDS 4096u        // reads up to this length are staged in LDS
 #define FQSX_SPEC 64u            // positions speculated per chunk (one per lane)
+#define FQSX_CQ 128u             // entries of the coding queue (power of two, >= 2 * FQSX_SPEC)
 
 // geometry of one rolling k-mer (kmer.h:279-298)
 struct KGeom {
@@ -173,4 +174,5 @@ enum {
   FQSX_ERR_PE_FULL = 6,
   FQSX_ERR_PE_READ_TOO_LONG = 7,
   FQSX_ERR_DECODE = 8,
+  FQSX_ERR_PIPE = 9,              // the coding queue between the two waves of a worker stalled
 };

@@ -24,6 +24,7 @@ typedef int32_t i32;
 #define FQ_DEVN __device__ __noinline__
 #define FQ_KERNEL extern "C" __global__
 #define FQ_KERNEL64 extern "C" __global__ __launch_bounds__(64)
+#define FQ_KERNEL128 extern "C" __global__ __launch_bounds__(128)
 #define FQ_WAVE 64
 #define FQ_LANE ((u32)(threadIdx.x & 63u))
 #define FQ_BLOCK ((u32)blockIdx.x)
@@ -33,8 +34,19 @@ typedef int32_t i32;
 // wave is in order, so draining it (and stopping compiler reordering) is all that is needed.  This
 // deliberately does NOT wait for outstanding global stores (a __syncthreads() would: vmcnt(0)).
 #define FQ_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-// Full drain: lanes are about to read global memory other lanes of the wave have written.
-#define FQ_SYNC_MEM() __syncthreads()
+// Full drain: lanes are about to read global memory other lanes of the wave have written.  A wave's own
+// stores and loads go through its CU's vector cache, so waiting for the stores to complete is enough.  (Not
+// __syncthreads(): the encode kernel runs two waves per workgroup that must never meet at a barrier, see below.)
+#define FQ_SYNC_MEM() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+// The one barrier of the two-wave encode kernel (after the LDS queue indices are initialised)
+#define FQ_WG_BARRIER() __syncthreads()
+#define FQ_WAVE_ID ((u32)(threadIdx.x >> 6))
+// LDS hand-off words between the two waves of a workgroup (release: everything this wave wrote before is
+// visible to a wave that acquires the value)
+FQ_DEV u32 lds_load_acq(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+FQ_DEV void lds_store_rel(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+FQ_DEV void fq_sleep() { __builtin_amdgcn_s_sleep(4); }
+FQ_DEV void atomic_add64(u64 *p, u64 v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
 
 FQ_DEV u32 wave_sum32(u32 v) {
 #pragma unroll
@@ -84,6 +96,7 @@ FQ_DEV double ema_update(double avg, double level) { return __dadd_rn(__dmul_rn(
 #define FQ_DEVN static
 #define FQ_KERNEL static
 #define FQ_KERNEL64 static
+#define FQ_KERNEL128 static
 #define FQ_WAVE 1
 #define FQ_LANE 0u
 #define FQ_BLOCK (fq_emu_block)
@@ -91,6 +104,12 @@ FQ_DEV double ema_update(double avg, double level) { return __dadd_rn(__dmul_rn(
 #define FQ_SHARED static thread_local
 #define FQ_SYNC() ((void)0)
 #define FQ_SYNC_MEM() ((void)0)
+#define FQ_WG_BARRIER() ((void)0)
+#define FQ_WAVE_ID 0u
+FQ_DEV u32 lds_load_acq(const u32 *p) { return *p; }
+FQ_DEV void lds_store_rel(u32 *p, u32 v) { *p = v; }
+FQ_DEV void fq_sleep() {}
+FQ_DEV void atomic_add64(u64 *p, u64 v) { *p += v; }
 static thread_local u32 fq_emu_block = 0, fq_emu_nblocks = 1;
 FQ_DEV u32 wave_sum32(u32 v) { return v; }
 FQ_DEV u64 wave_sum64(u64 v) { return v; }
