@@ -25,7 +25,6 @@ struct WgShared {
   u8 sp_kind[FQSX_SPEC];       // how the position's symbol is coded: SK_* (set by stage P for settled positions, else by stage C)
   u64 sp_cq[FQSX_SPEC];        // SK_RANK_PENDING: the four counts, 16 bits each
   u8 sp_lvz[FQSX_SPEC];        // SK_RANK_PENDING: level | cor_zone << 4
-  u32 sp_cnt[FQSX_SPEC];       // 4 x 8-bit counts
   u8 sp_flag[FQSX_SPEC];       // 0 slow path, 1 b-mer hit (fast path), 3 slow path with known global b-mer miss
   u8 sp_rsym[FQSX_SPEC];       // rank of the read's symbol under those counts
   u8 sp_rep[FQSX_SPEC];        // fast path: symbol repair_kmers_existing substitutes, or 0xff
@@ -38,13 +37,18 @@ struct WgShared {
   u32 fr_idx[64], fr_c0[64], fr_thr[64], fr_vis[64];   // final slot, its counter, threshold to re-validate (or ~0), slots visited
   u64 fr_q1[64], fr_q2[64], fr_q3[64];                 // the final slot's counter|tag|total and statistics at run start
   u64 fr_same[64];                                     // lanes of the run that end in the same slot
-  u32 fr_f[64], fr_c[64], fr_t[64];                    // range-coder triple of the position
+#ifdef FQSX_EMU
+  u32 fr_f[64], fr_c[64], fr_t[64];                    // range-coder triple of the position (GPU: lane registers)
+#endif
   u8 fr_lvl[64], fr_bad[64];
   u8 r2c[FQSX_RD_LDS];         // paired-end: codes of the second mate
   u64 pe_cand[512];            // paired-end: candidate partner b-mers (value | count << 2k)
   u64 pe_top[64];
   u64 pe_bk[3][64];            // paired-end insert batch (key, value, weight)
-  u64 pq_key[2][64];           // LDS mirror of the list entries not yet applied to the local tables (b, s)
+  u64 pq_key[2][FQSX_PQ];      // LDS mirror of the most recent b / s list entries (ring indexed by list position)
+  u64 ib_pos[64];              // insert_batch: target slot per lane
+  // hand-off words of the local-table inserter wave: list entries published / applied per kind (b, s); quit
+  u32 lq_target[2], lq_done[2], lq_quit;
   // stage P, positions whose global b-mer probe missed: the rest of find_counts' cascade and the
   // Hamming-1 fall-back, resolved lane-parallel (valid while no pending local insert interferes)
   u32 sx_lb[FQSX_SPEC];        // local b-mer counts, 4 x 8 bit
@@ -88,8 +92,9 @@ struct Wk {
   const u8 *din;                        // decoder input stream of this worker
   u64 din_len, din_pos, din_buffer;
   u32 la[3];                            // list entries already applied to the local tables (b, s)
-  u32 pq_n[2];                          // valid entries of the LDS mirror (b, s); ~0u = mirror overflowed
-  bool lq_applied;                      // a local-table flush happened since the last stage P (its local probes are stale)
+  u32 pq_lo[2];                         // list entries (b, s) below this index were in the local tables when stage P last probed them
+  bool lqh;                             // a third wave of the workgroup applies the local inserts (else: inline, on demand)
+  u32 lq_pub[2];                        // entries already published to that wave
   bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
   u32 cq_tail, cq_head;                 // this wave's copy of its own queue index
   u64 c_r_sym;                          // coder: ctx_r_sym, the last 8 rank-0 flags (dna.cpp:664-671)
@@ -422,14 +427,37 @@ FQ_DEV void insert_keys(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 sub,
   for (u32 j = 0; j < n && !err; ++j) insert_batch(cfg, sm, t, sub, keys + j, 1, rng, ci, nslots, err);
 #endif
 }
-// Local-table inserts (ht_*_local->insert, dna.cpp:826,839,861,872) are deferred: every b-/s-mer a
-// worker pushes to its mailbox list is also a local insert, so the not-yet-applied tail of the
-// list is the pending queue.  It is applied as lane-parallel batches, in order, before the next
-// local look-up, so the tables always hold exactly what the sequential algorithm would have.
+// Local-table inserts (ht_*_local->insert, dna.cpp:826,839,861,872): every b-/s-mer a worker pushes to its
+// mailbox list is also a local insert, so the list itself is the insert queue.  The entries are applied in list
+// order as lane-parallel batches -- by the inserter wave of the workgroup as soon as they are published (encode
+// kernel), or inline on demand (single-wave builds).  A look-up only has to wait for entries that could change its
+// answer, so the tables always give exactly what the sequential algorithm would have seen.
+FQ_DEV u32 lq_done_now(Wk &w, u32 qi) { return w.lqh ? lds_load_acq(&w.sm->lq_done[qi]) : w.la[qi ? MAIL_S : MAIL_B]; }
+FQ_DEV void lq_publish(Wk &w) {   // hand the list entries written so far to the inserter wave
+  if (!w.lqh) return;
+  const u32 nb = w.mn[MAIL_B], ns = w.mn[MAIL_S];
+  if (nb != w.lq_pub[0]) { lds_store_rel(&w.sm->lq_target[0], nb); w.lq_pub[0] = nb; }
+  if (ns != w.lq_pub[1]) { lds_store_rel(&w.sm->lq_target[1], ns); w.lq_pub[1] = ns; }
+}
 FQ_DEV void lq_flush(Wk &w, u32 kind) {
   const Mail &m = w.cfg->mail[kind];
-  u32 a = w.la[kind], n = w.mn[kind];
-  if (a >= n) { w.pq_n[kind == MAIL_S ? 1 : 0] = 0; return; }
+  const u32 qi = kind == MAIL_S ? 1 : 0;
+  const u32 n = w.mn[kind];
+  if (w.lqh) {
+    if (lds_load_acq(&w.sm->lq_done[qi]) >= n) return;
+    TM_BEGIN(t_lq);
+    TM_COUNT(w, CN_LQFLUSH);
+    lq_publish(w);
+    u32 spins = 0;
+    while (lds_load_acq(&w.sm->lq_done[qi]) < n) {
+      fq_sleep();
+      if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+    }
+    TM_END(w, TM_LQ, t_lq);
+    return;
+  }
+  const u32 a = w.la[kind];
+  if (a >= n) return;
   TM_BEGIN(t_lq);
   TM_COUNT(w, CN_LQFLUSH);
   u64 ns = 0;
@@ -438,34 +466,34 @@ FQ_DEV void lq_flush(Wk &w, u32 kind) {
   insert_keys(*w.cfg, w.sm, kind == MAIL_S ? w.cfg->l_s : w.cfg->l_b, w.tid, m.list + (u64)w.tid * m.cap + a, n - a,
               kind == MAIL_S ? RNG_LS : RNG_LB, kind == MAIL_S ? CINC_S : CINC_B, ns, err);
   w.la[kind] = n;
-  w.lq_applied = true;
-  w.pq_n[kind == MAIL_S ? 1 : 0] = 0;
   w.st[ST_LINS] += n - a;
   if (err) w.err = FQSX_ERR_LTAB_FULL;
   TM_END(w, TM_LQ, t_lq);
 }
+// does one of the list entries [lo, hi) of kind qi fall into the sibling group of full k-mer km?
+FQ_DEV bool pq_group_hit(Wk &w, u32 qi, const KGeom &g, const Kmer &km, u32 lo, u32 hi) {
+  const u32 k2 = 2 * g.k;
+  const bool nd = km_norm_dir(km, g);
+  const u64 v = (nd ? km.dir : km.rc) >> (64 - k2);
+  const u64 lowmask = (1ull << (k2 - 2)) - 1ull;
+  const u64 grp = nd ? (v >> 2) : (v & lowmask);
+  bool hit = false;
+  FQ_SYNC();
+  for (u32 t = lo + FQ_LANE; t < hi; t += FQ_WAVE) {
+    u64 pv = w.sm->pq_key[qi][t & (FQSX_PQ - 1)] >> (64 - k2);
+    hit |= nd ? ((pv >> 2) == grp) : ((pv & lowmask) == grp);
+  }
+  return wave_any(hit);
+}
 
-// Before a local look-up: apply the pending inserts only if one of them could change the answer
-// (same sibling group as the looked-up full k-mer), the mirror overflowed, or the k-mer is partial.
+// Before a local look-up: wait for the pending inserts only if one of them could change the answer
+// (same sibling group as the looked-up full k-mer), the mirror no longer covers them, or the k-mer is partial.
 FQ_DEV void lq_sync_for(Wk &w, u32 kind, const KGeom &g, const Kmer &km) {
   const u32 qi = kind == MAIL_S ? 1 : 0;
-  const u32 pn = w.pq_n[qi];
-  if (w.la[kind] >= w.mn[kind]) return;
-  bool need = pn == ~0u || km.cur != g.k;
-  if (!need) {
-    const u32 k2 = 2 * g.k;
-    const bool nd = km_norm_dir(km, g);
-    const u64 v = (nd ? km.dir : km.rc) >> (64 - k2);
-    const u64 lowmask = (1ull << (k2 - 2)) - 1ull;
-    const u64 grp = nd ? (v >> 2) : (v & lowmask);
-    bool hit = false;
-    FQ_SYNC();
-    for (u32 t = FQ_LANE; t < pn; t += FQ_WAVE) {
-      u64 pv = w.sm->pq_key[qi][t] >> (64 - k2);
-      hit |= nd ? ((pv >> 2) == grp) : ((pv & lowmask) == grp);
-    }
-    need = wave_any(hit);
-  }
+  const u32 n = w.mn[kind], d = lq_done_now(w, qi);
+  if (d >= n) return;
+  bool need = km.cur != g.k || n - d > FQSX_PQ;
+  if (!need) need = pq_group_hit(w, qi, g, km, d, n);
   if (need) lq_flush(w, kind);
 }
 
@@ -1170,11 +1198,7 @@ FQ_DEV void mail_push(Wk &w, u32 kind, u64 x) {
   m.list[(u64)w.tid * m.cap + c] = x;
   w.mn[kind] = c + 1;
   w.st[ST_MAIL] += 1;
-  if (kind != MAIL_P) {
-    const u32 qi = kind == MAIL_S ? 1 : 0;
-    u32 pn = w.pq_n[qi];
-    if (pn < 64) { w.sm->pq_key[qi][pn] = x; w.pq_n[qi] = pn + 1; } else w.pq_n[qi] = ~0u;
-  }
+  if (kind != MAIL_P) w.sm->pq_key[kind == MAIL_S ? 1 : 0][c & (FQSX_PQ - 1)] = x;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1462,23 +1486,19 @@ FQ_DEV void prefix_sorted(Wk &w, const u8 *p, u32 size) {  // compress_prefix_so
   push_p_both(w);
 }
 
-// Would a pending (not yet applied) local insert change a look-up of full k-mer `km`?  Pending = LDS
-// mirror of the list tail + the entries of chunk positions [q_done, j) that stage Q has not appended yet.
+// Could a local insert that stage P's probe may not have seen change a look-up of full k-mer `km`?  These are the
+// list entries from pq_lo on (LDS mirror) + the entries of chunk positions [q_done, j) that stage Q has not appended yet.
 FQ_DEV bool pend_conflict(Wk &w, u32 qi, const KGeom &g, const Kmer &km, u32 q_done, u32 j) {
   WgShared *sm = w.sm;
-  const u32 pn = w.pq_n[qi];
-  if (pn == ~0u) return true;
+  const u32 lo = w.pq_lo[qi], hi = w.mn[qi ? MAIL_S : MAIL_B];
+  if (hi - lo > FQSX_PQ) return true;
+  if (pq_group_hit(w, qi, g, km, lo, hi)) return true;
   const u32 k2 = 2 * g.k;
   const bool nd = km_norm_dir(km, g);
   const u64 v = (nd ? km.dir : km.rc) >> (64 - k2);
   const u64 lowmask = (1ull << (k2 - 2)) - 1ull;
   const u64 grp = nd ? (v >> 2) : (v & lowmask);
   bool hit = false;
-  FQ_SYNC();
-  for (u32 t = FQ_LANE; t < pn; t += FQ_WAVE) {
-    u64 pv = sm->pq_key[qi][t] >> (64 - k2);
-    hit |= nd ? ((pv >> 2) == grp) : ((pv & lowmask) == grp);
-  }
   for (u32 t = q_done + FQ_LANE; t < j; t += FQ_WAVE)
     if (sm->pv_flag[t] & (qi ? PV_S : PV_B)) {
       u64 pv = (qi ? sm->pv_s[t] : sm->pv_b[t]) >> (64 - k2);
@@ -1502,7 +1522,8 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
   WgShared *sm = w.sm;
   u64 ns = 0, nls = 0;
   u32 np = 0, nlp = 0;
-  w.lq_applied = false;
+  w.pq_lo[0] = lq_done_now(w, 0);   // everything below is in the local tables before the probes start
+  w.pq_lo[1] = lq_done_now(w, 1);
   FQ_SYNC();
   for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
     // roll the six k-mers j symbols forward in closed form: only the last min(j, k) new symbols matter
@@ -1565,7 +1586,6 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           if (!reversed) ctx_codes(lev, cfg, c, w.s_let, i, LV_BMER, cz, 0, size);
           else ctx_codes(lev, cfg, c, w.s_let, size - i - 1, LV_BMER, cz, 0, ~0u);  // dna.cpp:750-752
           for (u32 l = 0; l < 7; ++l) sm->sp_key[j][l] = lev[l];
-          sm->sp_cnt[j] = c.c[0] | (c.c[1] << 8) | (c.c[2] << 16) | (c.c[3] << 24);
           sm->sp_rsym[j] = (u8)rank_sym(w, c, sym);
           // repair_kmers_existing decision (dna.cpp:333-360)
           rep = repair_decide(w, c, sym);
@@ -1648,9 +1668,9 @@ FQ_DEV void flush_pushes(Wk &w, u32 a, u32 b) {
     if (w.mn[MAIL_B] + tb > mb.cap || w.mn[MAIL_S] + ts > ms.cap || w.mn[MAIL_P] + tp > mp.cap) { w.err = FQSX_ERR_MAIL_FULL; return; }
     if (nb) mb.list[(u64)w.tid * mb.cap + w.mn[MAIL_B] + ob] = sm->pv_b[t];
     if (nsm) ms.list[(u64)w.tid * ms.cap + w.mn[MAIL_S] + os] = sm->pv_s[t];
-    // LDS mirror of the entries still pending for the local tables
-    if (w.pq_n[0] != ~0u && w.pq_n[0] + tb <= 64) { if (nb) sm->pq_key[0][w.pq_n[0] + ob] = sm->pv_b[t]; w.pq_n[0] += tb; } else w.pq_n[0] = ~0u;
-    if (w.pq_n[1] != ~0u && w.pq_n[1] + ts <= 64) { if (nsm) sm->pq_key[1][w.pq_n[1] + os] = sm->pv_s[t]; w.pq_n[1] += ts; } else w.pq_n[1] = ~0u;
+    // LDS mirror of the most recent list entries
+    if (nb) sm->pq_key[0][(w.mn[MAIL_B] + ob) & (FQSX_PQ - 1)] = sm->pv_b[t];
+    if (nsm) sm->pq_key[1][(w.mn[MAIL_S] + os) & (FQSX_PQ - 1)] = sm->pv_s[t];
     if (npm) {
       u64 *dst = mp.list + (u64)w.tid * mp.cap + w.mn[MAIL_P] + op;
       dst[0] = sm->pv_pd[t];
@@ -2073,11 +2093,6 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       const u32 sym = rd_sym(w, p, pos, size);
       const u64 sym_k = sym == 4 ? 0 : sym;
       const u32 flag = sm->sp_flag[j];
-      if (flag == 3 && j > 0 && w.lq_applied && (sm->sx_flag[j] & SX_VALID)) {
-        // the local tables changed since stage P probed them: re-run stage P from this position
-        TM_COUNT(w, CN_LQSTALE);
-        break;
-      }
       TM_BEGIN(t_code);
       if (flag == 1) {
         // settled by stage P (level bmer): nothing to resolve; skip the whole stretch of such positions up to the
@@ -2114,7 +2129,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         bool rough = false, loaded = false, resolved = false;
         TM_COUNT(w, CN_SLOW);
         const u32 xf = flag == 3 ? sm->sx_flag[j] : 0;
-        if ((xf & SX_VALID) && !w.lq_applied) {
+        if (xf & SX_VALID) {
           // the cascade was resolved in stage P; it stands unless a pending local insert interferes
           Kmer bmj, smj;
           bmj.dir = sm->sp_sdir[2][j]; bmj.rc = sm->sp_src[2][j]; bmj.cur = sm->sp_scur[2][j];
@@ -2266,8 +2281,9 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       m = j + 1;
     }
     if (dirty) TM_COUNT(w, CN_DIRTY);
-    code_chunk(w, p, size, i, m, reversed, hist_start, first);
     flush_pushes(w, q_done, m);
+    code_chunk(w, p, size, i, m, reversed, hist_start, first);
+    lq_publish(w);   // (after the queue hand-off, whose release has already drained the list stores)
     if (w_pos != m) {  // the last committed position went through the fast path: materialise its state
       const u32 sym = rd_sym(w, p, i + m - 1, size);
       load_state(w, m - 1);
@@ -2339,6 +2355,7 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
   w.ws = ws;
   w.err = 0;
   w.piped = false;   // this wave codes directly
+  w.lqh = false;
   w.cq_head = w.cq_tail = 0;
   w.c_r_sym = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
@@ -2375,6 +2392,49 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
   if (w.err) *cfg.err = w.err;
 }
 
+// The inserter wave of the encode kernel: applies the worker's b-/s-mer list entries to its local tables, in list
+// order, as soon as the resolving wave publishes them.  It owns the local tables' contents, their fill counters and
+// the two local counter RNG streams while it has work; the resolving wave touches those only after it has seen
+// lq_done catch up (lq_flush), which it also does once more at the end of the segment.
+FQ_DEV void inserter_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
+  u32 la[2] = {0, 0}, err = 0, spins = 0;
+  u64 ns = 0, lins = 0;
+  bool failed = false;
+  for (;;) {
+    const u32 quit = lds_load_acq(&sm->lq_quit);
+    if (quit) break;
+    bool worked = false;
+    for (u32 qi = 0; qi < 2 && !failed; ++qi) {
+      const u32 kind = qi ? MAIL_S : MAIL_B;
+      const u32 tgt = lds_load_acq(&sm->lq_target[qi]);
+      if (tgt > la[qi]) {
+        const Mail &m = cfg.mail[kind];
+        const u32 n = tgt - la[qi] < FQ_WAVE ? tgt - la[qi] : FQ_WAVE;
+        insert_batch(cfg, sm, qi ? cfg.l_s : cfg.l_b, tid, m.list + (u64)tid * m.cap + la[qi], n, qi ? RNG_LS : RNG_LB,
+                     qi ? CINC_S : CINC_B, ns, err);
+        if (err) {   // table full: report, and release every waiter
+          failed = true;
+          *cfg.err = FQSX_ERR_LTAB_FULL;
+          lds_store_rel(&sm->lq_done[0], ~0u);
+          lds_store_rel(&sm->lq_done[1], ~0u);
+          break;
+        }
+        la[qi] += n;
+        lins += n;
+        FQ_SYNC_MEM();
+        lds_store_rel(&sm->lq_done[qi], la[qi]);
+        worked = true;
+      }
+    }
+    if (worked) spins = 0;
+    else {
+      fq_sleep();
+      if (++spins > (1u << 24)) break;   // never spin forever on the GPU
+    }
+  }
+  if (FQ_LANE == 0 && lins) atomic_add64(&cfg.ws[tid].stat[ST_LINS], lins);
+}
+
 // piped: this wave is the resolving half of a two-wave worker (see coder_segment_body)
 FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, bool decode = false, bool piped = false) {
   Wk w;
@@ -2385,6 +2445,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.ws = ws;
   w.err = 0;
   w.piped = piped;
+  w.lqh = piped;
   w.cq_head = w.cq_tail = 0;
   w.c_r_sym = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
@@ -2429,7 +2490,8 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
     w.repm_gate = !((nf ? (double)nu / (double)nf : 0.0) < 7.0);
   }
   w.la[0] = w.la[1] = w.la[2] = 0;
-  w.pq_n[0] = w.pq_n[1] = 0;
+  w.pq_lo[0] = w.pq_lo[1] = 0;
+  w.lq_pub[0] = w.lq_pub[1] = 0;
   FQ_SYNC();
   w.enc.low = ws->rc_low; w.enc.range = ws->rc_range; w.enc.len = ws->out_len;
   w.enc.cap = cfg.out_cap; w.enc.out = cfg.out + (u64)tid * cfg.out_cap;
@@ -2481,12 +2543,17 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
       compress_pair(w, cfg.bases + o0, (u32)(o1 - o0), cfg.bases + o1, (u32)(o2 - o1), prev, prev_size);
     }
   if (stop > cur) cur = stop;
-  // (entries still pending for the local tables need not be applied: ClearKmersToHT empties them next)
+  // The local tables are emptied next (ClearKmersToHT), but the inserts still pending for them are applied all the
+  // same: an insert that finds a counter above its threshold draws from the worker's cinc_lb / cinc_ls stream
+  // (dna.cpp:826,837), whose state lives on.
+  lq_flush(w, MAIL_B);
+  lq_flush(w, MAIL_S);
 
   // store state
-  if (piped) {   // everything is queued: let the coder wave finish
+  if (piped) {   // everything is queued: let the coder wave finish; the inserter wave has nothing left
     FQ_SYNC();
     lds_store_rel(&sm->cq_done, 1u);
+    lds_store_rel(&sm->lq_quit, 1u);
   }
   ws->cursor = (u32)cur;
   if (!piped) {
@@ -2549,12 +2616,12 @@ FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 tid
     u32 lim = n;
 #if FQ_WAVE > 1
     FQ_SYNC();
-    sm->bk_key[lane] = act ? pos : ~0ull;
+    sm->ib_pos[lane] = act ? pos : ~0ull;
     FQ_SYNC();
     bool clash = false;   // an earlier key of this round targets my slot
     if (act)
       for (u32 j = done; j < n; ++j)
-        if (j < lane && sm->bk_key[j] == pos) clash = true;
+        if (j < lane && sm->ib_pos[j] == pos) clash = true;
     const u64 cl = wave_ballot(clash);
     if (cl) lim = ctz64(cl);
     act = act && lane < lim;
