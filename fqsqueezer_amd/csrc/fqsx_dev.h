@@ -8,10 +8,23 @@
 
 // ---------------------------------------------------------------------------------------
 // workgroup-shared (LDS) state of one worker
+// What the read-head wave hands over per read: the head's symbols as finished coder triples, the p-mer list
+// entries, the rolling k-mers after the prefix and the read's letter histogram.
+#define FQSX_HD_RAW 56u
+struct HeadRec {
+  u32 n_raw, same, n_run, n_p;
+  u32 hist[4];
+  u64 raw[FQSX_HD_RAW][2];     // freq | cum << 32, total
+  u64 pmail[2];
+  u64 kdir[3], krc[3];
+  u32 kcur[3];
+};
 struct WgShared {
+  HeadRec hd[2];
+  u32 hd_ready, hd_taken;      // read heads finished / consumed (free-running counts within the launch)
   u32 mt[4][624];              // MT19937 states of cinc_b, cinc_s, cinc_lb, cinc_ls
   u32 mt_idx[4];
-  u8 rd[FQSX_RD_LDS];          // 2-bit codes (0..4) of the current read
+  u8 rd[2][FQSX_RD_LDS];       // 2-bit codes (0..4) of the current read (two buffers: the head wave stages the next read)
   u64 bk_key[256];             // probe batch: normalised k-mers
   u32 bk_res[256][4];          // probe batch: counts
   u8 bk_dir[256];              // probe batch: orientation
@@ -95,6 +108,8 @@ struct Wk {
   u32 pq_lo[2];                         // list entries (b, s) below this index were in the local tables when stage P last probed them
   bool lqh;                             // a third wave of the workgroup applies the local inserts (else: inline, on demand)
   u32 lq_pub[2];                        // entries already published to that wave
+  u8 *rdp;                              // LDS staging buffer of the current read's codes
+  HeadRec *rec;                         // read-head wave: where the head's output goes (null: code / push directly)
   bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
   u32 cq_tail, cq_head;                 // this wave's copy of its own queue index
   u64 c_r_sym;                          // coder: ctx_r_sym, the last 8 rank-0 flags (dna.cpp:664-671)
@@ -692,6 +707,15 @@ FQ_DEV void cq_publish(Wk &w, u32 n) {
 // A symbol of a small direct-indexed model: coded right here, or (two-wave kernel) handed to the coder wave as a
 // finished triple so that it keeps its place in the stream.
 FQ_DEV void rc_encode(Wk &w, u32 freq, u32 cum, u32 tot) {
+  if (w.rec) {   // read-head wave: the triple goes into the read's record
+    const u32 n = w.rec->n_raw;
+    FQ_SYNC();
+    if (n < FQSX_HD_RAW) {
+      if (FQ_LANE == 0) { w.rec->raw[n][0] = (u64)freq | ((u64)cum << 32); w.rec->raw[n][1] = tot; w.rec->n_raw = n + 1; }
+    } else w.err = FQSX_ERR_PIPE;
+    FQ_SYNC();
+    return;
+  }
   if (!w.piped) { rc_encode_rd(w, freq, cum, tot, recip_u16(tot)); return; }
   if (!cq_wait_space(w, 1)) return;
   WgShared *sm = w.sm;
@@ -1192,6 +1216,12 @@ FQ_DEV void ctx_letters_keys(u64 a[10], const DevCfg *cfg, u32 pos, u64 letters,
 // mailboxes (my_*_to_add push_back, dna.cpp:657-660,818-852): append in push order; the owner is
 // derived from the key by the partition kernels
 FQ_DEV void mail_push(Wk &w, u32 kind, u64 x) {
+  if (w.rec) {   // read-head wave (only ever pushes the prefix p-mer, both strands)
+    FQ_SYNC();
+    if (FQ_LANE == 0) { const u32 n = w.rec->n_p; w.rec->pmail[n & 1] = x; w.rec->n_p = n + 1; }
+    FQ_SYNC();
+    return;
+  }
   const Mail &m = w.cfg->mail[kind];
   u32 c = w.mn[kind];
   if (c >= m.cap) { w.err = FQSX_ERR_MAIL_FULL; return; }
@@ -1419,7 +1449,7 @@ FQ_DEV void insert_all(Wk &w, u64 sym) {
   km_insert(w.pm_u, cfg->gp, sym); km_insert(w.sm_u, cfg->gs, sym); km_insert(w.bm_u, cfg->gb, sym);
 }
 
-FQ_DEV u32 rd_sym(Wk &w, const u8 *p, u32 i, u32 size) { return size <= FQSX_RD_LDS ? (u32)w.sm->rd[i] : dna_code(p[i]); }
+FQ_DEV u32 rd_sym(Wk &w, const u8 *p, u32 i, u32 size) { return size <= FQSX_RD_LDS ? (u32)w.rdp[i] : dna_code(p[i]); }
 
 FQ_DEV void prefix_direct(Wk &w, const u8 *p, u32 size) {  // compress_prefix_direct, dna.cpp:506-546
   w.ctx_letters = ~0ull;
@@ -2294,15 +2324,12 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
   }
 }
 
-// CompressDirect / CompressSorted, dna.cpp:1517-1556,1716-1754.  `prev` is the previous read of
-// this worker inside the block (read_prev is cleared per block, application.cpp:624), or null.
-// first_of_pair = false: the second mate coded by CompressDirect(..., false): direct prefix, no duplicate flag
-FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev_size, bool first_of_pair = true) {
+// the head of a read: duplicate flag and prefix.  Returns true for a duplicate (nothing else is coded);
+// hist = the read's letter counts A, C, G, T.
+FQ_DEV bool read_head(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev_size, bool first_of_pair, u32 hist[4]) {
   const DevCfg *cfg = w.cfg;
-  WgShared *sm = w.sm;
   const bool orig = !first_of_pair || cfg->mode == 0 || cfg->mode == 2;
   // duplicate test + staging of the read's codes in LDS + letter histogram, all lane-parallel
-  TM_BEGIN(t_head);
   bool diff = prev == nullptr || prev_size != size;
   u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0;
   FQ_SYNC();
@@ -2310,30 +2337,87 @@ FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev
     u8 ch = p[i];
     if (!diff && prev[i] != ch) diff = true;
     u32 c = dna_code(ch);
-    if (i < FQSX_RD_LDS) sm->rd[i] = (u8)c;
+    if (i < FQSX_RD_LDS) w.rdp[i] = (u8)c;
     h0 += c == 0; h1 += c == 1; h2 += c == 2; h3 += c == 3;
   }
   FQ_SYNC();
+  hist[0] = wave_sum32(h0); hist[1] = wave_sum32(h1); hist[2] = wave_sum32(h2); hist[3] = wave_sum32(h3);
   bool same = !wave_any(diff);
   if (prev == nullptr || prev_size != size) same = false;
   if (first_of_pair) {
     u16 *m = small_base(w) + SM_OFF_FLAGS + w.ws->ctx_flags * (SM_FLAGS_N + 1);
     sm_encode(w, m, SM_FLAGS_N, 1u << 12, same ? 1u : 0u);
     w.ws->ctx_flags = ((w.ws->ctx_flags << 1) + (same ? 1u : 0u)) & 0xff;
-    if (same) return;
+    if (same) return true;
   }
   km_reset(w.pm); km_reset(w.sm_); km_reset(w.bm);
   km_reset(w.pm_u); km_reset(w.sm_u); km_reset(w.bm_u);
   w.cor_pos = 0;
   w.N_run = 0;
   if (orig) prefix_direct(w, p, size); else prefix_sorted(w, p, size);
+  return false;
+}
+FQ_DEV void add_s_letters(Wk &w, const u32 hist[4]) {  // update_s_letters, dna.cpp:2047-2057 (both strands)
+  w.s_let[0] += hist[0] + hist[3]; w.s_let[3] += hist[0] + hist[3];
+  w.s_let[1] += hist[1] + hist[2]; w.s_let[2] += hist[1] + hist[2];
+}
+// CompressDirect / CompressSorted, dna.cpp:1517-1556,1716-1754.  `prev` is the previous read of
+// this worker inside the block (read_prev is cleared per block, application.cpp:624), or null.
+// first_of_pair = false: the second mate coded by CompressDirect(..., false): direct prefix, no duplicate flag
+FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev_size, bool first_of_pair = true) {
+  const DevCfg *cfg = w.cfg;
+  const bool orig = !first_of_pair || cfg->mode == 0 || cfg->mode == 2;
+  u32 hist[4];
+  TM_BEGIN(t_head);
+  const bool same = read_head(w, p, size, prev, prev_size, first_of_pair, hist);
   TM_END(w, TM_READ_HEAD, t_head);
+  if (same) return;
   suffix(w, p, size, orig);
-  // update_s_letters, dna.cpp:2047-2057 (both strands)
-  h0 = wave_sum32(h0); h1 = wave_sum32(h1); h2 = wave_sum32(h2); h3 = wave_sum32(h3);
-  w.s_let[0] += h0 + h3; w.s_let[3] += h0 + h3;
-  w.s_let[1] += h1 + h2; w.s_let[2] += h1 + h2;
+  add_s_letters(w, hist);
   w.st[ST_BASES] += size;
+}
+// The same with the head taken from the read-head wave's record `idx` (single-end sorted mode of the encode kernel)
+FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx) {
+  WgShared *sm = w.sm;
+  TM_BEGIN(t_head);
+  u32 spins = 0;
+  while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
+    fq_sleep();
+    if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; return; }   // never spin forever on the GPU
+  }
+  const HeadRec *rec = &sm->hd[idx & 1];
+  const u32 n_raw = rec->n_raw;
+  const bool same = rec->same != 0;
+  // the head's symbols take their place in the stream
+  if (cq_wait_space(w, n_raw)) {
+    for (u32 j = FQ_LANE; j < n_raw; j += FQ_WAVE) {
+      const u32 e = (w.cq_tail + j) & (FQSX_CQ - 1);
+      sm->cq_key[e][0] = rec->raw[j][0];
+      sm->cq_key[e][1] = rec->raw[j][1];
+      sm->cq_kind[e] = SK_RAW;
+      sm->cq_rsym[e] = 5;
+    }
+    FQ_SYNC();
+    cq_publish(w, n_raw);
+  }
+  if (!same) {
+    mail_push(w, MAIL_P, rec->pmail[0]);
+    mail_push(w, MAIL_P, rec->pmail[1]);
+    w.pm.dir = rec->kdir[0]; w.pm.rc = rec->krc[0]; w.pm.cur = rec->kcur[0];
+    w.sm_.dir = rec->kdir[1]; w.sm_.rc = rec->krc[1]; w.sm_.cur = rec->kcur[1];
+    w.bm.dir = rec->kdir[2]; w.bm.rc = rec->krc[2]; w.bm.cur = rec->kcur[2];
+    w.pm_u = w.pm; w.sm_u = w.sm_; w.bm_u = w.bm;
+    w.cor_pos = 0;
+    w.N_run = rec->n_run;
+    w.rdp = sm->rd[idx & 1];
+    u32 hist[4] = {rec->hist[0], rec->hist[1], rec->hist[2], rec->hist[3]};
+    TM_END(w, TM_READ_HEAD, t_head);
+    suffix(w, p, size, false);
+    add_s_letters(w, hist);
+    w.st[ST_BASES] += size;
+  }
+  FQ_SYNC();
+  lds_store_rel(&sm->hd_taken, idx + 1);   // the record and its staging buffer are free again
 }
 
 #include "fqsx_pe.h"
@@ -2356,6 +2440,8 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
   w.err = 0;
   w.piped = false;   // this wave codes directly
   w.lqh = false;
+  w.rec = nullptr;
+  w.rdp = sm->rd[0];
   w.cq_head = w.cq_tail = 0;
   w.c_r_sym = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
@@ -2435,6 +2521,75 @@ FQ_DEV void inserter_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
   if (FQ_LANE == 0 && lins) atomic_add64(&cfg.ws[tid].stat[ST_LINS], lins);
 }
 
+// The read-head wave of the encode kernel (single-end sorted mode): for every read of the segment, one read ahead of
+// the resolving wave, the duplicate test, the staging of the read's codes in LDS, the p-mer prefix (rank sweep over
+// the p-mer vector, which only changes between launches) and the arithmetic of the head's small models -- everything
+// that depends on the reads alone.  It owns the head's contexts (flag histories, previous p-mer) and small models;
+// the symbols reach the coder wave as finished triples via the resolving wave, which keeps the stream order.
+FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg) {
+  if (cfg.mode != 1) return;
+  Wk w;
+  w.cfg = &cfg;
+  w.sm = sm;
+  w.tid = tid;
+  WState *ws = cfg.ws + tid;
+  w.ws = ws;
+  w.err = 0;
+  w.piped = false;
+  w.lqh = false;
+  w.cq_head = w.cq_tail = 0;
+  for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
+  for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
+  const u64 T = cfg.T;
+  u64 first = (u64)tid * n_reads / T, last = ((u64)tid + 1) * n_reads / T;   // PartitionForWorkers, reads_block.h:197-214
+  if (tid) first &= ~1ull;
+  if (tid + 1 < T) last &= ~1ull;
+  const u64 cur = seg == 0 ? first : ws->cursor;
+  u64 stop = last;
+  if (seg < S) stop = ((u64)seg + 1) * (last - first) / ((u64)S + 1) + first + 1;   // application.cpp:643
+  if (stop > last) stop = last;
+  for (u64 i = cur; i < stop && !w.err; ++i) {
+    const u32 idx = (u32)(i - cur);
+    u32 spins = 0;
+    while ((i32)(idx - lds_load_acq(&sm->hd_taken)) >= 2) {   // both records in use
+      fq_sleep();
+      if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+    }
+    if (w.err) break;
+    HeadRec *rec = &sm->hd[idx & 1];
+    w.rec = rec;
+    w.rdp = sm->rd[idx & 1];
+    FQ_SYNC();
+    if (FQ_LANE == 0) { rec->n_raw = 0; rec->n_p = 0; }
+    FQ_SYNC();
+    const u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
+    const u8 *prev = nullptr;
+    u32 prev_size = 0;
+    if (i > first) {
+      const u64 q0 = cfg.read_off[i - 1];
+      prev = cfg.bases + q0;
+      prev_size = (u32)(o0 - q0);
+    }
+    u32 hist[4];
+    const bool same = read_head(w, cfg.bases + o0, (u32)(o1 - o0), prev, prev_size, true, hist);
+    FQ_SYNC();
+    if (FQ_LANE == 0) {
+      rec->same = same ? 1u : 0u;
+      rec->n_run = w.N_run;
+      for (u32 x = 0; x < 4; ++x) rec->hist[x] = hist[x];
+      rec->kdir[0] = w.pm.dir; rec->krc[0] = w.pm.rc; rec->kcur[0] = w.pm.cur;
+      rec->kdir[1] = w.sm_.dir; rec->krc[1] = w.sm_.rc; rec->kcur[1] = w.sm_.cur;
+      rec->kdir[2] = w.bm.dir; rec->krc[2] = w.bm.rc; rec->kcur[2] = w.bm.cur;
+    }
+    FQ_SYNC();
+    lds_store_rel(&sm->hd_ready, idx + 1);
+  }
+  if (FQ_LANE == 0) {
+    for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
+  }
+  if (w.err) *cfg.err = w.err;
+}
+
 // piped: this wave is the resolving half of a two-wave worker (see coder_segment_body)
 FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, bool decode = false, bool piped = false) {
   Wk w;
@@ -2446,6 +2601,9 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.err = 0;
   w.piped = piped;
   w.lqh = piped;
+  w.rec = nullptr;
+  w.rdp = sm->rd[0];
+  const bool heads = piped && cfg.mode == 1;   // single-end sorted: the read heads come from the read-head wave
   w.cq_head = w.cq_tail = 0;
   w.c_r_sym = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
@@ -2518,7 +2676,12 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
     }
     ws->dec_pos = w.din_pos;
     ws->dec_buffer = w.din_buffer;
-  } else if (!paired)
+  } else if (heads)
+    for (u64 i = cur; i < stop && !w.err; ++i) {
+      u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
+      compress_read_rec(w, cfg.bases + o0, (u32)(o1 - o0), (u32)(i - cur));
+    }
+  else if (!paired)
     for (u64 i = cur; i < stop && !w.err; ++i) {
       u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
       const u8 *prev = nullptr;

@@ -202,16 +202,16 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
   u64 m1[4], a1[3], x1;
   {
     int mss = (int)size1 - k + 1, s1 = mss / 4, s2 = 2 * mss / 4, s3 = 3 * mss / 4;
-    m1[0] = pe_find_minimizer(cfg, sm->rd, 0, s1 + k - 1);
-    m1[1] = pe_find_minimizer(cfg, sm->rd, s1, s2 - s1 + k - 1);
-    m1[2] = pe_find_minimizer(cfg, sm->rd, s2, s3 - s2 + k - 1);
-    m1[3] = pe_find_minimizer(cfg, sm->rd, s3, (int)size1 - s3);
+    m1[0] = pe_find_minimizer(cfg, w.rdp, 0, s1 + k - 1);
+    m1[1] = pe_find_minimizer(cfg, w.rdp, s1, s2 - s1 + k - 1);
+    m1[2] = pe_find_minimizer(cfg, w.rdp, s2, s3 - s2 + k - 1);
+    m1[3] = pe_find_minimizer(cfg, w.rdp, s3, (int)size1 - s3);
     int a = mss / 3, b = 2 * mss / 3;
-    a1[0] = pe_find_minimizer(cfg, sm->rd, 0, a + k - 1);
-    a1[1] = pe_find_minimizer(cfg, sm->rd, a, b - a + k - 1);
-    a1[2] = pe_find_minimizer(cfg, sm->rd, b, (int)size1 - b);
+    a1[0] = pe_find_minimizer(cfg, w.rdp, 0, a + k - 1);
+    a1[1] = pe_find_minimizer(cfg, w.rdp, a, b - a + k - 1);
+    a1[2] = pe_find_minimizer(cfg, w.rdp, b, (int)size1 - b);
     int mid1 = ((int)size1 + k) / 2;
-    x1 = (~pe_find_maximizer(cfg, sm->rd, mid1 - k + 1, (int)size1 - (mid1 - k + 1))) & vm;
+    x1 = (~pe_find_maximizer(cfg, w.rdp, mid1 - k + 1, (int)size1 - (mid1 - k + 1))) & vm;
   }
   // second mate's codes
   FQ_SYNC();
@@ -278,19 +278,19 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
 #undef MPOS_ENC
       // CompressDirectWithMinim (dna.cpp:1559-1638): right part forwards from the anchor ...
       FQ_SYNC();
-      for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) sm->rd[i] = sm->r2c[i];
+      for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) w.rdp[i] = sm->r2c[i];
       FQ_SYNC();
-      pe_seed_kmers(w, sm->rd, mpos, mpos + (u32)k);
+      pe_seed_kmers(w, w.rdp, mpos, mpos + (u32)k);
       suffix(w, p2, size2, true, (u32)k + mpos, false, mpos);
       // ... then the left part on the reverse complement, anchored at the same b-mer
       const u32 rsz = mpos + (u32)k;
       FQ_SYNC();
       for (u32 i = FQ_LANE; i < rsz; i += FQ_WAVE) {
         u32 c = sm->r2c[rsz - 1 - i];
-        sm->rd[i] = (u8)(c == 4 ? 4 : 3 - c);
+        w.rdp[i] = (u8)(c == 4 ? 4 : 3 - c);
       }
       FQ_SYNC();
-      pe_seed_kmers(w, sm->rd, 0, (u32)k);
+      pe_seed_kmers(w, w.rdp, 0, (u32)k);
       suffix(w, p2, rsz, true, (u32)k, true, 0);
       // update_s_letters(p2), dna.cpp:1635
       u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0;
