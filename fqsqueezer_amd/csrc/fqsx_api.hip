@@ -34,24 +34,27 @@ extern "C" const char *fqsx_version(void) {
 
 // ---------------------------------------------------------------------------------------
 // kernels
-// One workgroup = one logical worker = four wavefronts (one per SIMD of its CU): wave 0 resolves the worker's reads (k-mer tables, counts,
+// One workgroup = one logical worker = five wavefronts: wave 0 resolves the worker's reads (k-mer tables, counts,
 // corrections, mailboxes) and queues every symbol in LDS, wave 1 codes them (context models + range coder), wave 2 applies the worker's local-table inserts,
-// wave 3 prepares the head of the next read (duplicate test, p-mer prefix).
+// wave 3 prepares the head of the next read (duplicate test, p-mer prefix), wave 4 runs stage P (k-mer rolling and table
+// probes, one position per lane) of the chunks ahead.
 #ifndef FQSX_EMU
-FQ_KERNEL256 void k_encode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
+FQ_KERNEL320 void k_encode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
   FQ_SHARED WgShared sm;
   if (threadIdx.x == 0) {
     sm.cq_tail = 0; sm.cq_head = 0; sm.cq_done = 0;
     sm.lq_target[0] = sm.lq_target[1] = 0; sm.lq_done[0] = sm.lq_done[1] = 0; sm.lq_quit = 0;
     sm.hd_ready = 0; sm.hd_taken = 0;
+    sm.sc_ready = 0; sm.sc_taken = 0; sm.sc_skip = 0; sm.sc_hd_taken = 0;
   }
   FQ_WG_BARRIER();
   if (FQ_WAVE_ID == 0) encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg, false, true);
   else if (FQ_WAVE_ID == 1) coder_segment_body(cfg, &sm, FQ_BLOCK, seg);
   else if (FQ_WAVE_ID == 2) inserter_segment_body(cfg, &sm, FQ_BLOCK);
-  else head_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
+  else if (FQ_WAVE_ID == 3) head_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
+  else scout_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
 }
-#define ENCODE_THREADS 256
+#define ENCODE_THREADS 320
 #else
 FQ_KERNEL64 void k_encode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
   FQ_SHARED WgShared sm;

@@ -8,6 +8,34 @@
 
 // ---------------------------------------------------------------------------------------
 // workgroup-shared (LDS) state of one worker
+// One stage-P chunk: everything about positions i0..i0+n-1 of a read that does not depend on the adaptive models,
+// computed one position per lane under the assumption "no k-mer correction since the k-mers stage P started from".
+struct SpecBuf {
+  u32 h_read, h_i0, h_n;       // scout chunks: read index within the launch, first position, positions
+  u32 h_pq_lo[2];              // list entries (b, s) below these were in the local tables when the chunk's probes started
+  u32 h_np, h_nlp;             // probes issued (global, local) ...
+  u64 h_ns, h_nls;             // ... and slots scanned, accounted when the chunk is used
+  u64 sp_sdir[6][FQSX_SPEC];   // rolled k-mers after insert_zero: pm, sm, bm, pm_u, sm_u, bm_u
+  u64 sp_src[6][FQSX_SPEC];
+  u8 sp_scur[6][FQSX_SPEC];
+  u64 sp_key[FQSX_SPEC][10];   // context keys of the position's symbol: 7 code levels (r_sym field left 0) or 10 letter levels
+  u8 sp_kind[FQSX_SPEC];       // how the position's symbol is coded: SK_* (set by stage P for settled positions, else by stage C)
+  u64 sp_cq[FQSX_SPEC];        // SK_RANK_PENDING: the four counts, 16 bits each
+  u8 sp_lvz[FQSX_SPEC];        // SK_RANK_PENDING: level | cor_zone << 4
+  u8 sp_flag[FQSX_SPEC];       // 0 slow path, 1 b-mer hit (fast path), 3 slow path with known global b-mer miss
+  u8 sp_rsym[FQSX_SPEC];       // rank of the read's symbol under those counts
+  u8 sp_rep[FQSX_SPEC];        // fast path: symbol repair_kmers_existing substitutes, or 0xff
+  u8 sp_nrun[FQSX_SPEC];       // N_run_len before the position
+  // mailbox entries of the chunk's positions (stage Q appends them lane-parallel)
+  u64 pv_b[FQSX_SPEC], pv_s[FQSX_SPEC], pv_pd[FQSX_SPEC], pv_pr[FQSX_SPEC];
+  u8 pv_flag[FQSX_SPEC];       // PV_* bits
+  // stage P, positions whose global b-mer probe missed: the rest of find_counts' cascade and the
+  // Hamming-1 fall-back, resolved lane-parallel (valid while no pending local insert interferes)
+  u32 sx_lb[FQSX_SPEC];        // local b-mer counts, 4 x 8 bit
+  u64 sx_s[FQSX_SPEC];         // global s-mer counts, 4 x 16 bit
+  u64 sx_ls[FQSX_SPEC];        // local s-mer counts, 4 x 16 bit
+  u8 sx_flag[FQSX_SPEC];       // SX_* bits
+};
 // What the read-head wave hands over per read: the head's symbols as finished coder triples, the p-mer list
 // entries, the rolling k-mers after the prefix and the read's letter histogram.
 #define FQSX_HD_RAW 56u
@@ -28,23 +56,10 @@ struct WgShared {
   u64 bk_key[256];             // probe batch: normalised k-mers
   u32 bk_res[256][4];          // probe batch: counts
   u8 bk_dir[256];              // probe batch: orientation
-  // speculation chunk (stage P): everything about positions i0..i0+63 that does not depend on the
-  // adaptive models, computed one position per lane under the assumption "no k-mer correction
-  // inside the chunk" (a correction ends the chunk, so the assumption holds for what is used)
-  u64 sp_sdir[6][FQSX_SPEC];   // rolled k-mers after insert_zero: pm, sm, bm, pm_u, sm_u, bm_u
-  u64 sp_src[6][FQSX_SPEC];
-  u8 sp_scur[6][FQSX_SPEC];
-  u64 sp_key[FQSX_SPEC][10];   // context keys of the position's symbol: 7 code levels (r_sym field left 0) or 10 letter levels
-  u8 sp_kind[FQSX_SPEC];       // how the position's symbol is coded: SK_* (set by stage P for settled positions, else by stage C)
-  u64 sp_cq[FQSX_SPEC];        // SK_RANK_PENDING: the four counts, 16 bits each
-  u8 sp_lvz[FQSX_SPEC];        // SK_RANK_PENDING: level | cor_zone << 4
-  u8 sp_flag[FQSX_SPEC];       // 0 slow path, 1 b-mer hit (fast path), 3 slow path with known global b-mer miss
-  u8 sp_rsym[FQSX_SPEC];       // rank of the read's symbol under those counts
-  u8 sp_rep[FQSX_SPEC];        // fast path: symbol repair_kmers_existing substitutes, or 0xff
-  u8 sp_nrun[FQSX_SPEC];       // N_run_len before the position
-  // mailbox entries of the chunk's positions (stage Q appends them lane-parallel)
-  u64 pv_b[FQSX_SPEC], pv_s[FQSX_SPEC], pv_pd[FQSX_SPEC], pv_pr[FQSX_SPEC];
-  u8 pv_flag[FQSX_SPEC];       // PV_* bits
+  SpecBuf sb[3];               // [0] filled by the resolving wave itself, [1..2] ring filled by the scout wave
+  u32 sc_ready, sc_taken;      // scout chunks published / released (free-running); chunk c lives in sb[1 + c % 2]
+  u32 sc_skip;                 // reads below this index (within the launch) need no further scout chunks
+  u32 sc_hd_taken;             // read heads the scout wave is done with
   u64 lev_tmp[10];             // level keys of a position coded outside the fast path
   // fast_run: per-position results of the lane-parallel context search / model stage
   u32 fr_idx[64], fr_c0[64], fr_thr[64], fr_vis[64];   // final slot, its counter, threshold to re-validate (or ~0), slots visited
@@ -62,12 +77,6 @@ struct WgShared {
   u64 ib_pos[64];              // insert_batch: target slot per lane
   // hand-off words of the local-table inserter wave: list entries published / applied per kind (b, s); quit
   u32 lq_target[2], lq_done[2], lq_quit;
-  // stage P, positions whose global b-mer probe missed: the rest of find_counts' cascade and the
-  // Hamming-1 fall-back, resolved lane-parallel (valid while no pending local insert interferes)
-  u32 sx_lb[FQSX_SPEC];        // local b-mer counts, 4 x 8 bit
-  u64 sx_s[FQSX_SPEC];         // global s-mer counts, 4 x 16 bit
-  u64 sx_ls[FQSX_SPEC];        // local s-mer counts, 4 x 16 bit
-  u8 sx_flag[FQSX_SPEC];       // SX_* bits
   // coding queue: every symbol of the worker's stream in stream order, as the context keys of a rank-/letter-coded
   // position (SK_RANK / SK_LETTER) or as a finished (freq, cum, total) triple of a small direct-indexed model
   // (SK_RAW: key[0] = freq | cum << 32, key[1] = total).  Filled by the wave that resolves the reads, drained by
@@ -109,6 +118,11 @@ struct Wk {
   bool lqh;                             // a third wave of the workgroup applies the local inserts (else: inline, on demand)
   u32 lq_pub[2];                        // entries already published to that wave
   u8 *rdp;                              // LDS staging buffer of the current read's codes
+  SpecBuf *sb;                          // stage-P chunk in use
+  bool scout;                           // stage P of clean chunks comes from the scout wave
+  bool sc_abandoned;                    // ... but no longer for the current read (a k-mer correction happened)
+  u32 sc_read;                          // index of the current read within the launch
+  u32 sc_taken;                         // scout chunks released so far
   HeadRec *rec;                         // read-head wave: where the head's output goes (null: code / push directly)
   bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
   u32 cq_tail, cq_head;                 // this wave's copy of its own queue index
@@ -1530,8 +1544,8 @@ FQ_DEV bool pend_conflict(Wk &w, u32 qi, const KGeom &g, const Kmer &km, u32 q_d
   const u64 grp = nd ? (v >> 2) : (v & lowmask);
   bool hit = false;
   for (u32 t = q_done + FQ_LANE; t < j; t += FQ_WAVE)
-    if (sm->pv_flag[t] & (qi ? PV_S : PV_B)) {
-      u64 pv = (qi ? sm->pv_s[t] : sm->pv_b[t]) >> (64 - k2);
+    if (w.sb->pv_flag[t] & (qi ? PV_S : PV_B)) {
+      u64 pv = (qi ? w.sb->pv_s[t] : w.sb->pv_b[t]) >> (64 - k2);
       hit |= nd ? ((pv >> 2) == grp) : ((pv & lowmask) == grp);
     }
   return wave_any(hit);
@@ -1547,18 +1561,21 @@ FQ_DEV u32 repair_decide(const Wk &w, const C4 &c, u32 sym) {
 // forward to position i0+j, probes the global b-mer table and -- on a plain hit -- derives everything
 // that depends only on (counts, position, symbol): the 7 context keys, the symbol's rank, the
 // repair decision; it also prepares the position's mailbox entries.
-FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed) {
+// The k-mers in w are the state before position i0 - joff (joff = 0: before the chunk itself; the scout wave starts
+// every chunk of a read from the state after the read's prefix).
+FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed, u32 joff = 0) {
   const DevCfg *cfg = w.cfg;
-  WgShared *sm = w.sm;
   u64 ns = 0, nls = 0;
   u32 np = 0, nlp = 0;
-  w.pq_lo[0] = lq_done_now(w, 0);   // everything below is in the local tables before the probes start
-  w.pq_lo[1] = lq_done_now(w, 1);
+  const u32 lo0 = lq_done_now(w, 0), lo1 = lq_done_now(w, 1);   // everything below is in the local tables before the probes start
   FQ_SYNC();
+  if (FQ_LANE == 0) { w.sb->h_pq_lo[0] = lo0; w.sb->h_pq_lo[1] = lo1; }
+  const u32 b0 = i0 - joff;   // position the k-mers in w stand before
   for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
-    // roll the six k-mers j symbols forward in closed form: only the last min(j, k) new symbols matter
+    // roll the six k-mers J symbols forward in closed form: only the last min(J, k) new symbols matter
     u64 fw = 0, rv = 0;   // new symbols packed oldest-first (fw) and complemented newest-first (rv)
-    const u32 L = j < 27 ? j : 27;
+    const u32 J = j + joff;
+    const u32 L = J < 27 ? J : 27;
     for (u32 s = 0; s < L; ++s) {
       u32 c = rd_sym(w, p, i0 + j - L + s, size);
       u64 ck = c == 4 ? 0 : c;
@@ -1567,21 +1584,21 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
     }
     u32 nrun = 0;
     {
-      u32 s = j;
-      while (s > 0 && rd_sym(w, p, i0 + s - 1, size) == 4) { --s; ++nrun; }
+      u32 s = J;
+      while (s > 0 && rd_sym(w, p, b0 + s - 1, size) == 4) { --s; ++nrun; }
       if (s == 0) nrun += w.N_run;
     }
-    Kmer pm = km_roll(w.pm, cfg->gp, j, fw, rv, L), sk = km_roll(w.sm_, cfg->gs, j, fw, rv, L), bm = km_roll(w.bm, cfg->gb, j, fw, rv, L);
-    Kmer pu = km_roll(w.pm_u, cfg->gp, j, fw, rv, L), su = km_roll(w.sm_u, cfg->gs, j, fw, rv, L), bu = km_roll(w.bm_u, cfg->gb, j, fw, rv, L);
+    Kmer pm = km_roll(w.pm, cfg->gp, J, fw, rv, L), sk = km_roll(w.sm_, cfg->gs, J, fw, rv, L), bm = km_roll(w.bm, cfg->gb, J, fw, rv, L);
+    Kmer pu = km_roll(w.pm_u, cfg->gp, J, fw, rv, L), su = km_roll(w.sm_u, cfg->gs, J, fw, rv, L), bu = km_roll(w.bm_u, cfg->gb, J, fw, rv, L);
     km_insert_zero(pm, cfg->gp); km_insert_zero(sk, cfg->gs); km_insert_zero(bm, cfg->gb);
     km_insert_zero(pu, cfg->gp); km_insert_zero(su, cfg->gs); km_insert_zero(bu, cfg->gb);
-    sm->sp_sdir[0][j] = pm.dir; sm->sp_src[0][j] = pm.rc; sm->sp_scur[0][j] = (u8)pm.cur;
-    sm->sp_sdir[1][j] = sk.dir; sm->sp_src[1][j] = sk.rc; sm->sp_scur[1][j] = (u8)sk.cur;
-    sm->sp_sdir[2][j] = bm.dir; sm->sp_src[2][j] = bm.rc; sm->sp_scur[2][j] = (u8)bm.cur;
-    sm->sp_sdir[3][j] = pu.dir; sm->sp_src[3][j] = pu.rc; sm->sp_scur[3][j] = (u8)pu.cur;
-    sm->sp_sdir[4][j] = su.dir; sm->sp_src[4][j] = su.rc; sm->sp_scur[4][j] = (u8)su.cur;
-    sm->sp_sdir[5][j] = bu.dir; sm->sp_src[5][j] = bu.rc; sm->sp_scur[5][j] = (u8)bu.cur;
-    sm->sp_nrun[j] = (u8)(nrun > 255 ? 255 : nrun);
+    w.sb->sp_sdir[0][j] = pm.dir; w.sb->sp_src[0][j] = pm.rc; w.sb->sp_scur[0][j] = (u8)pm.cur;
+    w.sb->sp_sdir[1][j] = sk.dir; w.sb->sp_src[1][j] = sk.rc; w.sb->sp_scur[1][j] = (u8)sk.cur;
+    w.sb->sp_sdir[2][j] = bm.dir; w.sb->sp_src[2][j] = bm.rc; w.sb->sp_scur[2][j] = (u8)bm.cur;
+    w.sb->sp_sdir[3][j] = pu.dir; w.sb->sp_src[3][j] = pu.rc; w.sb->sp_scur[3][j] = (u8)pu.cur;
+    w.sb->sp_sdir[4][j] = su.dir; w.sb->sp_src[4][j] = su.rc; w.sb->sp_scur[4][j] = (u8)su.cur;
+    w.sb->sp_sdir[5][j] = bu.dir; w.sb->sp_src[5][j] = bu.rc; w.sb->sp_scur[5][j] = (u8)bu.cur;
+    w.sb->sp_nrun[j] = (u8)(nrun > 255 ? 255 : nrun);
     const u32 i = i0 + j, sym = rd_sym(w, p, i, size);
     const u64 symk = sym == 4 ? 0 : sym;
     u32 flag = 0, rep = 0xff;
@@ -1615,8 +1632,8 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           u64 lev[7];
           if (!reversed) ctx_codes(lev, cfg, c, w.s_let, i, LV_BMER, cz, 0, size);
           else ctx_codes(lev, cfg, c, w.s_let, size - i - 1, LV_BMER, cz, 0, ~0u);  // dna.cpp:750-752
-          for (u32 l = 0; l < 7; ++l) sm->sp_key[j][l] = lev[l];
-          sm->sp_rsym[j] = (u8)rank_sym(w, c, sym);
+          for (u32 l = 0; l < 7; ++l) w.sb->sp_key[j][l] = lev[l];
+          w.sb->sp_rsym[j] = (u8)rank_sym(w, c, sym);
           // repair_kmers_existing decision (dna.cpp:333-360)
           rep = repair_decide(w, c, sym);
         }
@@ -1632,30 +1649,30 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           ++nlp;
           if (c4_any(l)) {
             xf |= SX_LB;
-            sm->sx_lb[j] = l.c[0] | (l.c[1] << 8) | (l.c[2] << 16) | (l.c[3] << 24);
+            w.sb->sx_lb[j] = l.c[0] | (l.c[1] << 8) | (l.c[2] << 16) | (l.c[3] << 24);
           } else {
             c4_zero(l);
             tab_rest(cfg->g_s, fs, ks, nds, l, ns);
             ++np;
             if (c4_any(l)) {
               xf |= SX_S;
-              sm->sx_s[j] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
+              w.sb->sx_s[j] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
             } else {
               tab_rest(cfg->l_s, fls, ks, nds, l, nls);
               ++nlp;
               if (c4_any(l)) {
                 xf |= SX_LS;
-                sm->sx_ls[j] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
+                w.sb->sx_ls[j] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
               }
             }
           }
         }
-        sm->sx_flag[j] = (u8)xf;
+        w.sb->sx_flag[j] = (u8)xf;
       }
     }
-    sm->sp_flag[j] = (u8)flag;
-    sm->sp_kind[j] = flag == 1 ? SK_RANK : SK_NONE;
-    sm->sp_rep[j] = (u8)rep;
+    w.sb->sp_flag[j] = (u8)flag;
+    w.sb->sp_kind[j] = flag == 1 ? SK_RANK : SK_NONE;
+    w.sb->sp_rep[j] = (u8)rep;
     // mailbox entries of this position (dna.cpp:818-852), k-mers after replace_last(sym)
     km_replace_last(pm, symk); km_replace_last(sk, symk); km_replace_last(bm, symk);
     u32 pf = 0;
@@ -1667,17 +1684,26 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
         if (flag == 1) pf |= (b_full && c4_get(c, sym) >= 3) ? PV_PHID : PV_P;
       }
     }
-    sm->pv_b[j] = km_norm(bm, cfg->gb);
-    sm->pv_s[j] = km_norm(sk, cfg->gs);
-    sm->pv_pd[j] = km_aligned_dir(pm);
-    sm->pv_pr[j] = km_aligned_rc(pm);
-    sm->pv_flag[j] = (u8)pf;
+    w.sb->pv_b[j] = km_norm(bm, cfg->gb);
+    w.sb->pv_s[j] = km_norm(sk, cfg->gs);
+    w.sb->pv_pd[j] = km_aligned_dir(pm);
+    w.sb->pv_pr[j] = km_aligned_rc(pm);
+    w.sb->pv_flag[j] = (u8)pf;
   }
   FQ_SYNC();
-  w.st[ST_GPROBE] += wave_sum32(np);
-  w.st[ST_GSLOT] += wave_sum64(ns);
-  w.st[ST_LPROBE] += wave_sum32(nlp);
-  w.st[ST_LSLOT] += wave_sum64(nls);
+  np = wave_sum32(np); nlp = wave_sum32(nlp);
+  ns = wave_sum64(ns); nls = wave_sum64(nls);
+  if (FQ_LANE == 0) { w.sb->h_np = np; w.sb->h_nlp = nlp; w.sb->h_ns = ns; w.sb->h_nls = nls; }
+  FQ_SYNC();
+}
+// a stage-P chunk becomes the one the resolving wave works on
+FQ_DEV void spec_adopt(Wk &w) {
+  w.pq_lo[0] = w.sb->h_pq_lo[0];
+  w.pq_lo[1] = w.sb->h_pq_lo[1];
+  w.st[ST_GPROBE] += w.sb->h_np;
+  w.st[ST_GSLOT] += w.sb->h_ns;
+  w.st[ST_LPROBE] += w.sb->h_nlp;
+  w.st[ST_LSLOT] += w.sb->h_nls;
 }
 
 // Stage Q: append the mailbox entries of chunk positions [a,b) to this worker's lists, lane-parallel,
@@ -1691,20 +1717,20 @@ FQ_DEV void flush_pushes(Wk &w, u32 a, u32 b) {
   FQ_SYNC();
   for (u32 base = a; base < b; base += FQ_WAVE) {
     const u32 t = base + FQ_LANE;
-    const u32 f = t < b ? sm->pv_flag[t] : 0;
+    const u32 f = t < b ? w.sb->pv_flag[t] : 0;
     const u32 nb = f & PV_B ? 1u : 0u, nsm = f & PV_S ? 1u : 0u, npm = f & PV_P ? 2u : 0u, nh = f & PV_PHID ? 2u : 0u;
     const u32 ob = wave_excl_scan32(nb), os = wave_excl_scan32(nsm), op = wave_excl_scan32(npm);
     const u32 tb = wave_sum32(nb), ts = wave_sum32(nsm), tp = wave_sum32(npm);
     if (w.mn[MAIL_B] + tb > mb.cap || w.mn[MAIL_S] + ts > ms.cap || w.mn[MAIL_P] + tp > mp.cap) { w.err = FQSX_ERR_MAIL_FULL; return; }
-    if (nb) mb.list[(u64)w.tid * mb.cap + w.mn[MAIL_B] + ob] = sm->pv_b[t];
-    if (nsm) ms.list[(u64)w.tid * ms.cap + w.mn[MAIL_S] + os] = sm->pv_s[t];
+    if (nb) mb.list[(u64)w.tid * mb.cap + w.mn[MAIL_B] + ob] = w.sb->pv_b[t];
+    if (nsm) ms.list[(u64)w.tid * ms.cap + w.mn[MAIL_S] + os] = w.sb->pv_s[t];
     // LDS mirror of the most recent list entries
-    if (nb) sm->pq_key[0][(w.mn[MAIL_B] + ob) & (FQSX_PQ - 1)] = sm->pv_b[t];
-    if (nsm) sm->pq_key[1][(w.mn[MAIL_S] + os) & (FQSX_PQ - 1)] = sm->pv_s[t];
+    if (nb) sm->pq_key[0][(w.mn[MAIL_B] + ob) & (FQSX_PQ - 1)] = w.sb->pv_b[t];
+    if (nsm) sm->pq_key[1][(w.mn[MAIL_S] + os) & (FQSX_PQ - 1)] = w.sb->pv_s[t];
     if (npm) {
       u64 *dst = mp.list + (u64)w.tid * mp.cap + w.mn[MAIL_P] + op;
-      dst[0] = sm->pv_pd[t];
-      dst[1] = sm->pv_pr[t];
+      dst[0] = w.sb->pv_pd[t];
+      dst[1] = w.sb->pv_pr[t];
     }
     w.mn[MAIL_B] += tb; w.mn[MAIL_S] += ts; w.mn[MAIL_P] += tp;
     w.hidden += wave_sum32(nh);
@@ -1716,13 +1742,13 @@ FQ_DEV void flush_pushes(Wk &w, u32 a, u32 b) {
 // rolled k-mer state of chunk position j (after insert_zero)
 FQ_DEV void load_state(Wk &w, u32 j) {
   WgShared *sm = w.sm;
-  w.pm.dir = sm->sp_sdir[0][j]; w.pm.rc = sm->sp_src[0][j]; w.pm.cur = sm->sp_scur[0][j];
-  w.sm_.dir = sm->sp_sdir[1][j]; w.sm_.rc = sm->sp_src[1][j]; w.sm_.cur = sm->sp_scur[1][j];
-  w.bm.dir = sm->sp_sdir[2][j]; w.bm.rc = sm->sp_src[2][j]; w.bm.cur = sm->sp_scur[2][j];
-  w.pm_u.dir = sm->sp_sdir[3][j]; w.pm_u.rc = sm->sp_src[3][j]; w.pm_u.cur = sm->sp_scur[3][j];
-  w.sm_u.dir = sm->sp_sdir[4][j]; w.sm_u.rc = sm->sp_src[4][j]; w.sm_u.cur = sm->sp_scur[4][j];
-  w.bm_u.dir = sm->sp_sdir[5][j]; w.bm_u.rc = sm->sp_src[5][j]; w.bm_u.cur = sm->sp_scur[5][j];
-  w.N_run = sm->sp_nrun[j];
+  w.pm.dir = w.sb->sp_sdir[0][j]; w.pm.rc = w.sb->sp_src[0][j]; w.pm.cur = w.sb->sp_scur[0][j];
+  w.sm_.dir = w.sb->sp_sdir[1][j]; w.sm_.rc = w.sb->sp_src[1][j]; w.sm_.cur = w.sb->sp_scur[1][j];
+  w.bm.dir = w.sb->sp_sdir[2][j]; w.bm.rc = w.sb->sp_src[2][j]; w.bm.cur = w.sb->sp_scur[2][j];
+  w.pm_u.dir = w.sb->sp_sdir[3][j]; w.pm_u.rc = w.sb->sp_src[3][j]; w.pm_u.cur = w.sb->sp_scur[3][j];
+  w.sm_u.dir = w.sb->sp_sdir[4][j]; w.sm_u.rc = w.sb->sp_src[4][j]; w.sm_u.cur = w.sb->sp_scur[4][j];
+  w.bm_u.dir = w.sb->sp_sdir[5][j]; w.bm_u.rc = w.sb->sp_src[5][j]; w.bm_u.cur = w.sb->sp_scur[5][j];
+  w.N_run = w.sb->sp_nrun[j];
 }
 FQ_DEV void replace_last_all(Wk &w, u64 symk) {
   km_replace_last(w.pm, symk); km_replace_last(w.sm_, symk); km_replace_last(w.bm, symk);
@@ -1772,24 +1798,24 @@ FQ_DEV void code_keys(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reversed
   const DevCfg *cfg = w.cfg;
   FQ_SYNC();
   for (u32 j = FQ_LANE; j < m; j += FQ_WAVE) {
-    const u32 kind = sm->sp_kind[j], pos = i0 + j, sym = rd_sym(w, p, pos, size);
+    const u32 kind = w.sb->sp_kind[j], pos = i0 + j, sym = rd_sym(w, p, pos, size);
     if (kind == SK_RANK_PENDING) {
-      const u64 cq = sm->sp_cq[j];
+      const u64 cq = w.sb->sp_cq[j];
       C4 c;
       c.c[0] = (u32)(cq & 0xffff); c.c[1] = (u32)((cq >> 16) & 0xffff); c.c[2] = (u32)((cq >> 32) & 0xffff); c.c[3] = (u32)(cq >> 48);
-      const u32 level = sm->sp_lvz[j] & 15u, cz = sm->sp_lvz[j] >> 4;
+      const u32 level = w.sb->sp_lvz[j] & 15u, cz = w.sb->sp_lvz[j] >> 4;
       u64 lev[7];
       if (!reversed) ctx_codes(lev, cfg, c, w.s_let, pos, level, cz, 0, size);
       else ctx_codes(lev, cfg, c, w.s_let, size - pos - 1, level, cz, 0, ~0u);   // dna.cpp:750-752
-      for (u32 l = 0; l < 7; ++l) sm->sp_key[j][l] = lev[l];
-      sm->sp_rsym[j] = (u8)rank_sym(w, c, sym);
-      sm->sp_kind[j] = SK_RANK;
+      for (u32 l = 0; l < 7; ++l) w.sb->sp_key[j][l] = lev[l];
+      w.sb->sp_rsym[j] = (u8)rank_sym(w, c, sym);
+      w.sb->sp_kind[j] = SK_RANK;
     } else if (kind == SK_LETTER_PENDING) {
       u64 lev[10];
       ctx_letters_keys(lev, cfg, pos, letters_before(w, p, pos, size, hist_start), size);   // dna.cpp:520-528,776-785
-      for (u32 l = 0; l < 10; ++l) sm->sp_key[j][l] = lev[l];
-      sm->sp_rsym[j] = (u8)sym;
-      sm->sp_kind[j] = SK_LETTER;
+      for (u32 l = 0; l < 10; ++l) w.sb->sp_key[j][l] = lev[l];
+      w.sb->sp_rsym[j] = (u8)sym;
+      w.sb->sp_kind[j] = SK_LETTER;
     }
   }
   FQ_SYNC();
@@ -2076,11 +2102,11 @@ FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reverse
   if (!cq_wait_space(w, m)) return;
   for (u32 j = FQ_LANE; j < m; j += FQ_WAVE) {
     const u32 e = (w.cq_tail + j) & (FQSX_CQ - 1);
-    const u32 kind = sm->sp_kind[j];
+    const u32 kind = w.sb->sp_kind[j];
     const u32 nk = kind == SK_LETTER ? 10u : 7u;
-    for (u32 l = 0; l < nk; ++l) sm->cq_key[e][l] = sm->sp_key[j][l];
+    for (u32 l = 0; l < nk; ++l) sm->cq_key[e][l] = w.sb->sp_key[j][l];
     sm->cq_kind[e] = (u8)(kind | (first && j == 0 ? SK_RESET : 0u));
-    sm->cq_rsym[e] = sm->sp_rsym[j];
+    sm->cq_rsym[e] = w.sb->sp_rsym[j];
   }
   FQ_SYNC();
   first = false;
@@ -2088,6 +2114,30 @@ FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reverse
   if (!w.piped) {
     while (w.cq_head != w.cq_tail && !w.err) w.cq_head += cq_process(w, w.cq_head, w.cq_tail - w.cq_head);
     TM_END(w, TM_FAST, t_c2);
+  }
+}
+
+// hand-over of the scout wave's stage-P chunks (see scout_segment_body)
+FQ_DEV void scout_release(Wk &w) {
+  w.sc_taken += 1;
+  FQ_SYNC();
+  lds_store_rel(&w.sm->sc_taken, w.sc_taken);
+}
+FQ_DEV bool scout_take(Wk &w, u32 i, u32 n) {
+  WgShared *sm = w.sm;
+  for (;;) {
+    u32 spins = 0;
+    while (lds_load_acq(&sm->sc_ready) == w.sc_taken) {
+      fq_sleep();
+      if (++spins > (1u << 22)) { w.sc_abandoned = true; return false; }   // never spin forever on the GPU
+    }
+    SpecBuf *b = &sm->sb[1 + (w.sc_taken & 1)];
+    const u32 r = b->h_read;
+    if ((i32)(r - w.sc_read) < 0) { scout_release(w); continue; }   // left over from a read that was finished without the scout
+    if (r == w.sc_read && b->h_i0 == i && b->h_n == n) { w.sb = b; return true; }
+    w.sc_abandoned = true;
+    lds_store_rel(&sm->sc_skip, w.sc_read + 1);
+    return false;
   }
 }
 
@@ -2102,12 +2152,18 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
   while (i < size && !w.err) {
     const u32 n = size - i < FQSX_SPEC ? size - i : FQSX_SPEC;
     TM_BEGIN(t_sp);
-    speculate(w, p, size, i, n, reversed);
+    bool pre = false;
+    if (w.scout && !w.sc_abandoned) pre = scout_take(w, i, n);   // stage P done ahead of time by the scout wave
+    if (!pre) {
+      w.sb = &sm->sb[0];
+      speculate(w, p, size, i, n, reversed);
+    }
+    spec_adopt(w);
     TM_END(w, TM_SPEC, t_sp);
     TM_COUNT(w, CN_CHUNK);
     u64 Fm = 0, Rm = 0;   // positions settled by stage P; settled positions whose repair fires
     for (u32 t = FQ_LANE; t < 64; t += FQ_WAVE) {
-      const bool f = t < n && sm->sp_flag[t] == 1, r = f && sm->sp_rep[t] != 0xff;
+      const bool f = t < n && w.sb->sp_flag[t] == 1, r = f && w.sb->sp_rep[t] != 0xff;
 #if FQ_WAVE > 1
       Fm = wave_ballot(f); Rm = wave_ballot(r);
 #else
@@ -2122,7 +2178,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       const u32 pos = i + j;
       const u32 sym = rd_sym(w, p, pos, size);
       const u64 sym_k = sym == 4 ? 0 : sym;
-      const u32 flag = sm->sp_flag[j];
+      const u32 flag = w.sb->sp_flag[j];
       TM_BEGIN(t_code);
       if (flag == 1) {
         // settled by stage P (level bmer): nothing to resolve; skip the whole stretch of such positions up to the
@@ -2135,7 +2191,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         const u32 pos = i + j;
         const u32 sym = rd_sym(w, p, pos, size);
         const u64 sym_k = sym == 4 ? 0 : sym;
-        const u32 rep = sm->sp_rep[j];
+        const u32 rep = w.sb->sp_rep[j];
 #ifdef FQSX_TIMING
         w.tm[CN_FAST] += len;
 #endif
@@ -2155,15 +2211,15 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         // not settled by stage P alone
         C4 counts;
         c4_zero(counts);
-        u32 level = LV_NONE, nrun_here = sm->sp_nrun[j];
+        u32 level = LV_NONE, nrun_here = w.sb->sp_nrun[j];
         bool rough = false, loaded = false, resolved = false;
         TM_COUNT(w, CN_SLOW);
-        const u32 xf = flag == 3 ? sm->sx_flag[j] : 0;
+        const u32 xf = flag == 3 ? w.sb->sx_flag[j] : 0;
         if (xf & SX_VALID) {
           // the cascade was resolved in stage P; it stands unless a pending local insert interferes
           Kmer bmj, smj;
-          bmj.dir = sm->sp_sdir[2][j]; bmj.rc = sm->sp_src[2][j]; bmj.cur = sm->sp_scur[2][j];
-          smj.dir = sm->sp_sdir[1][j]; smj.rc = sm->sp_src[1][j]; smj.cur = sm->sp_scur[1][j];
+          bmj.dir = w.sb->sp_sdir[2][j]; bmj.rc = w.sb->sp_src[2][j]; bmj.cur = w.sb->sp_scur[2][j];
+          smj.dir = w.sb->sp_sdir[1][j]; smj.rc = w.sb->sp_src[1][j]; smj.cur = w.sb->sp_scur[1][j];
           bool conflict = pend_conflict(w, 0, cfg->gb, bmj, q_done, j);
           if (!conflict && !(xf & (SX_LB | SX_S))) conflict = pend_conflict(w, 1, cfg->gs, smj, q_done, j);
           if (conflict) TM_COUNT(w, CN_CONFLICT);
@@ -2171,11 +2227,11 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
             resolved = true;
             TM_COUNT(w, CN_EXT);
             if (xf & SX_LB) {
-              u32 pc = sm->sx_lb[j];
+              u32 pc = w.sb->sx_lb[j];
               counts.c[0] = pc & 0xff; counts.c[1] = (pc >> 8) & 0xff; counts.c[2] = (pc >> 16) & 0xff; counts.c[3] = pc >> 24;
               level = LV_BMER;
             } else if (xf & (SX_S | SX_LS)) {
-              u64 pc = (xf & SX_S) ? sm->sx_s[j] : sm->sx_ls[j];
+              u64 pc = (xf & SX_S) ? w.sb->sx_s[j] : w.sb->sx_ls[j];
               counts.c[0] = (u32)(pc & 0xffff); counts.c[1] = (u32)((pc >> 16) & 0xffff);
               counts.c[2] = (u32)((pc >> 32) & 0xffff); counts.c[3] = (u32)(pc >> 48);
               level = LV_SMER;
@@ -2229,14 +2285,14 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           if (rough) cor_zone = 3;
           FQ_SYNC();
           if (FQ_LANE == 0) {   // keys, rank and coding: stage C2
-            sm->sp_cq[j] = (u64)(counts.c[0] & 0xffff) | ((u64)(counts.c[1] & 0xffff) << 16) | ((u64)(counts.c[2] & 0xffff) << 32) | ((u64)(counts.c[3] & 0xffff) << 48);
-            sm->sp_lvz[j] = (u8)(level | (cor_zone << 4));
-            sm->sp_kind[j] = SK_RANK_PENDING;
+            w.sb->sp_cq[j] = (u64)(counts.c[0] & 0xffff) | ((u64)(counts.c[1] & 0xffff) << 16) | ((u64)(counts.c[2] & 0xffff) << 32) | ((u64)(counts.c[3] & 0xffff) << 48);
+            w.sb->sp_lvz[j] = (u8)(level | (cor_zone << 4));
+            w.sb->sp_kind[j] = SK_RANK_PENDING;
           }
           FQ_SYNC();
         } else {
           FQ_SYNC();
-          if (FQ_LANE == 0) sm->sp_kind[j] = SK_LETTER_PENDING;
+          if (FQ_LANE == 0) w.sb->sp_kind[j] = SK_LETTER_PENDING;
           FQ_SYNC();
         }
         TM_END(w, TM_SCODE, t_sc);
@@ -2258,21 +2314,21 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           }
           FQ_SYNC();
           if (FQ_LANE == 0) {
-            sm->pv_b[j] = km_norm(w.bm, cfg->gb);
-            sm->pv_s[j] = km_norm(w.sm_, cfg->gs);
-            sm->pv_pd[j] = km_aligned_dir(w.pm);
-            sm->pv_pr[j] = km_aligned_rc(w.pm);
-            sm->pv_flag[j] = (u8)pf;
+            w.sb->pv_b[j] = km_norm(w.bm, cfg->gb);
+            w.sb->pv_s[j] = km_norm(w.sm_, cfg->gs);
+            w.sb->pv_pd[j] = km_aligned_dir(w.pm);
+            w.sb->pv_pr[j] = km_aligned_rc(w.pm);
+            w.sb->pv_flag[j] = (u8)pf;
           }
           FQ_SYNC();
           w_pos = j + 1;
         } else {
           // stage P's entries stand (k-mers unmodified); settle the p-mer entry, which depends on the level
-          u32 pf = sm->pv_flag[j];
+          u32 pf = w.sb->pv_flag[j];
           if (pf & PV_PCAND) {
             pf |= (lvl_sbm && c4_get(counts, sym) >= 3) ? PV_PHID : PV_P;   // the b-mer is full on this path
             FQ_SYNC();
-            if (FQ_LANE == 0) sm->pv_flag[j] = (u8)pf;
+            if (FQ_LANE == 0) w.sb->pv_flag[j] = (u8)pf;
             FQ_SYNC();
           }
         }
@@ -2319,6 +2375,11 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       load_state(w, m - 1);
       replace_last_all(w, sym == 4 ? 0 : sym);
       w.N_run = sym == 4 ? w.N_run + 1 : 0;
+    }
+    if (pre) scout_release(w);
+    if (dirty && w.scout && !w.sc_abandoned) {   // the scout's clean-read assumption no longer holds for this read
+      w.sc_abandoned = true;
+      lds_store_rel(&sm->sc_skip, w.sc_read + 1);
     }
     i += m;
   }
@@ -2410,6 +2471,8 @@ FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx) {
     w.cor_pos = 0;
     w.N_run = rec->n_run;
     w.rdp = sm->rd[idx & 1];
+    w.sc_read = idx;
+    w.sc_abandoned = false;
     u32 hist[4] = {rec->hist[0], rec->hist[1], rec->hist[2], rec->hist[3]};
     TM_END(w, TM_READ_HEAD, t_head);
     suffix(w, p, size, false);
@@ -2444,6 +2507,8 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
   w.rdp = sm->rd[0];
   w.cq_head = w.cq_tail = 0;
   w.c_r_sym = 0;
+  w.sb = &sm->sb[0];
+  w.scout = false;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
   for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
   if (seg == 0) { w.enc.low = 0; w.enc.range = 0xff00000000000000ULL; w.enc.len = 0; }   // application.cpp:624-628
@@ -2537,6 +2602,8 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
   w.err = 0;
   w.piped = false;
   w.lqh = false;
+  w.scout = false;
+  w.sb = &sm->sb[0];
   w.cq_head = w.cq_tail = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
   for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
@@ -2551,7 +2618,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
   for (u64 i = cur; i < stop && !w.err; ++i) {
     const u32 idx = (u32)(i - cur);
     u32 spins = 0;
-    while ((i32)(idx - lds_load_acq(&sm->hd_taken)) >= 2) {   // both records in use
+    while ((i32)(idx - lds_load_acq(&sm->hd_taken)) >= 2 || (i32)(idx - lds_load_acq(&sm->sc_hd_taken)) >= 2) {   // both records in use
       fq_sleep();
       if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
     }
@@ -2590,6 +2657,83 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
   if (w.err) *cfg.err = w.err;
 }
 
+// The scout wave of the encode kernel (single-end sorted mode): stage P of every chunk of every read, ahead of the
+// resolving wave, under the assumption that the read needs no k-mer correction -- then the rolling k-mers at any
+// position follow from the read's symbols and the state after its prefix (head record), the correction position
+// stays 0, and the letter totals are those of the reads before it.  Chunks go through a ring of two SpecBufs tagged
+// (read, first position); the resolving wave adopts the chunk it is about to process if the tag matches and falls
+// back to its own stage P for the rest of a read once a correction has happened (sc_skip tells the scout to move on).
+// The chunk records which local-list entries were already applied when its probes started, so the resolving wave's
+// validation of the local probes (pend_conflict) covers exactly the entries the scout may have missed.
+FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg) {
+  if (cfg.mode != 1) return;
+  Wk w;
+  w.cfg = &cfg;
+  w.sm = sm;
+  w.tid = tid;
+  WState *ws = cfg.ws + tid;
+  w.ws = ws;
+  w.err = 0;
+  w.piped = false;
+  w.lqh = true;    // (reads the inserter wave's progress)
+  w.rec = nullptr;
+  w.scout = false;
+  for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
+  for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
+  for (u32 i = 0; i < 4; ++i) w.s_let[i] = ws->s_letters[i];
+  const u64 T = cfg.T;
+  u64 first = (u64)tid * n_reads / T, last = ((u64)tid + 1) * n_reads / T;   // PartitionForWorkers, reads_block.h:197-214
+  if (tid) first &= ~1ull;
+  if (tid + 1 < T) last &= ~1ull;
+  const u64 cur = seg == 0 ? first : ws->cursor;
+  u64 stop = last;
+  if (seg < S) stop = ((u64)seg + 1) * (last - first) / ((u64)S + 1) + first + 1;   // application.cpp:643
+  if (stop > last) stop = last;
+  u32 made = 0;
+  bool quit = false;
+  for (u64 i = cur; i < stop && !quit; ++i) {
+    const u32 idx = (u32)(i - cur);
+    u32 spins = 0;
+    while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
+      fq_sleep();
+      if (lds_load_acq(&sm->cq_done) || ++spins > (1u << 23)) { quit = true; break; }
+    }
+    if (quit) break;
+    const HeadRec *rec = &sm->hd[idx & 1];
+    if (!rec->same) {
+      const u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
+      const u8 *p = cfg.bases + o0;
+      const u32 size = (u32)(o1 - o0);
+      w.rdp = sm->rd[idx & 1];
+      w.pm.dir = rec->kdir[0]; w.pm.rc = rec->krc[0]; w.pm.cur = rec->kcur[0];
+      w.sm_.dir = rec->kdir[1]; w.sm_.rc = rec->krc[1]; w.sm_.cur = rec->kcur[1];
+      w.bm.dir = rec->kdir[2]; w.bm.rc = rec->krc[2]; w.bm.cur = rec->kcur[2];
+      w.pm_u = w.pm; w.sm_u = w.sm_; w.bm_u = w.bm;
+      w.cor_pos = 0;
+      w.N_run = rec->n_run;
+      const u32 hist[4] = {rec->hist[0], rec->hist[1], rec->hist[2], rec->hist[3]};
+      for (u32 i0 = cfg.pmer; i0 < size && !quit; i0 += FQSX_SPEC) {
+        spins = 0;
+        while (made - lds_load_acq(&sm->sc_taken) >= 2) {   // both ring buffers hold unreleased chunks
+          fq_sleep();
+          if (lds_load_acq(&sm->cq_done) || ++spins > (1u << 23)) { quit = true; break; }
+        }
+        if (quit || lds_load_acq(&sm->sc_skip) > idx) break;
+        const u32 n = size - i0 < FQSX_SPEC ? size - i0 : FQSX_SPEC;
+        w.sb = &sm->sb[1 + (made & 1)];
+        speculate(w, p, size, i0, n, false, i0 - cfg.pmer);
+        if (FQ_LANE == 0) { w.sb->h_read = idx; w.sb->h_i0 = i0; w.sb->h_n = n; }
+        FQ_SYNC();
+        made += 1;
+        lds_store_rel(&sm->sc_ready, made);
+      }
+      add_s_letters(w, hist);
+    }
+    FQ_SYNC();
+    lds_store_rel(&sm->sc_hd_taken, idx + 1);
+  }
+}
+
 // piped: this wave is the resolving half of a two-wave worker (see coder_segment_body)
 FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, bool decode = false, bool piped = false) {
   Wk w;
@@ -2604,6 +2748,11 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.rec = nullptr;
   w.rdp = sm->rd[0];
   const bool heads = piped && cfg.mode == 1;   // single-end sorted: the read heads come from the read-head wave
+  w.sb = &sm->sb[0];
+  w.scout = heads;
+  w.sc_abandoned = false;
+  w.sc_read = 0;
+  w.sc_taken = 0;
   w.cq_head = w.cq_tail = 0;
   w.c_r_sym = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
