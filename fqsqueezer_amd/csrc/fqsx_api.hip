@@ -48,10 +48,11 @@ FQ_KERNEL320 void k_encode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
     sm.sc_ready = 0; sm.sc_taken = 0; sm.sc_skip = 0; sm.sc_hd_taken = 0;
   }
   FQ_WG_BARRIER();
-  if (FQ_WAVE_ID == 0) encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg, false, true);
-  else if (FQ_WAVE_ID == 1) coder_segment_body(cfg, &sm, FQ_BLOCK, seg);
-  else if (FQ_WAVE_ID == 2) inserter_segment_body(cfg, &sm, FQ_BLOCK);
-  else if (FQ_WAVE_ID == 3) head_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
+  // (waves 0 and 4 land on the same SIMD: the two least busy roles share it)
+  if (FQ_WAVE_ID == 1) encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg, false, true);
+  else if (FQ_WAVE_ID == 2) coder_segment_body(cfg, &sm, FQ_BLOCK, seg);
+  else if (FQ_WAVE_ID == 4) inserter_segment_body(cfg, &sm, FQ_BLOCK);
+  else if (FQ_WAVE_ID == 0) head_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
   else scout_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
 }
 #define ENCODE_THREADS 320
@@ -94,11 +95,23 @@ FQ_KERNEL64 void k_gather_stats(DevCfg cfg, u64 *out) {
   }
 }
 // stable partition of the mailbox lists by owner (count -> scan -> group offsets -> scatter)
-FQ_KERNEL64 void k_part_count(DevCfg cfg, u32 kind) {
-  FQ_SHARED u32 hist[256];
-  part_count_body(cfg, kind, FQ_BLOCK, hist);
+// (one launch covers the three mailbox kinds: blocks [0, g0) kind 0, [g0, g0+g1) kind 1, the rest kind 2)
+FQ_DEV void part_split(const DevCfg &cfg, u32 &kind, u32 &blk) {
+  kind = 0;
+  blk = FQ_BLOCK;
+  for (; kind < 2; ++kind) {
+    const u32 g = cfg.T * cfg.mail[kind].n_tiles;
+    if (blk < g) break;
+    blk -= g;
+  }
 }
-FQ_KERNEL64 void k_part_scan(DevCfg cfg, u32 kind) { part_scan_body(cfg, kind, FQ_BLOCK); }
+FQ_KERNEL64 void k_part_count(DevCfg cfg) {
+  FQ_SHARED u32 hist[256];
+  u32 kind, blk;
+  part_split(cfg, kind, blk);
+  part_count_body(cfg, kind, blk, hist);
+}
+FQ_KERNEL64 void k_part_scan(DevCfg cfg) { part_scan_body(cfg, FQ_BLOCK / cfg.T, FQ_BLOCK % cfg.T); }
 FQ_KERNEL64 void k_part_dstoff(DevCfg cfg, u32 *demand /*[2][T]+1*/) {
   part_dstoff_body(cfg, FQ_BLOCK);
   // per-owner demand of the coming insert phase (s- and b-mers) + the device error word
@@ -112,10 +125,12 @@ FQ_KERNEL64 void k_part_dstoff(DevCfg cfg, u32 *demand /*[2][T]+1*/) {
     }
   if (FQ_BLOCK == 0 && FQ_LANE == 0) demand[2 * cfg.T] = *cfg.err;
 }
-FQ_KERNEL64 void k_part_scatter(DevCfg cfg, u32 kind) {
+FQ_KERNEL64 void k_part_scatter(DevCfg cfg) {
   FQ_SHARED u32 cursor[256];
   FQ_SHARED u32 ld[64];
-  part_scatter_body(cfg, kind, FQ_BLOCK, cursor, ld);
+  u32 kind, blk;
+  part_split(cfg, kind, blk);
+  part_scatter_body(cfg, kind, blk, cursor, ld);
 }
 // paired-end insert phase: per-owner demand, then the inserts
 FQ_KERNEL64 void k_pe_demand(DevCfg cfg, u32 *demand) {
@@ -587,8 +602,9 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
     if (decode) LAUNCH(c, 0, k_decode_segment, T, 64, cfg, n_reads, (u32)S, seg);
     else LAUNCH(c, 0, k_encode_segment, T, ENCODE_THREADS, cfg, n_reads, (u32)S, seg);
     // size the global tables for this phase's inserts (exact per-owner demand)
-    for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_count, T * cfg.mail[k].n_tiles, 64, cfg, k);
-    for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_scan, T, 64, cfg, k);
+    const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
+    LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
+    LAUNCH(c, 2, k_part_scan, 3 * T, 64, cfg);
     LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand);
     if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, (4 * T + 1) * sizeof(u32)))) return rc;
     if (c->h_demand[2 * T]) {
@@ -614,7 +630,7 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
       if ((rc = dzero(c, cfg.l_pe.val, need_lpe * T * sizeof(u64)))) return rc;
       if ((rc = dzero(c, cfg.l_pe.filled, T * sizeof(u32)))) return rc;
     }
-    for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_part_scatter, T * cfg.mail[k].n_tiles, 64, cfg, k);
+    LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg);
     LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg);
     // ClearKmersToHT, dna.cpp:2475-2488 (mailbox counters are rewritten by the next encode launch)
     if ((rc = dzero(c, cfg.l_b.slots, need_lb * T * sizeof(u64)))) return rc;

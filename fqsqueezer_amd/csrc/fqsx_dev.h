@@ -8,6 +8,8 @@
 
 // ---------------------------------------------------------------------------------------
 // workgroup-shared (LDS) state of one worker
+#define FQSX_RR 6u
+#define FQSX_SCR 3u   // scout ring: chunks the scout wave may be ahead of their release
 // One stage-P chunk: everything about positions i0..i0+n-1 of a read that does not depend on the adaptive models,
 // computed one position per lane under the assumption "no k-mer correction since the k-mers stage P started from".
 struct SpecBuf {
@@ -35,6 +37,11 @@ struct SpecBuf {
   u64 sx_s[FQSX_SPEC];         // global s-mer counts, 4 x 16 bit
   u64 sx_ls[FQSX_SPEC];        // local s-mer counts, 4 x 16 bit
   u8 sx_flag[FQSX_SPEC];       // SX_* bits
+  // scout chunks: Hamming-1 sweeps (find_counts_rough_b) probed ahead for up to FQSX_RR positions whose cascade came up empty
+  u8 rr_idx[FQSX_SPEC];        // position -> sweep slot, 0xff = not probed ahead
+  u64 rr_res[FQSX_RR][64];     // per probe: the four sibling counts, 16 bits each
+  u64 rr_hit[FQSX_RR];         // probes that found something
+  u64 rr_ns[FQSX_RR];          // slots scanned
 };
 // What the read-head wave hands over per read: the head's symbols as finished coder triples, the p-mer list
 // entries, the rolling k-mers after the prefix and the read's letter histogram.
@@ -56,8 +63,8 @@ struct WgShared {
   u64 bk_key[256];             // probe batch: normalised k-mers
   u32 bk_res[256][4];          // probe batch: counts
   u8 bk_dir[256];              // probe batch: orientation
-  SpecBuf sb[3];               // [0] filled by the resolving wave itself, [1..2] ring filled by the scout wave
-  u32 sc_ready, sc_taken;      // scout chunks published / released (free-running); chunk c lives in sb[1 + c % 2]
+  SpecBuf sb[1 + FQSX_SCR];    // [0] filled by the resolving wave itself, [1..] ring filled by the scout wave
+  u32 sc_ready, sc_taken;      // scout chunks published / released (free-running); chunk c lives in sb[1 + c % FQSX_SCR]
   u32 sc_skip;                 // reads below this index (within the launch) need no further scout chunks
   u32 sc_hd_taken;             // read heads the scout wave is done with
   u64 lev_tmp[10];             // level keys of a position coded outside the fast path
@@ -1344,6 +1351,64 @@ FQ_DEV bool rough_kt(Wk &w, const KTab &t, const KGeom &g, const Kmer &can, u32 
   return c4_any(counts);
 }
 
+// The same sweep with its probes done ahead of time by the scout wave (slot r of the chunk): only the merges, which
+// draw from the worker's RNG in probe order, remain.
+FQ_DEV bool rough_merge_pre(Wk &w, u32 r, const KGeom &g, u32 rng, const Cinc &ci, C4 &counts) {
+  WgShared *sm = w.sm;
+  c4_zero(counts);
+  for (u64 mk = w.sb->rr_hit[r]; mk; mk &= mk - 1) {
+    const u64 v = w.sb->rr_res[r][ctz64(mk)];
+    counts.c[0] = cinc_merge(sm, rng, ci, counts.c[0], (u32)(v & 0xffff));
+    counts.c[1] = cinc_merge(sm, rng, ci, counts.c[1], (u32)((v >> 16) & 0xffff));
+    counts.c[2] = cinc_merge(sm, rng, ci, counts.c[2], (u32)((v >> 32) & 0xffff));
+    counts.c[3] = cinc_merge(sm, rng, ci, counts.c[3], (u32)(v >> 48));
+  }
+  w.st[ST_GPROBE] += 4 * (g.k - 1);
+  w.st[ST_GSLOT] += w.sb->rr_ns[r] + g.k - 1;
+  return c4_any(counts);
+}
+#if FQ_WAVE > 1
+// scout wave: the sweeps of the chunk's first FQSX_RR positions that will need one (global b-mer miss, cascade empty)
+FQ_DEV void scout_rough(Wk &w, u32 n) {
+  const DevCfg *cfg = w.cfg;
+  SpecBuf *sb = w.sb;
+  const KGeom &g = cfg->gb;
+  const u32 n3 = 3 * (g.k - 1);
+  if (n3 > 64) return;
+  const u32 lane = FQ_LANE;
+  FQ_SYNC();
+  const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_LB | SX_S | SX_LS)) == SX_VALID;
+  u64 cm = wave_ballot(cand);
+  for (u32 r = 0; cm && r < FQSX_RR; cm &= cm - 1, ++r) {
+    const u32 j = ctz64(cm);
+    const u64 cdir = sb->sp_sdir[2][j], crc = sb->sp_src[2][j];
+    u64 ns = 0, res = 0;
+    bool hit = false;
+    if (lane < n3) {
+      const u32 i = lane / 3, r3 = lane - 3 * i;
+      u32 sh = 62 - 2 * i;
+      const u32 orig = (u32)((cdir >> sh) & 3ull);
+      const u64 sy = r3 + (r3 >= orig ? 1u : 0u);
+      const u64 d = (cdir & ~(3ull << sh)) + (sy << sh);
+      sh = 64 - 2 * g.k + 2 * i;
+      const u64 rr = (crc & ~(3ull << sh)) + ((3 - sy) << sh);
+      const bool nd = (d & g.kernel_mask) < (rr & g.kernel_mask);
+      const u64 key = nd ? d : rr;
+      C4 c;
+      c4_zero(c);
+      tab_scan(cfg->g_b, sb_owner(cfg, key), key, nd, c, ns);
+      res = (u64)c.c[0] | ((u64)c.c[1] << 16) | ((u64)c.c[2] << 32) | ((u64)c.c[3] << 48);
+      hit = res != 0;
+      sb->rr_res[r][lane] = res;
+    }
+    const u64 hm = wave_ballot(hit);
+    ns = wave_sum64(ns);
+    if (lane == 0) { sb->rr_hit[r] = hm; sb->rr_ns[r] = ns; sb->rr_idx[j] = (u8)r; }
+  }
+  FQ_SYNC();
+}
+#endif
+
 // find_counts, dna.cpp:457-502.  b_miss_known: the speculation stage already probed the global
 // b-mer table for exactly this (full) b-mer and found nothing.
 FQ_DEV u32 find_counts(Wk &w, C4 &counts, bool b_miss_known) {
@@ -1570,6 +1635,7 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
   const u32 lo0 = lq_done_now(w, 0), lo1 = lq_done_now(w, 1);   // everything below is in the local tables before the probes start
   FQ_SYNC();
   if (FQ_LANE == 0) { w.sb->h_pq_lo[0] = lo0; w.sb->h_pq_lo[1] = lo1; }
+  for (u32 j = FQ_LANE; j < FQSX_SPEC; j += FQ_WAVE) w.sb->rr_idx[j] = 0xff;
   const u32 b0 = i0 - joff;   // position the k-mers in w stand before
   for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
     // roll the six k-mers J symbols forward in closed form: only the last min(J, k) new symbols matter
@@ -2131,7 +2197,7 @@ FQ_DEV bool scout_take(Wk &w, u32 i, u32 n) {
       fq_sleep();
       if (++spins > (1u << 22)) { w.sc_abandoned = true; return false; }   // never spin forever on the GPU
     }
-    SpecBuf *b = &sm->sb[1 + (w.sc_taken & 1)];
+    SpecBuf *b = &sm->sb[1 + w.sc_taken % FQSX_SCR];
     const u32 r = b->h_read;
     if ((i32)(r - w.sc_read) < 0) { scout_release(w); continue; }   // left over from a read that was finished without the scout
     if (r == w.sc_read && b->h_i0 == i && b->h_n == n) { w.sb = b; return true; }
@@ -2238,7 +2304,9 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
             } else {
               TM_BEGIN(t_r);
               TM_COUNT(w, CN_ROUGH);
-              rough = rough_kt(w, cfg->g_b, cfg->gb, bmj, RNG_B, CINC_B, counts);  // dna.cpp:711-718
+              const u32 rr = w.sb->rr_idx[j];
+              if (rr != 0xff) rough = rough_merge_pre(w, rr, cfg->gb, RNG_B, CINC_B, counts);
+              else rough = rough_kt(w, cfg->g_b, cfg->gb, bmj, RNG_B, CINC_B, counts);  // dna.cpp:711-718
               if (rough) level = LV_PMER;
               TM_END(w, TM_ROUGH, t_r);
             }
@@ -2660,7 +2728,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
 // The scout wave of the encode kernel (single-end sorted mode): stage P of every chunk of every read, ahead of the
 // resolving wave, under the assumption that the read needs no k-mer correction -- then the rolling k-mers at any
 // position follow from the read's symbols and the state after its prefix (head record), the correction position
-// stays 0, and the letter totals are those of the reads before it.  Chunks go through a ring of two SpecBufs tagged
+// stays 0, and the letter totals are those of the reads before it.  Chunks go through a small ring of SpecBufs tagged
 // (read, first position); the resolving wave adopts the chunk it is about to process if the tag matches and falls
 // back to its own stage P for the rest of a read once a correction has happened (sc_skip tells the scout to move on).
 // The chunk records which local-list entries were already applied when its probes started, so the resolving wave's
@@ -2714,14 +2782,17 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       const u32 hist[4] = {rec->hist[0], rec->hist[1], rec->hist[2], rec->hist[3]};
       for (u32 i0 = cfg.pmer; i0 < size && !quit; i0 += FQSX_SPEC) {
         spins = 0;
-        while (made - lds_load_acq(&sm->sc_taken) >= 2) {   // both ring buffers hold unreleased chunks
+        while (made - lds_load_acq(&sm->sc_taken) >= FQSX_SCR) {   // every ring buffer holds an unreleased chunk
           fq_sleep();
           if (lds_load_acq(&sm->cq_done) || ++spins > (1u << 23)) { quit = true; break; }
         }
         if (quit || lds_load_acq(&sm->sc_skip) > idx) break;
         const u32 n = size - i0 < FQSX_SPEC ? size - i0 : FQSX_SPEC;
-        w.sb = &sm->sb[1 + (made & 1)];
+        w.sb = &sm->sb[1 + made % FQSX_SCR];
         speculate(w, p, size, i0, n, false, i0 - cfg.pmer);
+#if FQ_WAVE > 1
+        scout_rough(w, n);
+#endif
         if (FQ_LANE == 0) { w.sb->h_read = idx; w.sb->h_i0 = i0; w.sb->h_n = n; }
         FQ_SYNC();
         made += 1;
