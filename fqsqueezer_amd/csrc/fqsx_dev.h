@@ -42,6 +42,11 @@ struct SpecBuf {
   u64 rr_res[FQSX_RR][64];     // per probe: the four sibling counts, 16 bits each
   u64 rr_hit[FQSX_RR];         // probes that found something
   u64 rr_ns[FQSX_RR];          // slots scanned
+  // scout chunks: the global-table look-ups of the read's first positions, whose b-mer is still partial (find_counts
+  // probes 4^m paddings of a partial k-mer): per trial the four sibling counts, in trial order
+  u8 ep_off[FQSX_SPEC][2];     // position, table (0 global b, 1 global s) -> first entry of ep_res, 0xff = not probed ahead
+  u64 ep_res[64];
+  u8 ep_ns[64];                // slots scanned per trial
 };
 // What the read-head wave hands over per read: the head's symbols as finished coder triples, the p-mer list
 // entries, the rolling k-mers after the prefix and the read's letter histogram.
@@ -534,8 +539,42 @@ FQ_DEV void lq_sync_for(Wk &w, u32 kind, const KGeom &g, const Kmer &km) {
 }
 
 // find / find_full / find_partial (ht_kmer.h:189-203,266-327,504-510)
-FQ_DEV bool kt_find(Wk &w, const KTab &t, bool global, const KGeom &g, const Kmer &km, u32 rng, const Cinc &ci, C4 &out) {
+FQ_DEV bool kt_find(Wk &w, const KTab &t, bool global, const KGeom &g, const Kmer &km, u32 rng, const Cinc &ci, C4 &out, u32 pre = 0xff) {
   c4_zero(out);
+  if (pre != 0xff) {   // the scout wave has probed this look-up's trials already (ep_res, trial order): merges only
+    const u32 m = g.k - km.cur, cnt = 1u << (2 * m);
+    u64 hm = 0;
+    u32 nsl = 0;
+    FQ_SYNC();
+#if FQ_WAVE > 1
+    {
+      const bool in = FQ_LANE < cnt;   // cnt <= 16
+      const u32 e = pre + (in ? FQ_LANE : 0u);
+      hm = wave_ballot(in && w.sb->ep_res[e] != 0);
+      nsl = in ? w.sb->ep_ns[e] : 0u;
+    }
+#else
+    for (u32 i = 0; i < cnt; ++i) {
+      hm |= (u64)(w.sb->ep_res[pre + i] != 0) << i;
+      nsl += w.sb->ep_ns[pre + i];
+    }
+#endif
+    w.st[ST_GPROBE] += cnt;
+    w.st[ST_GSLOT] += wave_sum32(nsl);
+    if (m == 0) {
+      const u64 v = w.sb->ep_res[pre];
+      out.c[0] = (u32)(v & 0xffff); out.c[1] = (u32)((v >> 16) & 0xffff); out.c[2] = (u32)((v >> 32) & 0xffff); out.c[3] = (u32)(v >> 48);
+      return c4_any(out);
+    }
+    for (u64 mk = hm; mk; mk &= mk - 1) {
+      const u64 v = w.sb->ep_res[pre + ctz64(mk)];
+      for (u32 x = 0; x < 4; ++x) {
+        const u32 loc = (u32)((v >> (16 * x)) & 0xffff);
+        if (loc) out.c[x] = cinc_merge(w.sm, rng, ci, out.c[x], loc);  // ht_kmer.h:321-323
+      }
+    }
+    return c4_any(out);
+  }
   if (km.cur == g.k) {
     u64 ns = 0;
     u64 key = km_norm(km, g);
@@ -1407,17 +1446,67 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
   }
   FQ_SYNC();
 }
+// scout wave, first chunk of a read: the global look-ups find_counts will make at the positions whose b-mer is still
+// partial -- all 4^m paddings of an almost full b-/s-mer (up to 16), or the one probe of a full s-mer -- in one round
+FQ_DEV void scout_early(Wk &w, u32 n) {
+  const DevCfg *cfg = w.cfg;
+  SpecBuf *sb = w.sb;
+  const u32 lane = FQ_LANE;
+  const u32 bmargin = cfg->bmer - cfg->smer - 1, smargin = cfg->smer - cfg->pmer + 1;
+  // groups of trials in (position, table) order; every lane derives the same list and picks its own trial
+  u32 total = 0, my_e = ~0u, my_tb = 0, my_t = 0, my_m = 0;
+  FQ_SYNC();
+  for (u32 e = 0; e < n && e < 32; ++e) {
+    const u32 cb = sb->sp_scur[2][e], cs = sb->sp_scur[1][e];
+    if (cb == cfg->gb.k) break;   // from here on stage P probes the full b-mer itself
+    for (u32 tb = 0; tb < 2; ++tb) {
+      const u32 cur = tb ? cs : cb, k = tb ? cfg->gs.k : cfg->gb.k, margin = tb ? smargin : bmargin;
+      if (cur + margin < k) continue;
+      const u32 m = k - cur;
+      if (m > 2) continue;
+      const u32 cnt = 1u << (2 * m);
+      if (total + cnt > 64) continue;
+      if (lane >= total && lane < total + cnt) { my_e = e; my_tb = tb; my_t = lane - total; my_m = m; }
+      if (lane == 0) sb->ep_off[e][tb] = (u8)total;
+      total += cnt;
+    }
+  }
+  if (my_e != ~0u) {
+    const KGeom &g = my_tb ? cfg->gs : cfg->gb;
+    const KTab &t = my_tb ? cfg->g_s : cfg->g_b;
+    const u32 kx = my_tb ? 1u : 2u;
+    const u64 kd = sb->sp_sdir[kx][my_e], kr = sb->sp_src[kx][my_e];
+    const u32 cur = sb->sp_scur[kx][my_e];
+    u64 d = my_m ? kd >> (2 * my_m) : kd, r = kr & (~0ull << (64 - 2 * cur));   // ht_kmer.h:291-310
+    for (u32 j = 0; j < my_m; ++j) {
+      const u64 sym = (my_t >> (2 * j)) & 3;
+      d |= sym << (62 - 2 * j);
+      r |= (3 - sym) << (64 - 2 * g.k + 2 * j);
+    }
+    const bool nd = (d & g.kernel_mask) < (r & g.kernel_mask);
+    const u64 key = nd ? d : r;
+    C4 c;
+    c4_zero(c);
+    u64 ns = 0;
+    tab_scan(t, sb_owner(cfg, key), key, nd, c, ns);
+    sb->ep_res[lane] = (u64)c.c[0] | ((u64)c.c[1] << 16) | ((u64)c.c[2] << 32) | ((u64)c.c[3] << 48);
+    sb->ep_ns[lane] = (u8)(ns > 255 ? 255 : ns);
+  }
+  FQ_SYNC();
+}
 #endif
 
 // find_counts, dna.cpp:457-502.  b_miss_known: the speculation stage already probed the global
 // b-mer table for exactly this (full) b-mer and found nothing.
-FQ_DEV u32 find_counts(Wk &w, C4 &counts, bool b_miss_known) {
+// ep: chunk position whose global look-ups the scout wave may have probed ahead (w's k-mers are that position's)
+FQ_DEV u32 find_counts(Wk &w, C4 &counts, bool b_miss_known, u32 ep = ~0u) {
   const DevCfg *cfg = w.cfg;
   c4_zero(counts);
   u32 bmargin = cfg->bmer - cfg->smer - 1;
   u32 smargin = cfg->smer - cfg->pmer + 1;
+  const u32 pre_b = ep != ~0u ? w.sb->ep_off[ep][0] : 0xffu, pre_s = ep != ~0u ? w.sb->ep_off[ep][1] : 0xffu;
   if (km_almost_full(w.bm, cfg->gb, bmargin)) {
-    if (!b_miss_known && kt_find(w, cfg->g_b, true, cfg->gb, w.bm, RNG_B, CINC_B, counts)) {
+    if (!b_miss_known && kt_find(w, cfg->g_b, true, cfg->gb, w.bm, RNG_B, CINC_B, counts, pre_b)) {
       u32 sat = (counts.c[0] == 63) + (counts.c[1] == 63) + (counts.c[2] == 63) + (counts.c[3] == 63);
       if (sat > 1) {
         C4 c2;
@@ -1433,7 +1522,7 @@ FQ_DEV u32 find_counts(Wk &w, C4 &counts, bool b_miss_known) {
     }
   }
   if (km_almost_full(w.sm_, cfg->gs, smargin)) {
-    if (kt_find(w, cfg->g_s, true, cfg->gs, w.sm_, RNG_S, CINC_S, counts)) return LV_SMER;
+    if (kt_find(w, cfg->g_s, true, cfg->gs, w.sm_, RNG_S, CINC_S, counts, pre_s)) return LV_SMER;
     lq_sync_for(w, MAIL_S, cfg->gs, w.sm_);
     if (kt_find(w, cfg->l_s, false, cfg->gs, w.sm_, RNG_LS, CINC_S, counts)) return LV_SMER;
   } else if (find_counts_p(w, counts))
@@ -1635,7 +1724,7 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
   const u32 lo0 = lq_done_now(w, 0), lo1 = lq_done_now(w, 1);   // everything below is in the local tables before the probes start
   FQ_SYNC();
   if (FQ_LANE == 0) { w.sb->h_pq_lo[0] = lo0; w.sb->h_pq_lo[1] = lo1; }
-  for (u32 j = FQ_LANE; j < FQSX_SPEC; j += FQ_WAVE) w.sb->rr_idx[j] = 0xff;
+  for (u32 j = FQ_LANE; j < FQSX_SPEC; j += FQ_WAVE) { w.sb->rr_idx[j] = 0xff; w.sb->ep_off[j][0] = 0xff; w.sb->ep_off[j][1] = 0xff; }
   const u32 b0 = i0 - joff;   // position the k-mers in w stand before
   for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
     // roll the six k-mers J symbols forward in closed form: only the last min(J, k) new symbols matter
@@ -2322,7 +2411,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           loaded = true;
           nrun_here = w.N_run;
           TM_BEGIN(t_fc);
-          level = find_counts(w, counts, flag == 3);
+          level = find_counts(w, counts, flag == 3, j);
           TM_END(w, TM_FINDC, t_fc);
           if (level == LV_BMER_UNC) {
             w.bm = w.bm_u; w.sm_ = w.sm_u; w.pm = w.pm_u;
@@ -2792,6 +2881,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         speculate(w, p, size, i0, n, false, i0 - cfg.pmer);
 #if FQ_WAVE > 1
         scout_rough(w, n);
+        if (i0 == cfg.pmer) scout_early(w, n);
 #endif
         if (FQ_LANE == 0) { w.sb->h_read = idx; w.sb->h_i0 = i0; w.sb->h_n = n; }
         FQ_SYNC();
