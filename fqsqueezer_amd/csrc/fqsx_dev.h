@@ -1874,8 +1874,16 @@ FQ_DEV void flush_pushes(Wk &w, u32 a, u32 b) {
     const u32 t = base + FQ_LANE;
     const u32 f = t < b ? w.sb->pv_flag[t] : 0;
     const u32 nb = f & PV_B ? 1u : 0u, nsm = f & PV_S ? 1u : 0u, npm = f & PV_P ? 2u : 0u, nh = f & PV_PHID ? 2u : 0u;
-    const u32 ob = wave_excl_scan32(nb), os = wave_excl_scan32(nsm), op = wave_excl_scan32(npm);
-    const u32 tb = wave_sum32(nb), ts = wave_sum32(nsm), tp = wave_sum32(npm);
+#if FQ_WAVE > 1
+    // every position contributes 0 or 1 (b, s) or 0 or 2 (p) entries: offsets and totals from ballots
+    const u64 lt = (1ull << FQ_LANE) - 1ull;
+    const u64 bb = wave_ballot(nb != 0), bs = wave_ballot(nsm != 0), bp = wave_ballot(npm != 0), bh = wave_ballot(nh != 0);
+    const u32 ob = popc64(bb & lt), os = popc64(bs & lt), op = 2 * popc64(bp & lt);
+    const u32 tb = popc64(bb), ts = popc64(bs), tp = 2 * popc64(bp), th = 2 * popc64(bh);
+#else
+    const u32 ob = 0, os = 0, op = 0;
+    const u32 tb = nb, ts = nsm, tp = npm, th = nh;
+#endif
     if (w.mn[MAIL_B] + tb > mb.cap || w.mn[MAIL_S] + ts > ms.cap || w.mn[MAIL_P] + tp > mp.cap) { w.err = FQSX_ERR_MAIL_FULL; return; }
     if (nb) mb.list[(u64)w.tid * mb.cap + w.mn[MAIL_B] + ob] = w.sb->pv_b[t];
     if (nsm) ms.list[(u64)w.tid * ms.cap + w.mn[MAIL_S] + os] = w.sb->pv_s[t];
@@ -1888,7 +1896,7 @@ FQ_DEV void flush_pushes(Wk &w, u32 a, u32 b) {
       dst[1] = w.sb->pv_pr[t];
     }
     w.mn[MAIL_B] += tb; w.mn[MAIL_S] += ts; w.mn[MAIL_P] += tp;
-    w.hidden += wave_sum32(nh);
+    w.hidden += th;
     w.st[ST_MAIL] += tb + ts + tp;
   }
   TM_END(w, TM_POST, t_q);

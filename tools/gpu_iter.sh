@@ -11,4 +11,6 @@ tail -4 $O/pytest.log
 timeout -k 10 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie --no-t255 --concurrent 0 > $O/bench.log 2>&1; echo "bench rc=$?" >> $O/bench.log
 tail -2 $O/bench.log
 if [ -f tools/libfqsx_timing.so ]; then timeout -k 10 300 python tools/gpu_timing.py 1000000 64 > $O/timing.log 2>&1; tail -5 $O/timing.log; fi
+
+timeout -k 10 400 python tools/gpu_blocks.py > $O/blocks.log 2>&1; tail -1 $O/blocks.log
 exit 0
