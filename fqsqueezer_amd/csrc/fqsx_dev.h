@@ -42,6 +42,11 @@ struct SpecBuf {
   u64 rr_res[FQSX_RR][64];     // per probe: the four sibling counts, 16 bits each
   u64 rr_hit[FQSX_RR];         // probes that found something
   u64 rr_ns[FQSX_RR];          // slots scanned
+  // ... and for every other such position in compact form when at most 3 of the sweep's probes found something
+  // (rr_idx 0xfe): which probes, and their counts in probe order
+  u64 rc_hit[FQSX_SPEC];
+  u64 rc_val[FQSX_SPEC][3];
+  u32 rc_ns[FQSX_SPEC];
   // scout chunks: the global-table look-ups of the read's first positions, whose b-mer is still partial (find_counts
   // probes 4^m paddings of a partial k-mer): per trial the four sibling counts, in trial order
   u8 ep_off[FQSX_SPEC][2];     // position, table (0 global b, 1 global s) -> first entry of ep_res, 0xff = not probed ahead
@@ -1392,9 +1397,22 @@ FQ_DEV bool rough_kt(Wk &w, const KTab &t, const KGeom &g, const Kmer &can, u32 
 
 // The same sweep with its probes done ahead of time by the scout wave (slot r of the chunk): only the merges, which
 // draw from the worker's RNG in probe order, remain.
-FQ_DEV bool rough_merge_pre(Wk &w, u32 r, const KGeom &g, u32 rng, const Cinc &ci, C4 &counts) {
+FQ_DEV bool rough_merge_pre(Wk &w, u32 r, u32 j, const KGeom &g, u32 rng, const Cinc &ci, C4 &counts) {
   WgShared *sm = w.sm;
   c4_zero(counts);
+  if (r == 0xfe) {   // compact form: the hits' counts are stored in probe order
+    u32 x = 0;
+    for (u64 mk = w.sb->rc_hit[j]; mk; mk &= mk - 1, ++x) {
+      const u64 v = w.sb->rc_val[j][x];
+      counts.c[0] = cinc_merge(sm, rng, ci, counts.c[0], (u32)(v & 0xffff));
+      counts.c[1] = cinc_merge(sm, rng, ci, counts.c[1], (u32)((v >> 16) & 0xffff));
+      counts.c[2] = cinc_merge(sm, rng, ci, counts.c[2], (u32)((v >> 32) & 0xffff));
+      counts.c[3] = cinc_merge(sm, rng, ci, counts.c[3], (u32)(v >> 48));
+    }
+    w.st[ST_GPROBE] += 4 * (g.k - 1);
+    w.st[ST_GSLOT] += w.sb->rc_ns[j] + g.k - 1;
+    return c4_any(counts);
+  }
   for (u64 mk = w.sb->rr_hit[r]; mk; mk &= mk - 1) {
     const u64 v = w.sb->rr_res[r][ctz64(mk)];
     counts.c[0] = cinc_merge(sm, rng, ci, counts.c[0], (u32)(v & 0xffff));
@@ -1407,7 +1425,9 @@ FQ_DEV bool rough_merge_pre(Wk &w, u32 r, const KGeom &g, u32 rng, const Cinc &c
   return c4_any(counts);
 }
 #if FQ_WAVE > 1
-// scout wave: the sweeps of the chunk's first FQSX_RR positions that will need one (global b-mer miss, cascade empty)
+// scout wave: the sweeps of the chunk's positions that will need one (global b-mer miss, cascade empty), four
+// sweeps in flight at a time (one probe of each per lane).  A sweep with at most 3 hits is kept in compact form,
+// fuller ones take one of the FQSX_RR full-size slots; whatever does not fit is left to the resolving wave.
 FQ_DEV void scout_rough(Wk &w, u32 n) {
   const DevCfg *cfg = w.cfg;
   SpecBuf *sb = w.sb;
@@ -1415,34 +1435,62 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
   const u32 n3 = 3 * (g.k - 1);
   if (n3 > 64) return;
   const u32 lane = FQ_LANE;
+  const u64 lt = (1ull << lane) - 1ull;
   FQ_SYNC();
   const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_LB | SX_S | SX_LS)) == SX_VALID;
   u64 cm = wave_ballot(cand);
-  for (u32 r = 0; cm && r < FQSX_RR; cm &= cm - 1, ++r) {
-    const u32 j = ctz64(cm);
-    const u64 cdir = sb->sp_sdir[2][j], crc = sb->sp_src[2][j];
-    u64 ns = 0, res = 0;
-    bool hit = false;
-    if (lane < n3) {
-      const u32 i = lane / 3, r3 = lane - 3 * i;
-      u32 sh = 62 - 2 * i;
-      const u32 orig = (u32)((cdir >> sh) & 3ull);
-      const u64 sy = r3 + (r3 >= orig ? 1u : 0u);
-      const u64 d = (cdir & ~(3ull << sh)) + (sy << sh);
-      sh = 64 - 2 * g.k + 2 * i;
-      const u64 rr = (crc & ~(3ull << sh)) + ((3 - sy) << sh);
-      const bool nd = (d & g.kernel_mask) < (rr & g.kernel_mask);
-      const u64 key = nd ? d : rr;
-      C4 c;
-      c4_zero(c);
-      tab_scan(cfg->g_b, sb_owner(cfg, key), key, nd, c, ns);
-      res = (u64)c.c[0] | ((u64)c.c[1] << 16) | ((u64)c.c[2] << 32) | ((u64)c.c[3] << 48);
-      hit = res != 0;
-      sb->rr_res[r][lane] = res;
+  u32 big = 0;
+  const bool in = lane < n3;
+  const u32 pi = lane / 3, r3 = lane - 3 * pi;
+  const u32 shd = 62 - 2 * pi, shr = 64 - 2 * g.k + 2 * pi;
+  while (cm) {
+    u32 js[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ok[q] = cm != 0;
+      js[q] = ok[q] ? ctz64(cm) : 0u;
+      cm &= cm - 1;
     }
-    const u64 hm = wave_ballot(hit);
-    ns = wave_sum64(ns);
-    if (lane == 0) { sb->rr_hit[r] = hm; sb->rr_ns[r] = ns; sb->rr_idx[j] = (u8)r; }
+    TabIt f[4];
+    u64 key[4];
+    bool nd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      key[q] = 0; nd[q] = false; f[q].s = nullptr; f[q].p = 0; f[q].it0 = 0; f[q].it1 = 0;
+      if (ok[q] && in) {
+        const u64 cdir = sb->sp_sdir[2][js[q]], crc = sb->sp_src[2][js[q]];
+        const u32 orig = (u32)((cdir >> shd) & 3ull);
+        const u64 sy = r3 + (r3 >= orig ? 1u : 0u);
+        const u64 d = (cdir & ~(3ull << shd)) + (sy << shd);
+        const u64 rr = (crc & ~(3ull << shr)) + ((3 - sy) << shr);
+        nd[q] = (d & g.kernel_mask) < (rr & g.kernel_mask);
+        key[q] = nd[q] ? d : rr;
+        f[q] = tab_first(cfg->g_b, sb_owner(cfg, key[q]), key[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!ok[q]) continue;   // (uniform)
+      u64 ns = 0, res = 0;
+      if (in) {
+        C4 c;
+        c4_zero(c);
+        tab_rest(cfg->g_b, f[q], key[q], nd[q], c, ns);
+        res = (u64)c.c[0] | ((u64)c.c[1] << 16) | ((u64)c.c[2] << 32) | ((u64)c.c[3] << 48);
+      }
+      const u64 hm = wave_ballot(res != 0);
+      const u32 nsum = wave_sum32((u32)ns);
+      const u32 nh = popc64(hm), j = js[q];
+      if (nh <= 3) {
+        if (res != 0) sb->rc_val[j][popc64(hm & lt)] = res;
+        if (lane == 0) { sb->rc_hit[j] = hm; sb->rc_ns[j] = nsum; sb->rr_idx[j] = 0xfe; }
+      } else if (big < FQSX_RR) {
+        if (in) sb->rr_res[big][lane] = res;
+        if (lane == 0) { sb->rr_hit[big] = hm; sb->rr_ns[big] = nsum; sb->rr_idx[j] = (u8)big; }
+        ++big;
+      }
+    }
   }
   FQ_SYNC();
 }
@@ -2402,7 +2450,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
               TM_BEGIN(t_r);
               TM_COUNT(w, CN_ROUGH);
               const u32 rr = w.sb->rr_idx[j];
-              if (rr != 0xff) rough = rough_merge_pre(w, rr, cfg->gb, RNG_B, CINC_B, counts);
+              if (rr != 0xff) rough = rough_merge_pre(w, rr, j, cfg->gb, RNG_B, CINC_B, counts);
               else rough = rough_kt(w, cfg->g_b, cfg->gb, bmj, RNG_B, CINC_B, counts);  // dna.cpp:711-718
               if (rough) level = LV_PMER;
               TM_END(w, TM_ROUGH, t_r);
