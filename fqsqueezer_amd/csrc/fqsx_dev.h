@@ -9,6 +9,7 @@
 // ---------------------------------------------------------------------------------------
 // workgroup-shared (LDS) state of one worker
 #define FQSX_RR 6u
+#define FQSX_SW 4u    // Hamming-1 sweeps the scout wave keeps in flight (one probe of each per lane)
 #define FQSX_SCR 3u   // scout ring: chunks the scout wave may be ahead of their release
 // One stage-P chunk: everything about positions i0..i0+n-1 of a read that does not depend on the adaptive models,
 // computed one position per lane under the assumption "no k-mer correction since the k-mers stage P started from".
@@ -1425,7 +1426,7 @@ FQ_DEV bool rough_merge_pre(Wk &w, u32 r, u32 j, const KGeom &g, u32 rng, const 
   return c4_any(counts);
 }
 #if FQ_WAVE > 1
-// scout wave: the sweeps of the chunk's positions that will need one (global b-mer miss, cascade empty), four
+// scout wave: the sweeps of the chunk's positions that will need one (global b-mer miss, cascade empty), FQSX_SW
 // sweeps in flight at a time (one probe of each per lane).  A sweep with at most 3 hits is kept in compact form,
 // fuller ones take one of the FQSX_RR full-size slots; whatever does not fit is left to the resolving wave.
 FQ_DEV void scout_rough(Wk &w, u32 n) {
@@ -1444,19 +1445,19 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
   const u32 pi = lane / 3, r3 = lane - 3 * pi;
   const u32 shd = 62 - 2 * pi, shr = 64 - 2 * g.k + 2 * pi;
   while (cm) {
-    u32 js[4];
-    bool ok[4];
+    u32 js[FQSX_SW];
+    bool ok[FQSX_SW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < (int)FQSX_SW; ++q) {
       ok[q] = cm != 0;
       js[q] = ok[q] ? ctz64(cm) : 0u;
       cm &= cm - 1;
     }
-    TabIt f[4];
-    u64 key[4];
-    bool nd[4];
+    TabIt f[FQSX_SW];
+    u64 key[FQSX_SW];
+    bool nd[FQSX_SW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < (int)FQSX_SW; ++q) {
       key[q] = 0; nd[q] = false; f[q].s = nullptr; f[q].p = 0; f[q].it0 = 0; f[q].it1 = 0;
       if (ok[q] && in) {
         const u64 cdir = sb->sp_sdir[2][js[q]], crc = sb->sp_src[2][js[q]];
@@ -1470,7 +1471,7 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < (int)FQSX_SW; ++q) {
       if (!ok[q]) continue;   // (uniform)
       u64 ns = 0, res = 0;
       if (in) {
