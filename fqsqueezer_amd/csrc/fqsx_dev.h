@@ -40,6 +40,7 @@ struct SpecBuf {
   u8 sx_flag[FQSX_SPEC];       // SX_* bits
   // scout chunks: Hamming-1 sweeps (find_counts_rough_b) probed ahead for up to FQSX_RR positions whose cascade came up empty
   u8 rr_idx[FQSX_SPEC];        // position -> sweep slot, 0xff = not probed ahead
+  u32 rr_front;                // the sweeps of all positions below this one are finished (the chunk is published before them)
   u64 rr_res[FQSX_RR][64];     // per probe: the four sibling counts, 16 bits each
   u64 rr_hit[FQSX_RR];         // probes that found something
   u64 rr_ns[FQSX_RR];          // slots scanned
@@ -1445,6 +1446,7 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
   const u32 pi = lane / 3, r3 = lane - 3 * pi;
   const u32 shd = 62 - 2 * pi, shr = 64 - 2 * g.k + 2 * pi;
   while (cm) {
+    if (lds_load_acq(&w.sm->sc_skip) > w.sc_read) break;   // the read was finished without the scout: nobody will look
     u32 js[FQSX_SW];
     bool ok[FQSX_SW];
 #pragma unroll
@@ -1492,8 +1494,22 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
         ++big;
       }
     }
+    // everything below the next unswept position is final
+    FQ_SYNC();
+    lds_store_rel(&sb->rr_front, cm ? ctz64(cm) : FQSX_SPEC);
   }
   FQ_SYNC();
+  lds_store_rel(&sb->rr_front, FQSX_SPEC);
+}
+// the first position of the chunk that still needs a sweep (scout wave, before the chunk is published)
+FQ_DEV u32 scout_rough_first(Wk &w, u32 n) {
+  SpecBuf *sb = w.sb;
+  const u32 lane = FQ_LANE;
+  if (3 * (w.cfg->gb.k - 1) > 64) return FQSX_SPEC;
+  FQ_SYNC();
+  const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_LB | SX_S | SX_LS)) == SX_VALID;
+  const u64 cm = wave_ballot(cand);
+  return cm ? ctz64(cm) : FQSX_SPEC;
 }
 // scout wave, first chunk of a read: the global look-ups find_counts will make at the positions whose b-mer is still
 // partial -- all 4^m paddings of an almost full b-/s-mer (up to 16), or the one probe of a full s-mer -- in one round
@@ -1774,6 +1790,7 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
   FQ_SYNC();
   if (FQ_LANE == 0) { w.sb->h_pq_lo[0] = lo0; w.sb->h_pq_lo[1] = lo1; }
   for (u32 j = FQ_LANE; j < FQSX_SPEC; j += FQ_WAVE) { w.sb->rr_idx[j] = 0xff; w.sb->ep_off[j][0] = 0xff; w.sb->ep_off[j][1] = 0xff; }
+  if (FQ_LANE == 0) w.sb->rr_front = FQSX_SPEC;
   const u32 b0 = i0 - joff;   // position the k-mers in w stand before
   for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
     // roll the six k-mers J symbols forward in closed form: only the last min(J, k) new symbols matter
@@ -2450,6 +2467,13 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
             } else {
               TM_BEGIN(t_r);
               TM_COUNT(w, CN_ROUGH);
+              {   // the scout wave may still be sweeping this chunk
+                u32 spins = 0;
+                while (lds_load_acq(&w.sb->rr_front) <= j) {
+                  fq_sleep();
+                  if (++spins > (1u << 22)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+                }
+              }
               const u32 rr = w.sb->rr_idx[j];
               if (rr != 0xff) rough = rough_merge_pre(w, rr, j, cfg->gb, RNG_B, CINC_B, counts);
               else rough = rough_kt(w, cfg->g_b, cfg->gb, bmj, RNG_B, CINC_B, counts);  // dna.cpp:711-718
@@ -2925,6 +2949,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       w.pm_u = w.pm; w.sm_u = w.sm_; w.bm_u = w.bm;
       w.cor_pos = 0;
       w.N_run = rec->n_run;
+      w.sc_read = idx;
       const u32 hist[4] = {rec->hist[0], rec->hist[1], rec->hist[2], rec->hist[3]};
       for (u32 i0 = cfg.pmer; i0 < size && !quit; i0 += FQSX_SPEC) {
         spins = 0;
@@ -2937,13 +2962,18 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         w.sb = &sm->sb[1 + made % FQSX_SCR];
         speculate(w, p, size, i0, n, false, i0 - cfg.pmer);
 #if FQ_WAVE > 1
-        scout_rough(w, n);
         if (i0 == cfg.pmer) scout_early(w, n);
+        const u32 front0 = scout_rough_first(w, n);
+#else
+        const u32 front0 = FQSX_SPEC;
 #endif
-        if (FQ_LANE == 0) { w.sb->h_read = idx; w.sb->h_i0 = i0; w.sb->h_n = n; }
+        if (FQ_LANE == 0) { w.sb->h_read = idx; w.sb->h_i0 = i0; w.sb->h_n = n; w.sb->rr_front = front0; }
         FQ_SYNC();
         made += 1;
-        lds_store_rel(&sm->sc_ready, made);
+        lds_store_rel(&sm->sc_ready, made);   // the resolving wave may start on the chunk ...
+#if FQ_WAVE > 1
+        scout_rough(w, n);                     // ... while its sweeps are still being probed (rr_front)
+#endif
       }
       add_s_letters(w, hist);
     }
