@@ -2169,17 +2169,16 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len) {
 #if FQ_WAVE > 1
   {
     const u32 t = FQ_LANE;
+    // intersect, over the bits of the slot index, the ballots of the lanes that agree with mine on that bit
     const u32 mine = sm->fr_idx[t];
     const bool ok = !sm->fr_bad[t] && !((KR >> t) & 1);
-    u64 rem = wave_ballot(ok), same = 0;
-    while (rem) {
-      const u32 lead = ctz64(rem);
-      const u32 li = wave_bcast32(mine, lead);
-      const u64 g = wave_ballot(ok && mine == li);
-      if (ok && mine == li) same = g;
-      rem &= ~g;
+    u64 same = wave_ballot(ok);
+    for (u64 cap = w.cfg->ctx_cap_mask, b = 0; cap; cap >>= 1, ++b) {
+      const bool bit = (mine >> b) & 1u;
+      const u64 m = wave_ballot(bit);
+      same &= bit ? m : ~m;
     }
-    sm->fr_same[t] = same;
+    sm->fr_same[t] = ok ? same : 0ull;
   }
 #else
   for (u32 t = 0; t < 64; ++t) {
@@ -2234,19 +2233,35 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len) {
   {
     double ac = w.avg_code, al = w.avg_letters;
     u32 t = 0;
-    for (; t < L; ++t) {
 #if FQ_WAVE > 1
-      // ema_update with its level term precomputed by the position's lane
-      if ((KR >> t) & 1) continue;
-      const double pl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lane_pl), t), __builtin_amdgcn_readlane(__double2loint(lane_pl), t));
-      if ((KL >> t) & 1) {
-        if ((int)(al + 0.49) != s0l) break;
-        al = __dadd_rn(__dmul_rn(0.999, al), pl);
-      } else {
-        if ((int)(ac + 0.49) != s0c) break;
-        ac = __dadd_rn(__dmul_rn(0.999, ac), pl);
+    // The recurrence runs over all L positions without looking at its values (two dependent fp64 operations per
+    // position; ema_update with the level term precomputed by the position's lane); every lane keeps the average its
+    // position started from, the starting-level test is then one lane-parallel comparison, and in the rare case it
+    // fails somewhere the recurrence is simply run again up to that position.
+    for (int pass = 0; pass < 2; ++pass) {
+      double before = 0.0;
+      ac = w.avg_code; al = w.avg_letters;
+      for (t = 0; t < L; ++t) {
+        if ((KR >> t) & 1) continue;
+        const double pl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lane_pl), t), __builtin_amdgcn_readlane(__double2loint(lane_pl), t));
+        if ((KL >> t) & 1) {
+          before = FQ_LANE == t ? al : before;
+          al = __dadd_rn(__dmul_rn(0.999, al), pl);
+        } else {
+          before = FQ_LANE == t ? ac : before;
+          ac = __dadd_rn(__dmul_rn(0.999, ac), pl);
+        }
       }
+      if (pass) break;
+      const u32 ln = FQ_LANE;
+      const bool chk = ln < L && !((KR >> ln) & 1);
+      const u64 viol = wave_ballot(chk && (int)(before + 0.49) != (((KL >> ln) & 1) ? s0l : s0c));
+      if (!viol) break;
+      L = ctz64(viol);   // the first position whose starting level differs: the run ends before it
+    }
+    t = L;
 #else
+    for (; t < L; ++t) {
       if ((KR >> t) & 1) continue;
       if ((KL >> t) & 1) {
         if ((int)(al + 0.49) != s0l) break;
@@ -2255,8 +2270,8 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len) {
         if ((int)(ac + 0.49) != s0c) break;
         ac = ema_update(ac, (double)sm->fr_lvl[t]);
       }
-#endif
     }
+#endif
     L = t;
     TM_END(w, TM_CR_AVG, t_avg);
     if (L == 0) return 0;
