@@ -88,6 +88,25 @@ def test_hip_matches_oracle_many_workers_and_tiny_blocks():
             assert a.encode_block(bases, off, g) == b.encode_block(bases, off, g)
 
 
+def test_hip_worker_pipeline_matches_oracle_sorted_mode():
+    """The five wavefronts of a worker (resolve / coder / inserter / read head / scout) against the CPU oracle in the
+    mode that uses all of them: the bitstream's maximum of 255 workers on reads with substitutions and N (k-mer
+    corrections make the resolving wave drop the scout's chunks), and 64 workers on ragged reads with N runs,
+    duplicates and lengths from below the k-mer sizes to several chunks (`c4`, `c7`)."""
+    from oracle.pyoracle import OracleCodec
+    from fqsqueezer_amd.synth import synth_reads
+    reads = synth_reads(30000, 100, 200000, 23)
+    cases = [(255, hp.Records([b"@r%d" % i for i in range(len(reads))], reads, reads)), (64, c4_records()), (64, c7_records())]
+    for T, rec in cases:
+        header = hp.make_header(T, "se_sorted", 1)
+        a, b = gpu(header), OracleCodec(header)
+        order = np.concatenate(hp.sorted_order(rec))          # the file in sorted order, cut into blocks of >= 2 T reads
+        B = 2048 if T == 255 else 1500
+        for g, lo in enumerate(range(0, len(order) - 2 * T, B)):
+            bases, off = hp.block_arrays(rec, order[lo:lo + B])
+            assert a.encode_block(bases, off, g) == b.encode_block(bases, off, g), f"T={T} block {g}"
+
+
 def test_gpu_encode_decode_round_trip_many_workers():
     """encode -> decode entirely on the GPU at T=64 (size-independent property: the block comes back)."""
     from fqsqueezer_amd.synth import synth_reads
