@@ -10,7 +10,8 @@ from fqsqueezer_amd.synth import synth_reads, read_id
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "tools", "libfqsx_timing.so")
+lib = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else os.path.join(ROOT, "tools", "libfqsx_timing.so")
+max_blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 1 << 30   # only the first blocks of the file
 reads = synth_reads(1000000, 100, 5000000, 2)[:n]
 rec = hp.Records([read_id(i) for i in range(n)], reads, reads)
 header = hp.make_header(T, "se_sorted", 5)
@@ -18,9 +19,12 @@ blocks = hp.form_blocks(rec, "se_sorted")
 c = DnaCodec(header, lib_path=lib)
 c.set_profiling(True)
 t0 = time.time()
-for g, idx in enumerate(blocks):
+n_done = 0
+for g, idx in enumerate(blocks[:max_blocks]):
     bases, off = hp.block_arrays(rec, idx)
     c.encode_block(bases, off, g)
+    n_done += len(idx)
+n = n_done
 dt = time.time() - t0
 st = c.stats(); kt = c.kernel_times()
 names = ["total", "spec", "fast", "slow", "post_q", "read_head", "lq_flush", "rough", "repair_missing", "find_counts"]
