@@ -80,6 +80,13 @@ FQ_KERNEL64 void k_compact_streams(DevCfg cfg, const u64 *lens, u8 *dst) {
   const u8 *src = cfg.out + (u64)tid * cfg.out_cap;
   for (u64 i = FQ_LANE; i < n; i += FQ_WAVE) dst[off + i] = src[i];
 }
+// ClearKmersToHT (dna.cpp:2475-2488): the workers' local tables and their fill counters, in one launch
+FQ_KERNEL64 void k_clear_local(DevCfg cfg, u64 nb_slots, u64 ns_slots) {
+  const u64 stride = (u64)FQ_NBLOCKS * FQ_WAVE, first = (u64)FQ_BLOCK * FQ_WAVE + FQ_LANE;
+  for (u64 i = first; i < nb_slots; i += stride) cfg.l_b.slots[i] = 0;
+  for (u64 i = first; i < ns_slots; i += stride) cfg.l_s.slots[i] = 0;
+  for (u64 i = first; i < 2ull * cfg.T; i += stride) cfg.l_s.filled[i] = 0;   // l_s.filled and l_b.filled are adjacent
+}
 FQ_KERNEL64 void k_finish_block(DevCfg cfg, u64 *lens /*[T+1]*/) {
   if (FQ_LANE == 0) {
     finish_block_body(cfg, FQ_BLOCK);
@@ -633,9 +640,11 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
     LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg);
     LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg);
     // ClearKmersToHT, dna.cpp:2475-2488 (mailbox counters are rewritten by the next encode launch)
-    if ((rc = dzero(c, cfg.l_b.slots, need_lb * T * sizeof(u64)))) return rc;
-    if ((rc = dzero(c, cfg.l_s.slots, need_ls * T * sizeof(u64)))) return rc;
-    if ((rc = dzero(c, cfg.l_s.filled, 2 * T * sizeof(u32)))) return rc;  // l_s.filled and l_b.filled are adjacent
+    {
+      const u64 words = (need_lb + need_ls) * T;
+      const u32 grid = (u32)std::min<u64>(2048, (words + 4095) / 4096 + 1);
+      LAUNCH(c, 2, k_clear_local, grid, 64, cfg, need_lb * T, need_ls * T);
+    }
   }
   if (decode) {
     u32 derr = 0;

@@ -467,10 +467,18 @@ FQ_DEV void batch_count(Wk &w, const KTab &t, u32 n) {  // exact counts of the b
 // lane-parallel in-order insert of <= 64 keys into sub-table `sub` (defined below)
 FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 sub, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
                          u64 &nslots, u32 &err);
+FQ_DEV void insert_batch_k(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 sub, u64 mykey, u32 n, u32 rng, const Cinc &ci,
+                           u64 &nslots, u32 &err);
 FQ_DEV void insert_keys(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 sub, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
                         u64 &nslots, u32 &err) {
 #if FQ_WAVE > 1
-  for (u32 o = 0; o < n && !err; o += FQ_WAVE) insert_batch(cfg, sm, t, sub, keys + o, n - o < FQ_WAVE ? n - o : FQ_WAVE, rng, ci, nslots, err);
+  // the keys of the next batch are fetched while the current one is applied (the list is read-only here)
+  u64 nextk = FQ_LANE < n ? keys[FQ_LANE] : 0;
+  for (u32 o = 0; o < n && !err; o += FQ_WAVE) {
+    const u64 k = nextk;
+    if (o + FQ_WAVE + FQ_LANE < n) nextk = keys[o + FQ_WAVE + FQ_LANE];
+    insert_batch_k(cfg, sm, t, sub, k, n - o < FQ_WAVE ? n - o : FQ_WAVE, rng, ci, nslots, err);
+  }
 #else
   for (u32 j = 0; j < n && !err; ++j) insert_batch(cfg, sm, t, sub, keys + j, 1, rng, ci, nslots, err);
 #endif
@@ -3167,11 +3175,16 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
 // again after the round's stores -- exactly the sequential result, in 1-2 rounds instead of n steps.
 FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 tid, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
                          u64 &nslots, u32 &err) {
+  insert_batch_k(cfg, sm, t, tid, FQ_LANE < n ? keys[FQ_LANE] : 0, n, rng, ci, nslots, err);
+}
+// mykey: this lane's key of the batch (lanes >= n: ignored)
+FQ_DEV void insert_batch_k(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 tid, u64 mykey, u32 n, u32 rng, const Cinc &ci,
+                           u64 &nslots, u32 &err) {
   (void)cfg;
   u64 *s = t.slots + (u64)tid * t.stride;
   const u64 cm = (1ull << t.cbits) - 1ull;
   const u32 lane = FQ_LANE;
-  const u64 v = lane < n ? keys[lane] >> (64 - 2 * t.k) : 0;
+  const u64 v = lane < n ? mykey >> (64 - 2 * t.k) : 0;
   const u64 home = tab_home(t, v);
   u32 filled = t.filled[tid];
   for (u32 done = 0; done < n;) {
