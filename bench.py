@@ -86,13 +86,18 @@ def main() -> None:
     n_bases = int(a.reads) * int(a.len)
     torch.cuda.synchronize()
 
+    block_done = []   # host clock after every block of the most recent pass (a block call returns when its streams are back)
+
     def one_step(profile: bool = False):
         codec = DnaCodec(header, device=local_rank)
         if profile:
             codec.set_profiling(True)
         out_bytes = 0
+        block_done.clear()
+        block_done.append(time.perf_counter())
         for g, (d_b, d_o, off) in enumerate(dev_blocks):
             out_bytes += codec.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g, collect=False)
+            block_done.append(time.perf_counter())
         res = (out_bytes, codec.stats() if profile else None, codec.kernel_times() if profile else None)
         codec.close()
         return res
@@ -123,6 +128,14 @@ def main() -> None:
         return
 
     value = world * n_bases * a.steps / elapsed / 1e6
+    # rate over the blocks past the reference's warm-up schedule (calc_no_synchronizations, application.h:85-92: from
+    # block 100 on a block is one segment), from the last timed pass -- what a file much longer than this one runs at
+    steady = None
+    if len(dev_blocks) > 110 and len(block_done) == len(dev_blocks) + 1:
+        sb = sum(int(off[-1]) for (_, _, off) in dev_blocks[100:])
+        steady = {"value": round(sb / (block_done[-1] - block_done[100]) / 1e6, 4), "unit": "Mbases/s",
+                  "blocks": f"100..{len(dev_blocks) - 1}", "warmup_blocks_value": round(sum(int(off[-1]) for (_, _, off) in dev_blocks[:70]) / (block_done[70] - block_done[0]) / 1e6, 4),
+                  "note": "this rank, same timed pass: blocks >= 100 (one synchronisation segment per block) vs blocks 0..69 (30 segments per block, two reads per worker and segment)"}
 
     # ---- kernel-level measurement pass (HIP events around every launch on the codec's stream; untimed)
     _, st, kt = one_step(profile=True)
@@ -194,8 +207,7 @@ def main() -> None:
         conc = {"instances": a.concurrent, "value": round(a.concurrent * n_bases / dt / 1e6, 4), "unit": "Mbases/s",
                 "identical_output": len(set(outs)) == 1 and outs[0] == dna_bytes,
                 "note": "independent compressions of the workload file running concurrently on one GPU as threads of this process "
-                        "(aggregate rate; the HIP runtime serialises threads -- as separate processes 4 / 8 files reach 47 / 78 Mbases/s, "
-                        "tools/gpu_multi_proc.sh, profiles/r01_concurrent_files.json)"}
+                        "(aggregate rate; one file occupies T of the 256 CUs)"}
 
     # HBM traffic of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/traffic.json), if recorded
     traffic = None
@@ -220,7 +232,7 @@ def main() -> None:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2+rank), -om s -gs {a.gs} -qm n -im n",
                    "workers_T": a.threads, "blocks": len(blocks), "per_gpu": "one independent file per GPU"},
-        "bits_per_base": round(8.0 * dna_bytes / n_bases, 5), "pcie_inclusive_mbases_s": pcie, "workers_255": t255, "concurrent_files": conc,
+        "bits_per_base": round(8.0 * dna_bytes / n_bases, 5), "steady_state": steady, "pcie_inclusive_mbases_s": pcie, "workers_255": t255, "concurrent_files": conc,
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
