@@ -105,6 +105,9 @@ struct WgShared {
   u8 cq_rsym[FQSX_CQ];
   u32 cq_tail, cq_head, cq_done;   // entries published / consumed (free-running); producer finished
 };
+#ifndef FQSX_EMU
+static_assert(sizeof(WgShared) <= 160u * 1024u, "WgShared must fit the 160 KB of LDS of a gfx950 CU");
+#endif
 enum { SX_VALID = 1, SX_LB = 2, SX_S = 4, SX_LS = 8 };
 enum { SK_NONE = 0, SK_RANK = 1, SK_LETTER = 2, SK_RANK_PENDING = 3, SK_LETTER_PENDING = 4, SK_RAW = 5, SK_KIND_MASK = 7,
        SK_RESET = 8 /* the r_sym history restarts at this entry (first symbol of a compress_suffix call, dna.cpp:676) */ };
