@@ -17,7 +17,7 @@
 #define FQSX_RD_LDS 4096u        // reads up to this length are staged in LDS
 #define FQSX_SPEC 64u            // positions speculated per chunk (one per lane)
 #define FQSX_PQ 512u             // entries of the LDS mirror of each local-insert list (power of two)
-#define FQSX_CQ 128u             // entries of the coding queue (power of two, >= 2 * FQSX_SPEC)
+#define FQSX_CQ 256u             // entries of the coding queue (power of two, >= 2 * FQSX_SPEC)
 
 // geometry of one rolling k-mer (kmer.h:279-298)
 struct KGeom {
