@@ -94,6 +94,7 @@ struct WgShared {
   u64 pe_bk[3][64];            // paired-end insert batch (key, value, weight)
   u64 pq_key[2][FQSX_PQ];      // LDS mirror of the most recent b / s list entries (ring indexed by list position)
   u64 ib_pos[64];              // insert_batch: target slot per lane
+  u32 qm_bits[4][128];         // quiet_miss_mask: 4096-bit sets of the sibling groups of recent list entries (b dir, b rc, s dir, s rc)
   // hand-off words of the local-table inserter wave: list entries published / applied per kind (b, s); quit
   u32 lq_target[2], lq_done[2], lq_quit;
   // coding queue: every symbol of the worker's stream in stream order, as the context keys of a rank-/letter-coded
@@ -2372,6 +2373,65 @@ FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reverse
   }
 }
 
+#if FQ_WAVE > 1
+// Positions of a chunk where stage P found nothing in any table (global b miss, cascade empty) and where no list
+// entry stage P may have missed -- the entries since its snapshot (LDS mirror) and those of the chunk's earlier
+// positions -- lies in the position's b or s sibling group, i.e. exactly the positions for which pend_conflict
+// would say no twice.  The mirror is tested through hashed bit sets (a set bit only sends the position down the
+// exact per-position path), the chunk's own entries exactly.  One position per lane.
+FQ_DEV u32 grp_hash(u64 g) { return (u32)((g * 0x9E3779B97F4A7C15ull) >> 52); }   // 12 bits
+FQ_DEV u64 quiet_miss_mask(Wk &w, u32 n) {
+  SpecBuf *sb = w.sb;
+  WgShared *sm = w.sm;
+  const DevCfg *cfg = w.cfg;
+  const u32 lane = FQ_LANE;
+  FQ_SYNC();
+  const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_LB | SX_S | SX_LS)) == SX_VALID;
+  const u64 A = wave_ballot(cand);
+  if (popc64(A) < 8) return 0;   // not worth the set-up: the per-position path handles them
+  const u32 lo_b = w.pq_lo[0], hi_b = w.mn[MAIL_B], lo_s = w.pq_lo[1], hi_s = w.mn[MAIL_S];
+  if (hi_b - lo_b > FQSX_PQ || hi_s - lo_s > FQSX_PQ) return 0;
+  const u32 k2b = 2 * cfg->gb.k, k2s = 2 * cfg->gs.k;
+  const u64 lmb = (1ull << (k2b - 2)) - 1ull, lms = (1ull << (k2s - 2)) - 1ull;
+  // this lane's two sibling groups
+  const u64 bd = sb->sp_sdir[2][lane], br = sb->sp_src[2][lane], sd = sb->sp_sdir[1][lane], sr = sb->sp_src[1][lane];
+  const bool ndb = (bd & cfg->gb.kernel_mask) < (br & cfg->gb.kernel_mask), nds = (sd & cfg->gs.kernel_mask) < (sr & cfg->gs.kernel_mask);
+  const u64 vb = (ndb ? bd : br) >> (64 - k2b), vs = (nds ? sd : sr) >> (64 - k2s);
+  const u64 gb = ndb ? (vb >> 2) : (vb & lmb), gs = nds ? (vs >> 2) : (vs & lms);
+  // bit sets of the mirror entries' groups, both readings of every entry
+  for (u32 i = lane; i < 4 * 128; i += FQ_WAVE) (&sm->qm_bits[0][0])[i] = 0;
+  FQ_SYNC();
+  for (u32 e = lo_b + lane; e < hi_b; e += FQ_WAVE) {
+    const u64 pv = sm->pq_key[0][e & (FQSX_PQ - 1)] >> (64 - k2b);
+    const u32 h0 = grp_hash(pv >> 2), h1 = grp_hash(pv & lmb);
+    atomicOr(&sm->qm_bits[0][h0 >> 5], 1u << (h0 & 31));
+    atomicOr(&sm->qm_bits[1][h1 >> 5], 1u << (h1 & 31));
+  }
+  for (u32 e = lo_s + lane; e < hi_s; e += FQ_WAVE) {
+    const u64 pv = sm->pq_key[1][e & (FQSX_PQ - 1)] >> (64 - k2s);
+    const u32 h0 = grp_hash(pv >> 2), h1 = grp_hash(pv & lms);
+    atomicOr(&sm->qm_bits[2][h0 >> 5], 1u << (h0 & 31));
+    atomicOr(&sm->qm_bits[3][h1 >> 5], 1u << (h1 & 31));
+  }
+  FQ_SYNC();
+  const u32 hb = grp_hash(gb), hs = grp_hash(gs);
+  bool maybe = ((sm->qm_bits[ndb ? 0 : 1][hb >> 5] >> (hb & 31)) & 1u) != 0 || ((sm->qm_bits[nds ? 2 : 3][hs >> 5] >> (hs & 31)) & 1u) != 0;
+  // the entries of the chunk's earlier positions, exactly
+  for (u32 t = 0; t + 1 < n; ++t) {
+    const u32 f = sb->pv_flag[t];
+    if (f & PV_B) {
+      const u64 pv = sb->pv_b[t] >> (64 - k2b);
+      maybe |= lane > t && (ndb ? (pv >> 2) == gb : (pv & lmb) == gb);
+    }
+    if (f & PV_S) {
+      const u64 pv = sb->pv_s[t] >> (64 - k2s);
+      maybe |= lane > t && (nds ? (pv >> 2) == gs : (pv & lms) == gs);
+    }
+  }
+  return wave_ballot(cand && !maybe);
+}
+#endif
+
 // hand-over of the scout wave's stage-P chunks (see scout_segment_body)
 FQ_DEV void scout_release(Wk &w) {
   w.sc_taken += 1;
@@ -2425,6 +2485,10 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       Fm |= (u64)f << t; Rm |= (u64)r << t;
 #endif
     }
+    u64 Qm = 0;       // positions nothing is found for anywhere unless their Hamming-1 sweep finds something (quiet_miss_mask)
+#if FQ_WAVE > 1
+    if (pre && !w.repm_gate) Qm = quiet_miss_mask(w, n);   // (with the gate open repair_kmers_missing may fire: per-position path)
+#endif
     u32 q_done = 0;   // chunk positions whose mailbox entries are already in the lists
     u32 w_pos = 0;    // w's k-mers = state before position w_pos of the chunk
     u32 m = 0;        // committed positions
@@ -2434,6 +2498,41 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       const u32 sym = rd_sym(w, p, pos, size);
       const u64 sym_k = sym == 4 ? 0 : sym;
       const u32 flag = w.sb->sp_flag[j];
+#if FQ_WAVE > 1
+      if ((Qm >> j) & 1) {
+        // A stretch of positions where every look-up came up empty and the sweep did too: level none, the symbol is
+        // letter-coded, stage P's mailbox entries stand (p-mer included), nothing draws from an RNG and no repair
+        // can fire (dna.cpp:706-744,776-785,840-874) -- settled for the whole stretch in one lane-parallel step.
+        u32 spins = 0, front;
+        while ((front = lds_load_acq(&w.sb->rr_front)) <= j) {   // the scout wave may still be sweeping this chunk
+          fq_sleep();
+          if (++spins > (1u << 22)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+        }
+        const u32 t = FQ_LANE;
+        const bool empty = t < front && t < n && ((Qm >> t) & 1) && w.sb->rr_idx[t] == 0xfe && w.sb->rc_hit[t] == 0;
+        const u64 run = wave_ballot(empty) >> j;
+        const u32 len = ~run ? ctz64(~run) : 64u;
+        if (len) {
+          const bool in = t >= j && t < j + len;
+          u32 nsl = 0;
+          if (in) {
+            w.sb->sp_kind[t] = SK_LETTER_PENDING;
+            const u32 pf = w.sb->pv_flag[t];
+            if (pf & PV_PCAND) w.sb->pv_flag[t] = (u8)(pf | PV_P);
+            nsl = w.sb->rc_ns[t];
+          }
+          FQ_SYNC();
+          w.st[ST_GPROBE] += (u64)len * 4 * (cfg->gb.k - 1);
+          w.st[ST_GSLOT] += wave_sum32(nsl) + (u64)len * (cfg->gb.k - 1);
+#ifdef FQSX_TIMING
+          w.tm[CN_SLOW] += len; w.tm[CN_EXT] += len; w.tm[CN_ROUGH] += len;
+#endif
+          j += len - 1;
+          m = j + 1;
+          continue;
+        }
+      }
+#endif
       TM_BEGIN(t_code);
       if (flag == 1) {
         // settled by stage P (level bmer): nothing to resolve; skip the whole stretch of such positions up to the
