@@ -2444,7 +2444,11 @@ FQ_DEV bool scout_take(Wk &w, u32 i, u32 n) {
     u32 spins = 0;
     while (lds_load_acq(&sm->sc_ready) == w.sc_taken) {
       fq_sleep();
-      if (++spins > (1u << 22)) { w.sc_abandoned = true; return false; }   // never spin forever on the GPU
+      if (++spins > (1u << 22)) {   // never spin forever on the GPU: go on without the scout for this read
+        w.sc_abandoned = true;
+        lds_store_rel(&sm->sc_skip, w.sc_read + 1);
+        return false;
+      }
     }
     SpecBuf *b = &sm->sb[1 + w.sc_taken % FQSX_SCR];
     const u32 r = b->h_read;
@@ -2739,11 +2743,11 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       replace_last_all(w, sym == 4 ? 0 : sym);
       w.N_run = sym == 4 ? w.N_run + 1 : 0;
     }
-    if (pre) scout_release(w);
     if (dirty && w.scout && !w.sc_abandoned) {   // the scout's clean-read assumption no longer holds for this read
       w.sc_abandoned = true;
-      lds_store_rel(&sm->sc_skip, w.sc_read + 1);
+      lds_store_rel(&sm->sc_skip, w.sc_read + 1);   // (before the release below: a scout woken by it must see the skip)
     }
+    if (pre) scout_release(w);
     i += m;
   }
 }
@@ -3081,6 +3085,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       for (u32 i0 = cfg.pmer; i0 < size && !quit; i0 += FQSX_SPEC) {
         spins = 0;
         while (made - lds_load_acq(&sm->sc_taken) >= FQSX_SCR) {   // every ring buffer holds an unreleased chunk
+          if (lds_load_acq(&sm->sc_skip) > idx) break;   // nobody will take further chunks of this read (the ring is drained at the next read that uses the scout)
           fq_sleep();
           if (lds_load_acq(&sm->cq_done) || ++spins > (1u << 23)) { quit = true; break; }
         }

@@ -76,6 +76,22 @@ def test_hip_matches_reference_1M_t64_bit_exact():
     assert st["bases"] <= 100_000_000 and st["coded"] > 80_000_000
 
 
+@pytest.mark.parametrize("t", [1, 8])
+def test_hip_matches_reference_1M_other_worker_counts(t):
+    """SURVEY 8(d) config 2 asks T in {1, 8, 64}: the same file as `fqs-1.1 e -t 1` / `-t 8` would write it (T = 1 is one
+    workgroup for the whole file: the first 40 blocks)."""
+    check_against_digest(gpu, f"c2_1M_s_t{t}.json", max_blocks=40 if t == 1 else None)
+
+
+@pytest.mark.parametrize("t", [64, 8])
+def test_hip_matches_reference_1M_150bp_bit_exact(t):
+    """The workload BASELINE.json's metric is quoted on (bench.py's default): 1 M x 150 bp SE sorted, -gs 8, every
+    block's DNA streams hash-identical to `fqs-1.1 e -t 64` (and `-t 8`)."""
+    codec = check_against_digest(gpu, f"c12_1M150_s_t{t}.json")
+    st = codec.stats()
+    assert st["bases"] <= 150_000_000 and st["coded"] > 120_000_000
+
+
 def test_hip_matches_oracle_many_workers_and_tiny_blocks():
     from oracle.pyoracle import OracleCodec
     rec = c4_records()

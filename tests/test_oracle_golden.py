@@ -47,6 +47,12 @@ def test_oracle_matches_reference_1M(t):
     check_against_digest(OracleCodec, f"c2_1M_s_t{t}.json")
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("t", [8, 64])
+def test_oracle_matches_reference_1M_150bp(t):
+    check_against_digest(OracleCodec, f"c12_1M150_s_t{t}.json")   # the metric's workload (bench.py default)
+
+
 @pytest.mark.parametrize("name,recs", [("c1_10k_o_t4.fqs", c1_records), ("c1_10k_s_t4.fqs", c1_records), ("c4_ragged_s_t3.fqs", c4_records),
                                        ("c7_mixedlen_o_t3.fqs", c7_records), ("c5_pe4k_o_t4.fqs", c5_records), ("c5_pe4k_s_t4.fqs", c5_records)])
 def test_oracle_decodes_reference_streams(name, recs):

@@ -17,6 +17,8 @@ Fixtures (data only -- inputs are re-generated deterministically by fqsqueezer_a
                             (-qm o -im o) and digests of all four streams for -om s with -im i -qm 8 / -im o -qm o
   c11_pe_full_*.json        2000 pairs (G=60kbp, seed 11), varied ids incl. typical and atypical mate ids, -p, full modes
   c3_50k150_s_t8.json       50k x 150bp, G=250kbp, seed 3, -om s -gs 8 (150 bp metric shape)
+  c12_1M150_s_t{8,64}.json  1M x 150bp, G=7.5Mbp, seed 2, -om s -gs 8: the workload BASELINE.json's metric is quoted on
+                            (bench.py's default), per-block SHA-256 of the reference DNA streams
 Usage: python tools/make_golden.py [--work /tmp/w] [--only c1|c2|c3]
 """
 import argparse, hashlib, json, os, subprocess, sys
@@ -189,6 +191,8 @@ def main():
                                    "-tmp", os.path.join(a.work, "tmpf_"), "-out", out, f1, f2], stdout=subprocess.DEVNULL)
             json.dump(fdigest(out, {"input": "c11 (2000 pairs x 100bp, G=60kbp, seed 11, synth_ids_varied mates 1/2)", "om": om, "qm": qm, "im": im,
                                     "threads": t, "paired": True}), open(os.path.join(GOLD, f"c11_pe_full_{tag}.json"), "w"))
+    if a.only in ("", "c12"):
+        c12(a)
     if a.only in ("", "c3"):
         fq = os.path.join(a.work, "c3.fq")
         if not os.path.exists(fq):
@@ -197,6 +201,17 @@ def main():
         run_ref(fq, out, "s", 8, 8, a.work)
         meta = {"reads": 50000, "len": 150, "genome": 250000, "seed": 3, "gs": 8, "om": "s", "threads": 8}
         json.dump(digest(out, meta), open(os.path.join(GOLD, "c3_50k150_s_t8.json"), "w"))
+
+
+def c12(a):
+    fq = os.path.join(a.work, "c12.fq")
+    if not os.path.exists(fq):
+        write_fastq(fq, synth_reads(1000000, 150, 7500000, 2), seed=2)
+    for t in (64, 8):
+        out = os.path.join(a.work, f"c12_s_t{t}.fqs")
+        run_ref(fq, out, "s", t, 8, a.work)
+        meta = {"reads": 1000000, "len": 150, "genome": 7500000, "seed": 2, "gs": 8, "om": "s", "threads": t}
+        json.dump(digest(out, meta), open(os.path.join(GOLD, f"c12_1M150_s_t{t}.json"), "w"))
 
 
 def ragged():
