@@ -11,7 +11,7 @@
 // which is the barrier structure of the reference worker loop (fqs/application.cpp:610-669)
 // with kernel boundaries in place of CBarrier.  Built with hipcc for gfx950; the FQSX_EMU
 // build (tests/emu only) runs the same kernels as plain loops for debugging without a GPU.
-#include "fqsx_dev.h"
+#include "fqsx_kernels.h"
 #include "fqsx_qual.h"
 #include "../../include/fqsx.h"
 
@@ -33,42 +33,10 @@ extern "C" const char *fqsx_version(void) {
 }
 
 // ---------------------------------------------------------------------------------------
-// kernels
-// One workgroup = one logical worker = five wavefronts: wave 0 resolves the worker's reads (k-mer tables, counts,
-// corrections, mailboxes) and queues every symbol in LDS, wave 1 codes them (context models + range coder), wave 2 applies the worker's local-table inserts,
-// wave 3 prepares the head of the next read (duplicate test, p-mer prefix), wave 4 runs stage P (k-mer rolling and table
-// probes, one position per lane) of the chunks ahead.
-#ifndef FQSX_EMU
-FQ_KERNEL320 void k_encode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
-  FQ_SHARED WgShared sm;
-  if (threadIdx.x == 0) {
-    sm.cq_tail = 0; sm.cq_head = 0; sm.cq_done = 0;
-    sm.lq_target[0] = sm.lq_target[1] = 0; sm.lq_done[0] = sm.lq_done[1] = 0; sm.lq_quit = 0;
-    sm.hd_ready = 0; sm.hd_taken = 0;
-    sm.sc_ready = 0; sm.sc_taken = 0; sm.sc_skip = 0; sm.sc_hd_taken = 0;
-  }
-  FQ_WG_BARRIER();
-  // (waves 0 and 4 land on the same SIMD: the two least busy roles share it)
-  if (FQ_WAVE_ID == 1) encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg, false, true);
-  else if (FQ_WAVE_ID == 2) coder_segment_body(cfg, &sm, FQ_BLOCK, seg);
-  else if (FQ_WAVE_ID == 4) inserter_segment_body(cfg, &sm, FQ_BLOCK);
-  else if (FQ_WAVE_ID == 0) head_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
-  else scout_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
-}
-#define ENCODE_THREADS 320
-#else
-FQ_KERNEL64 void k_encode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
-  FQ_SHARED WgShared sm;
-  encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg);
-}
-#define ENCODE_THREADS 64
-#endif
-FQ_KERNEL64 void k_decode_segment(DevCfg cfg, u32 n_reads, u32 S, u32 seg) {
-  FQ_SHARED WgShared sm;
-  encode_segment_body(cfg, &sm, FQ_BLOCK, n_reads, S, seg, true);
-}
+// kernels.  The encode / decode kernels live in translation units of their own (fqsx_k_se.hip, fqsx_k_pe.hip,
+// fqsx_k_dec.hip; launchers in fqsx_kernels.h); here: the insert phase, the mailbox partition, growth, the block epilogue.
 FQ_KERNEL64 void k_insert_phase(DevCfg cfg) {  // grid = 3 * T: (owner, mailbox kind)
-  FQ_SHARED WgShared sm;
+  FQ_SHARED InsShared sm;
   insert_phase_body(cfg, &sm, FQ_BLOCK / 3, FQ_BLOCK % 3);
 }
 // gathers the T streams of the block into one contiguous buffer (one D2H transfer per block)
@@ -141,11 +109,11 @@ FQ_KERNEL64 void k_part_scatter(DevCfg cfg) {
 }
 // paired-end insert phase: per-owner demand, then the inserts
 FQ_KERNEL64 void k_pe_demand(DevCfg cfg, u32 *demand) {
-  FQ_SHARED WgShared sm;
+  FQ_SHARED InsShared sm;
   pe_insert_body(cfg, &sm, FQ_BLOCK, true, demand);
 }
 FQ_KERNEL64 void k_pe_insert(DevCfg cfg) {
-  FQ_SHARED WgShared sm;
+  FQ_SHARED InsShared sm;
   pe_insert_body(cfg, &sm, FQ_BLOCK, false, nullptr);
 }
 FQ_KERNEL void k_rehash_ptab(PTab o, PTab n, u32 n_sub) {
@@ -472,6 +440,29 @@ int mail_alloc(fqsx_dna *c, u32 kind, u32 cap) {
   return FQSX_OK;
 }
 
+// one encode / decode launch over segment `seg` (T workgroups); timed with HIP events when profiling is on
+int launch_segment(fqsx_dna *c, bool decode, u32 n_reads, u32 S, u32 seg) {
+  EncArgs a;
+  a.cfg = c->cfg;
+  a.n_reads = n_reads; a.S = S; a.seg = seg; a.pad = (u32)c->k_n[0];   // (launch index: time stamps of the timing build)
+#ifndef FQSX_EMU
+  if (c->profiling) HIPCHK(hipEventRecord(c->ev0, c->stream));
+  const int e = decode ? fqsx_launch_decode(c->stream, a) : c->paired ? fqsx_launch_encode_pe(c->stream, a) : fqsx_launch_encode_se(c->stream, a);
+  if (e) { g_err = std::string("encode/decode kernel launch: ") + hipGetErrorString((hipError_t)e); return FQSX_E_HIP; }
+  if (c->profiling) {
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->k_ms[0] += ms;
+  }
+#else
+  if (decode) fqsx_emu_decode(a); else if (c->paired) fqsx_emu_encode_pe(a); else fqsx_emu_encode_se(a);
+#endif
+  c->k_n[0] += 1;
+  return FQSX_OK;
+}
+
 // decode: dec_streams/dec_lens (host) are the T input streams, bases_out (host) receives the block
 int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u64 *h_off, u32 n_reads, u32 generation,
                       const u8 **streams, u64 *lens, const u8 *const *dec_streams = nullptr, const u64 *dec_lens = nullptr,
@@ -606,8 +597,7 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
   }
 
   for (u32 seg = 0; seg <= (u32)S; ++seg) {
-    if (decode) LAUNCH(c, 0, k_decode_segment, T, 64, cfg, n_reads, (u32)S, seg);
-    else LAUNCH(c, 0, k_encode_segment, T, ENCODE_THREADS, cfg, n_reads, (u32)S, seg);
+    if ((rc = launch_segment(c, decode, n_reads, (u32)S, seg))) return rc;
     // size the global tables for this phase's inserts (exact per-owner demand)
     const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
     LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
@@ -788,6 +778,10 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   }
   if ((rc = dalloc(c, &p, sizeof(u32) * 4, true))) return rc;
   cfg.err = (u32 *)p;
+#ifdef FQSX_TIMING
+  if ((rc = dalloc(c, &p, (u64)FQSX_TRACE_LAUNCHES * T * 8 * sizeof(u64), true))) return rc;
+  cfg.trace = (u64 *)p;
+#endif
   if ((rc = dalloc(c, &p, (4 * (u64)T + 1) * sizeof(u32), true))) return rc;
   c->d_demand = (u32 *)p;
   if ((rc = dalloc(c, &p, ((u64)T + 64) * sizeof(u64), true))) return rc;
@@ -928,6 +922,15 @@ int fqsx_dna_stats(fqsx_dna *c, uint64_t out[48]) {
   if (!c || !out) return FQSX_E_ARG;
   LAUNCH(c, 2, k_gather_stats, 1, 64, c->cfg, c->d_lens + c->T);
   return d2h_sync(c, out, c->d_lens + c->T, 48 * sizeof(u64));
+}
+
+// timing builds: the role time stamps of the first `max_launches` encode launches ([launch][worker][8], 10 ns ticks);
+// returns the number of launches copied (0 in product builds)
+int fqsx_dna_trace(fqsx_dna *c, uint64_t *out, uint32_t max_launches) {
+  if (!c || !out || !c->cfg.trace) return 0;
+  u32 n = (u32)std::min<u64>(std::min<u64>(c->k_n[0], FQSX_TRACE_LAUNCHES), max_launches);
+  if (n && d2h_sync(c, out, c->cfg.trace, (u64)n * c->T * 8 * sizeof(u64))) return 0;
+  return (int)n;
 }
 
 int fqsx_dna_set_profiling(fqsx_dna *c, int enable) {
@@ -1276,3 +1279,9 @@ extern "C" int fqsx_sort_order(const uint8_t *bases, const uint64_t *read_off, u
   for (u32 i = 0; i < n_reads; ++i) order_out[i] = v[i].second;
   return FQSX_OK;
 }
+
+#ifdef FQSX_EMU   // the emulation build is one translation unit
+#include "fqsx_k_se.hip"
+#include "fqsx_k_pe.hip"
+#include "fqsx_k_dec.hip"
+#endif

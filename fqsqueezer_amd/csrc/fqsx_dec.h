@@ -341,7 +341,7 @@ FQ_DEV void dec_update_s_letters(Wk &w, const u8 *codes, u32 size) {
 // prev_out: previous first mate of this worker in the output block (read_prev), or null.
 FQ_DEV bool read_dec(Wk &w, u8 *codes, u8 *p_out, u32 size, const u8 *prev_out, bool first_of_pair) {
   const DevCfg *cfg = w.cfg;
-  const bool orig = !first_of_pair || cfg->mode == 0 || cfg->mode == 2;
+  const bool orig = !first_of_pair || w.mode == 0 || w.mode == 2;
   if (first_of_pair) {
     u16 *m = small_base(w) + SM_OFF_FLAGS + w.ws->ctx_flags * (SM_FLAGS_N + 1);
     const bool same = sm_decode(w, m, SM_FLAGS_N, 1u << 12) != 0;

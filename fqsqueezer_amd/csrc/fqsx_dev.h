@@ -109,6 +109,38 @@ struct WgShared {
 #ifndef FQSX_EMU
 static_assert(sizeof(WgShared) <= 160u * 1024u, "WgShared must fit the 160 KB of LDS of a gfx950 CU");
 #endif
+// LDS of the insert-phase kernels (k_insert_phase, k_pe_insert): one RNG stream at a time and the batch scratch
+struct InsShared {
+  u32 mt[4][624];
+  u32 mt_idx[4];
+  u64 ib_pos[64];
+  u64 bk_key[64];
+  u64 pe_bk[3][64];
+};
+// Arguments of the encode / decode kernels: one struct, so that a role (FQ_ROLE) finds them in the kernel-argument
+// segment (scalar loads) instead of having them passed through vector registers.
+struct EncArgs {
+  DevCfg cfg;
+  u32 n_reads, S, seg, pad;
+};
+// A role receives the address of the kernel arguments as an ordinary (vector-register) argument -- the kernarg segment
+// pointer itself is only defined in the kernel function -- and makes it wave-uniform again, so that the arguments are
+// read with scalar loads from the constant address space.
+#ifndef FQSX_EMU
+__shared__ WgShared fq_wg_lds;   // the worker's LDS block (allocated only for kernels that reach it)
+FQ_DEV WgShared *fq_wg() { return &fq_wg_lds; }
+typedef const __attribute__((address_space(4))) EncArgs *FqArgsP;
+FQ_DEV FqArgsP fq_kernarg() { return (FqArgsP)__builtin_amdgcn_kernarg_segment_ptr(); }
+FQ_DEV const EncArgs *fq_args(FqArgsP a) {
+  const unsigned long v = (unsigned long)a;
+  const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+  return (const EncArgs *)(FqArgsP)(((unsigned long)hi << 32) | lo);
+}
+#else
+typedef const EncArgs *FqArgsP;
+FQ_DEV WgShared *fq_wg() { static thread_local WgShared s; return &s; }
+FQ_DEV const EncArgs *fq_args(FqArgsP a) { return a; }
+#endif
 enum { SX_VALID = 1, SX_LB = 2, SX_S = 4, SX_LS = 8 };
 enum { SK_NONE = 0, SK_RANK = 1, SK_LETTER = 2, SK_RANK_PENDING = 3, SK_LETTER_PENDING = 4, SK_RAW = 5, SK_KIND_MASK = 7,
        SK_RESET = 8 /* the r_sym history restarts at this entry (first symbol of a compress_suffix call, dna.cpp:676) */ };
@@ -117,13 +149,14 @@ enum { PV_B = 1, PV_S = 2, PV_P = 4, PV_PHID = 8, PV_PCAND = 16 };
 struct C4 { u32 c[4]; };
 struct Kmer { u64 dir, rc; u32 cur; };
 struct Cinc { u32 thr, mult, maxv; };
-struct Enc { u64 low, range, len, cap; u8 *out; };
+struct Enc { u64 low, range, len, cap, acc; u8 *out; };   // acc: bytes of the 8-byte output word being filled
 
 struct Wk {
   const DevCfg *cfg;
   WgShared *sm;
   WState *ws;
   u32 tid;
+  u32 mode;                             // dna_mode, a compile-time constant of the kernel (template argument of the bodies)
   Enc enc;
   Kmer pm, sm_, bm, pm_u, sm_u, bm_u;   // corrected and uncorrected rolling k-mers (dna.h:160-168)
   u64 ctx_letters;
@@ -154,6 +187,14 @@ struct Wk {
   u64 tm[32];
   u32 err;
 };
+// role time stamps of one launch (timing builds): 0 resolve start, 1 head end, 2 resolve end, 3 coder end, 4 scout end,
+// 5 inserter end, 6 resolve: reads done (before the final flush of the local inserts)
+#define FQSX_TRACE_LAUNCHES 4096u
+#ifdef FQSX_TIMING
+#define TM_STAMP(cfg, tid, launch, slot) do { if ((cfg).trace && (launch) < FQSX_TRACE_LAUNCHES && FQ_LANE == 0) (cfg).trace[((u64)(launch) * (cfg).T + (tid)) * 8 + (slot)] = fq_clock(); } while (0)
+#else
+#define TM_STAMP(cfg, tid, launch, slot) ((void)0)
+#endif
 #ifdef FQSX_TIMING
 #define TM_BEGIN(v) u64 v = fq_clock()
 #define TM_END(w, slot, v) (w).tm[slot] += fq_clock() - (v)
@@ -468,12 +509,16 @@ FQ_DEV void batch_count(Wk &w, const KTab &t, u32 n) {  // exact counts of the b
   w.st[ST_GSLOT] += wave_sum64(ns);
 }
 
-// lane-parallel in-order insert of <= 64 keys into sub-table `sub` (defined below)
-FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 sub, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
+// lane-parallel in-order insert of <= 64 keys into sub-table `sub` (defined below).  SM: the LDS block of the calling
+// kernel -- WgShared in the encode kernels, the small InsShared in the insert-phase kernels (mt, mt_idx, ib_pos).
+template <class SM>
+FQ_DEV void insert_batch(const DevCfg &cfg, SM *sm, const KTab &t, u32 sub, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
                          u64 &nslots, u32 &err);
-FQ_DEV void insert_batch_k(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 sub, u64 mykey, u32 n, u32 rng, const Cinc &ci,
+template <class SM>
+FQ_DEV void insert_batch_k(const DevCfg &cfg, SM *sm, const KTab &t, u32 sub, u64 mykey, u32 n, u32 rng, const Cinc &ci,
                            u64 &nslots, u32 &err);
-FQ_DEV void insert_keys(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 sub, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
+template <class SM>
+FQ_DEV void insert_keys(const DevCfg &cfg, SM *sm, const KTab &t, u32 sub, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
                         u64 &nslots, u32 &err) {
 #if FQ_WAVE > 1
   // the keys of the next batch are fetched while the current one is applied (the list is read-only here)
@@ -721,9 +766,26 @@ FQ_DEV u64 siv_count_equal(Wk &w, u64 lo, u64 hi, u64 flag) {
 
 // ---------------------------------------------------------------------------------------
 // range coder (CRangeEncoder, sub_rc.h:32-87) writing into the worker's HBM stream
+// The coder state is wave-uniform and kept in scalar registers (readfirstlane at enc_open), so the dependent chain of
+// a coding step -- multiply-high, compare, add, shift -- runs on the scalar unit.  Output bytes are gathered into the
+// aligned 8-byte word they belong to and leave with one store per word.
+FQ_DEV void enc_open(Wk &w, u64 low, u64 range, u64 len, const DevCfg &cfg) {
+  w.enc.low = uniform64(low); w.enc.range = uniform64(range); w.enc.len = uniform64(len);
+  w.enc.cap = cfg.out_cap; w.enc.out = cfg.out + (u64)w.tid * cfg.out_cap;
+  w.enc.acc = 0;
+  const u32 part = (u32)(w.enc.len & 7);
+  if (part && w.enc.len < w.enc.cap) w.enc.acc = uniform64(((const u64 *)w.enc.out)[w.enc.len >> 3]) & ((1ull << (8 * part)) - 1ull);
+}
+FQ_DEV void enc_close(Wk &w) {   // the partly filled word (its tail is rewritten when the stream goes on)
+  if ((w.enc.len & 7) && w.enc.len < w.enc.cap) ((u64 *)w.enc.out)[w.enc.len >> 3] = w.enc.acc;
+}
 FQ_DEV void rc_put(Wk &w, u8 b) {
-  if (w.enc.len < w.enc.cap) w.enc.out[w.enc.len] = b; else w.err = FQSX_ERR_OUT_OVERFLOW;
+  w.enc.acc |= (u64)b << (8 * (u32)(w.enc.len & 7));
   ++w.enc.len;
+  if ((w.enc.len & 7) == 0) {
+    if (w.enc.len <= w.enc.cap) ((u64 *)w.enc.out)[(w.enc.len >> 3) - 1] = w.enc.acc; else w.err = FQSX_ERR_OUT_OVERFLOW;
+    w.enc.acc = 0;
+  }
 }
 // exact range / tot for tot < 2^16 without the 64-bit software divide or an IEEE fp64 division: hardware
 // reciprocal (~26 bits) + one Newton step (~52 bits), high word and the remaining < 2^48 dividend each by one fp64
@@ -752,10 +814,21 @@ FQ_DEV u64 div_u64_rd(u64 x, u32 d, double rd) {
   return ((u64)qh << 32) + q;
 }
 FQ_DEV u64 div_u64_small(u64 x, u32 d) { return div_u64_rd(x, d, recip_u16(d)); }
-// rd = recip_u16(tot), computed off the serial chain where the caller can
-FQ_DEV void rc_encode_rd(Wk &w, u32 freq, u32 cum, u32 tot, double rd) {
+// One coding step (Encode, sub_rc.h:60-77) with the division as an integer multiply-high by
+// m = floor((2^64-1) / tot), 2 <= tot < 2^16: for any range < 2^64, mulhi(range, m) is the quotient or one less.
+// Integer only and wave-uniform: the whole dependent chain of a symbol runs on the scalar unit (low / range live in
+// scalar registers, see enc_open).  m is computed off the chain where the caller can (one lane per position in code_run).
+FQ_DEV u64 recip64_u16(u32 d) { return div_u64_rd(~0ull, d, recip_u16(d)); }
+FQ_DEV void rc_encode_m(Wk &w, u32 freq, u32 cum, u32 tot, u64 m) {
   const u64 Top = 0x00ffffffffffffULL, M = 0xff00000000000000ULL;
-  u64 range = div_u64_rd(w.enc.range, tot, rd), low = w.enc.low;
+  freq = uniform32(freq); cum = uniform32(cum); tot = uniform32(tot); m = uniform64(m);
+  u64 low = w.enc.low;
+#ifndef FQSX_EMU
+  u64 range = __umul64hi(w.enc.range, m);
+#else
+  u64 range = (u64)(((unsigned __int128)w.enc.range * m) >> 64);
+#endif
+  if (w.enc.range - range * tot >= tot) ++range;
   low += range * cum;
   range *= freq;
   while (range <= Top) {
@@ -767,6 +840,9 @@ FQ_DEV void rc_encode_rd(Wk &w, u32 freq, u32 cum, u32 tot, double rd) {
   w.enc.low = low;
   w.enc.range = range;
   w.st[ST_CODED] += 1;
+}
+FQ_DEV void rc_encode_rd(Wk &w, u32 freq, u32 cum, u32 tot, double rd) {
+  rc_encode_m(w, freq, cum, tot, div_u64_rd(~0ull, tot, rd));
 }
 
 // producer side of the coding queue: wait until `need` more entries fit
@@ -809,32 +885,6 @@ FQ_DEV void rc_encode(Wk &w, u32 freq, u32 cum, u32 tot) {
   FQ_SYNC();
   cq_publish(w, 1);
 }
-// The same step with the division as an integer multiply-high by m = floor((2^64-1) / tot), 2 <= tot < 2^16 (computed
-// off the serial chain, one lane per position): for any range < 2^64, mulhi(range, m) is the quotient or one less.  Integer
-// only and wave-uniform, so the whole dependent chain of a position can run on the scalar unit.
-FQ_DEV u64 recip64_u16(u32 d) { return div_u64_rd(~0ull, d, recip_u16(d)); }
-FQ_DEV void rc_encode_m(Wk &w, u32 freq, u32 cum, u32 tot, u64 m) {
-  const u64 Top = 0x00ffffffffffffULL, M = 0xff00000000000000ULL;
-  u64 low = w.enc.low;
-#ifndef FQSX_EMU
-  u64 range = __umul64hi(w.enc.range, m);
-#else
-  u64 range = (u64)(((unsigned __int128)w.enc.range * m) >> 64);
-#endif
-  if (w.enc.range - range * tot >= tot) ++range;
-  low += range * cum;
-  range *= freq;
-  while (range <= Top) {
-    if ((low ^ (low + range)) & M) range = (low | Top) - low;
-    rc_put(w, (u8)(low >> 56));
-    low <<= 8;
-    range <<= 8;
-  }
-  w.enc.low = low;
-  w.enc.range = range;
-  w.st[ST_CODED] += 1;
-}
-
 // small direct-indexed adaptive model in HBM: N stats + total (CSimpleModel, rc.h:20-173; Encode rc.h:397-405)
 FQ_DEV void sm_encode(Wk &w, u16 *m, u32 n, u32 max_total, u32 x) {
   u32 cum = 0;
@@ -912,6 +962,7 @@ FQ_DEV u32 ctx_find(Wk &w, u32 tag, u64 key, Slot4 &s) {
     u64 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];  // one 32-byte slot, fetched in one round trip
 #ifndef FQSX_EMU
     asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));   // ... which the compiler would otherwise split by sinking the key load below the tag test
+    q0 = uniform64(q0); q1 = uniform64(q1); q2 = uniform64(q2); q3 = uniform64(q3);   // (wave-uniform: keeps the search and the coder state on the scalar unit)
 #endif
     w.st[ST_CTX] += 1;
     u32 tg = slot_tag(q1);
@@ -2756,7 +2807,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
 // hist = the read's letter counts A, C, G, T.
 FQ_DEV bool read_head(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev_size, bool first_of_pair, u32 hist[4]) {
   const DevCfg *cfg = w.cfg;
-  const bool orig = !first_of_pair || cfg->mode == 0 || cfg->mode == 2;
+  const bool orig = !first_of_pair || w.mode == 0 || w.mode == 2;
   // duplicate test + staging of the read's codes in LDS + letter histogram, all lane-parallel
   bool diff = prev == nullptr || prev_size != size;
   u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0;
@@ -2793,8 +2844,7 @@ FQ_DEV void add_s_letters(Wk &w, const u32 hist[4]) {  // update_s_letters, dna.
 // this worker inside the block (read_prev is cleared per block, application.cpp:624), or null.
 // first_of_pair = false: the second mate coded by CompressDirect(..., false): direct prefix, no duplicate flag
 FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev_size, bool first_of_pair = true) {
-  const DevCfg *cfg = w.cfg;
-  const bool orig = !first_of_pair || cfg->mode == 0 || cfg->mode == 2;
+  const bool orig = !first_of_pair || w.mode == 0 || w.mode == 2;
   u32 hist[4];
   TM_BEGIN(t_head);
   const bool same = read_head(w, p, size, prev, prev_size, first_of_pair, hist);
@@ -2860,11 +2910,12 @@ FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx) {
 // The coder wave of the two-wave encode kernel: drains the coding queue while the other wave of the workgroup
 // resolves the reads.  Nothing the resolving wave decides depends on the context models, the level averages or the
 // range coder, so this wave owns them (and the worker's output stream) outright; the hand-off is the LDS queue.
-FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg) {
+FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg, u32 launch = 0) {
   Wk w;
   w.cfg = &cfg;
   w.sm = sm;
   w.tid = tid;
+  w.mode = 0;   // (unused by the coder)
   WState *ws = cfg.ws + tid;
   w.ws = ws;
   w.err = 0;
@@ -2878,9 +2929,8 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
   w.scout = false;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
   for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
-  if (seg == 0) { w.enc.low = 0; w.enc.range = 0xff00000000000000ULL; w.enc.len = 0; }   // application.cpp:624-628
-  else { w.enc.low = ws->rc_low; w.enc.range = ws->rc_range; w.enc.len = ws->out_len; }
-  w.enc.cap = cfg.out_cap; w.enc.out = cfg.out + (u64)tid * cfg.out_cap;
+  if (seg == 0) enc_open(w, 0, 0xff00000000000000ULL, 0, cfg);   // application.cpp:624-628
+  else enc_open(w, ws->rc_low, ws->rc_range, ws->out_len, cfg);
   w.avg_code = ws->avg_code; w.avg_letters = ws->avg_letters;
   u32 head = 0, spins = 0;
   TM_BEGIN(t_all);
@@ -2901,6 +2951,8 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
     }
   }
   TM_END(w, TM_P2, t_all);   // launch start to the last symbol coded (compare with the resolving wave's TM_TOTAL)
+  TM_STAMP(cfg, tid, launch, 3);
+  enc_close(w);
   ws->rc_low = w.enc.low; ws->rc_range = w.enc.range; ws->out_len = w.enc.len;
   ws->avg_code = w.avg_code; ws->avg_letters = w.avg_letters;
   if (FQ_LANE == 0) {
@@ -2916,7 +2968,7 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
 // order, as soon as the resolving wave publishes them.  It owns the local tables' contents, their fill counters and
 // the two local counter RNG streams while it has work; the resolving wave touches those only after it has seen
 // lq_done catch up (lq_flush), which it also does once more at the end of the segment.
-FQ_DEV void inserter_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
+FQ_DEV void inserter_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 launch = 0) {
   u32 la[2] = {0, 0}, err = 0, spins = 0;
   u64 ns = 0, lins = 0;
   bool failed = false;
@@ -2953,6 +3005,7 @@ FQ_DEV void inserter_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
     }
   }
   if (FQ_LANE == 0 && lins) atomic_add64(&cfg.ws[tid].stat[ST_LINS], lins);
+  TM_STAMP(cfg, tid, launch, 5);
 }
 
 // The read-head wave of the encode kernel (single-end sorted mode): for every read of the segment, one read ahead of
@@ -2960,12 +3013,12 @@ FQ_DEV void inserter_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid) {
 // the p-mer vector, which only changes between launches) and the arithmetic of the head's small models -- everything
 // that depends on the reads alone.  It owns the head's contexts (flag histories, previous p-mer) and small models;
 // the symbols reach the coder wave as finished triples via the resolving wave, which keeps the stream order.
-FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg) {
-  if (cfg.mode != 1) return;
+FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, u32 launch = 0) {
   Wk w;
   w.cfg = &cfg;
   w.sm = sm;
   w.tid = tid;
+  w.mode = 1;   // single-end sorted: the only mode with a read-head wave
   WState *ws = cfg.ws + tid;
   w.ws = ws;
   w.err = 0;
@@ -3024,6 +3077,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
     for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
   }
   if (w.err) *cfg.err = w.err;
+  TM_STAMP(cfg, tid, launch, 1);
 }
 
 // The scout wave of the encode kernel (single-end sorted mode): stage P of every chunk of every read, ahead of the
@@ -3034,12 +3088,12 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
 // back to its own stage P for the rest of a read once a correction has happened (sc_skip tells the scout to move on).
 // The chunk records which local-list entries were already applied when its probes started, so the resolving wave's
 // validation of the local probes (pend_conflict) covers exactly the entries the scout may have missed.
-FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg) {
-  if (cfg.mode != 1) return;
+FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, u32 launch = 0) {
   Wk w;
   w.cfg = &cfg;
   w.sm = sm;
   w.tid = tid;
+  w.mode = 1;
   WState *ws = cfg.ws + tid;
   w.ws = ws;
   w.err = 0;
@@ -3112,14 +3166,19 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
     FQ_SYNC();
     lds_store_rel(&sm->sc_hd_taken, idx + 1);
   }
+  TM_STAMP(cfg, tid, launch, 4);
 }
 
-// piped: this wave is the resolving half of a two-wave worker (see coder_segment_body)
-FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, bool decode = false, bool piped = false) {
+// piped: this wave is the resolving half of a multi-wave worker (see coder_segment_body).
+// MODE (dna_mode), DECODE and PIPED are compile-time constants: every kernel holds only the code of its own mode.
+template <int MODE, bool DECODE, bool PIPED>
+FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, u32 launch = 0) {
+  constexpr bool decode = DECODE, piped = PIPED;
   Wk w;
   w.cfg = &cfg;
   w.sm = sm;
   w.tid = tid;
+  w.mode = (u32)MODE;
   WState *ws = cfg.ws + tid;
   w.ws = ws;
   w.err = 0;
@@ -3127,7 +3186,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.lqh = piped;
   w.rec = nullptr;
   w.rdp = sm->rd[0];
-  const bool heads = piped && cfg.mode == 1;   // single-end sorted: the read heads come from the read-head wave
+  constexpr bool heads = PIPED && MODE == 1;   // single-end sorted: the read heads come from the read-head wave
   w.sb = &sm->sb[0];
   w.scout = heads;
   w.sc_abandoned = false;
@@ -3138,6 +3197,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
   for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
   TM_BEGIN(t_total);
+  TM_STAMP(cfg, tid, launch, 0);
   const u64 T = cfg.T;
   // PartitionForWorkers, reads_block.h:197-214
   u64 first = (u64)tid * n_reads / T, last = ((u64)tid + 1) * n_reads / T;
@@ -3152,7 +3212,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
     }
     ws->dec_pos = ~0ull;   // decoder: stream not started yet
   }
-  const bool paired = cfg.mode >= 2;
+  constexpr bool paired = MODE >= 2;
   u64 stop;
   if (seg < S) {
     const u64 ns = ((u64)seg + 1) * (last - first) / ((u64)S + 1) + first;
@@ -3180,8 +3240,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.pq_lo[0] = w.pq_lo[1] = 0;
   w.lq_pub[0] = w.lq_pub[1] = 0;
   FQ_SYNC();
-  w.enc.low = ws->rc_low; w.enc.range = ws->rc_range; w.enc.len = ws->out_len;
-  w.enc.cap = cfg.out_cap; w.enc.out = cfg.out + (u64)tid * cfg.out_cap;
+  enc_open(w, ws->rc_low, ws->rc_range, ws->out_len, cfg);
   w.avg_code = ws->avg_code; w.avg_letters = ws->avg_letters;
   for (u32 i = 0; i < 4; ++i) w.s_let[i] = ws->s_letters[i];
   w.hidden = ws->hidden_updates;
@@ -3235,6 +3294,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
       compress_pair(w, cfg.bases + o0, (u32)(o1 - o0), cfg.bases + o1, (u32)(o2 - o1), prev, prev_size);
     }
   if (stop > cur) cur = stop;
+  TM_STAMP(cfg, tid, launch, 6);
   // The local tables are emptied next (ClearKmersToHT), but the inserts still pending for them are applied all the
   // same: an insert that finds a counter above its threshold draws from the worker's cinc_lb / cinc_ls stream
   // (dna.cpp:826,837), whose state lives on.
@@ -3249,12 +3309,14 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   }
   ws->cursor = (u32)cur;
   if (!piped) {
+    enc_close(w);
     ws->rc_low = w.enc.low; ws->rc_range = w.enc.range; ws->out_len = w.enc.len;
     ws->avg_code = w.avg_code; ws->avg_letters = w.avg_letters;
   }
   for (u32 i = 0; i < 4; ++i) ws->s_letters[i] = w.s_let[i];
   ws->hidden_updates = w.hidden;
   TM_END(w, TM_TOTAL, t_total);
+  TM_STAMP(cfg, tid, launch, 2);
   if (!piped) {
     for (u32 i = 0; i < ST_N; ++i) ws->stat[i] += w.st[i];
     for (u32 i = 0; i < 32; ++i) ws->stat[16 + i] += w.tm[i];
@@ -3280,12 +3342,14 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
 // twice, or two new keys racing for one empty slot): the batch is then applied in rounds, each round
 // taking the longest prefix of the remaining keys that is free of such pairs, and the rest probes
 // again after the round's stores -- exactly the sequential result, in 1-2 rounds instead of n steps.
-FQ_DEV void insert_batch(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 tid, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
+template <class SM>
+FQ_DEV void insert_batch(const DevCfg &cfg, SM *sm, const KTab &t, u32 tid, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
                          u64 &nslots, u32 &err) {
   insert_batch_k(cfg, sm, t, tid, FQ_LANE < n ? keys[FQ_LANE] : 0, n, rng, ci, nslots, err);
 }
 // mykey: this lane's key of the batch (lanes >= n: ignored)
-FQ_DEV void insert_batch_k(const DevCfg &cfg, WgShared *sm, const KTab &t, u32 tid, u64 mykey, u32 n, u32 rng, const Cinc &ci,
+template <class SM>
+FQ_DEV void insert_batch_k(const DevCfg &cfg, SM *sm, const KTab &t, u32 tid, u64 mykey, u32 n, u32 rng, const Cinc &ci,
                            u64 &nslots, u32 &err) {
   (void)cfg;
   u64 *s = t.slots + (u64)tid * t.stride;
@@ -3431,7 +3495,8 @@ FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor 
 // owner `tid` applies its group of mailbox `kind` (InsertKmersToHT, dna.cpp:2393-2472).  The three
 // mailboxes touch disjoint state (p-mer vector / ht_smer + cinc_s / ht_bmer + cinc_b), so they run as
 // three independent workgroups per owner.
-FQ_DEV void insert_phase_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 kind) {
+template <class SM>
+FQ_DEV void insert_phase_body(const DevCfg &cfg, SM *sm, u32 tid, u32 kind) {
   WState *ws = cfg.ws + tid;
   const Mail &m = cfg.mail[kind];
   const u32 lo = m.dst_off[tid], hi = m.dst_off[tid + 1];

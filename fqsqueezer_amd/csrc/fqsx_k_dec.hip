@@ -1,0 +1,37 @@
+// fqsx_k_dec.hip -- the decode kernels (fqsx_dec.h): one wavefront per worker, every position through the complete
+// logic (the next k-mer depends on the symbol being decoded, so there is no stage P).
+#include "fqsx_kernels.h"
+
+template <int MODE> FQ_ROLE void role_decode(FqArgsP ap) {
+  const EncArgs *a = fq_args(ap);
+  encode_segment_body<MODE, true, false>(a->cfg, fq_wg(), FQ_BLOCK, a->n_reads, a->S, a->seg, a->pad);
+}
+
+#ifndef FQSX_EMU
+FQ_KERNEL64 void k_decode_se_orig(EncArgs a) { (void)a; role_decode<0>(fq_kernarg()); }
+FQ_KERNEL64 void k_decode_se_sorted(EncArgs a) { (void)a; role_decode<1>(fq_kernarg()); }
+FQ_KERNEL64 void k_decode_pe_orig(EncArgs a) { (void)a; role_decode<2>(fq_kernarg()); }
+FQ_KERNEL64 void k_decode_pe_sorted(EncArgs a) { (void)a; role_decode<3>(fq_kernarg()); }
+int fqsx_launch_decode(hipStream_t s, const EncArgs &a) {
+  const dim3 g(a.cfg.T), b(64);
+  switch (a.cfg.mode) {
+    case 0: hipLaunchKernelGGL(k_decode_se_orig, g, b, 0, s, a); break;
+    case 1: hipLaunchKernelGGL(k_decode_se_sorted, g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(k_decode_pe_orig, g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL(k_decode_pe_sorted, g, b, 0, s, a); break;
+  }
+  return (int)hipGetLastError();
+}
+#else
+static void fqsx_emu_decode(const EncArgs &a) {
+    for (u32 b = 0; b < a.cfg.T; ++b) {
+    fq_emu_block = b;
+    switch (a.cfg.mode) {
+      case 0: encode_segment_body<0, true, false>(a.cfg, fq_wg(), b, a.n_reads, a.S, a.seg); break;
+      case 1: encode_segment_body<1, true, false>(a.cfg, fq_wg(), b, a.n_reads, a.S, a.seg); break;
+      case 2: encode_segment_body<2, true, false>(a.cfg, fq_wg(), b, a.n_reads, a.S, a.seg); break;
+      default: encode_segment_body<3, true, false>(a.cfg, fq_wg(), b, a.n_reads, a.S, a.seg); break;
+    }
+  }
+}
+#endif

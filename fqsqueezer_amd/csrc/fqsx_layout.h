@@ -164,6 +164,7 @@ struct DevCfg {
   u8 *dscratch;                // [T][2][dcap] 0..4 codes of the read being decoded (+ reverse-complement line)
   u64 dcap;
   u32 *err;                    // device error word (0 = ok)
+  u64 *trace;                  // -DFQSX_TIMING builds: [launch][worker][8] clock stamps of the roles (else null)
 };
 
 enum {

@@ -317,7 +317,8 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
 // ---- insert phase: owner `tid` scans every source's triples and applies those it owns.  Inserts commute
 // (count = min(sum, max)), so the scan order is irrelevant; a batch of <= 64 owned triples is applied
 // lane-parallel unless two of them touch the same slot.
-FQ_DEV void pe_apply_batch(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n, u32 &err) {
+template <class SM>
+FQ_DEV void pe_apply_batch(const DevCfg &cfg, SM *sm, u32 tid, u32 n, u32 &err) {
   const PTab &t = cfg.g_pe;
   const u32 cs = 2 * cfg.bmer;
   const u64 vm = (1ull << cs) - 1ull, maxc = (~0ull) >> cs;
@@ -388,7 +389,8 @@ FQ_DEV void pe_apply_batch(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n, u32 
 }
 
 // count_only: number of triples owner `tid` will insert (upper bound of new slots) -> demand[tid]
-FQ_DEV void pe_insert_body(const DevCfg &cfg, WgShared *sm, u32 tid, bool count_only, u32 *demand) {
+template <class SM>
+FQ_DEV void pe_insert_body(const DevCfg &cfg, SM *sm, u32 tid, bool count_only, u32 *demand) {
   const u32 T = cfg.T;
   const u64 vm = (1ull << (2 * cfg.bmer)) - 1ull;
   u32 pending = 0, total = 0, err = 0;

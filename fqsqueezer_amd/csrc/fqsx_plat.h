@@ -22,9 +22,15 @@ typedef int32_t i32;
 #include <hip/hip_runtime.h>
 #define FQ_DEV __device__ __forceinline__
 #define FQ_DEVN __device__ __noinline__
+// One role of a worker (resolve / coder / inserter / read head / scout): a real function, called once by its wave,
+// so that every role gets its own register allocation and its own stretch of code.  It takes no pointer arguments:
+// the LDS block and the kernel arguments are reached through fq_wg() / fq_args(), which keeps their address spaces
+// (ds_* instructions, scalar loads) visible to the compiler inside the role.
+#define FQ_ROLE static __device__ __noinline__
 #define FQ_KERNEL extern "C" __global__
 #define FQ_KERNEL64 extern "C" __global__ __launch_bounds__(64)
 #define FQ_KERNEL320 extern "C" __global__ __launch_bounds__(320)
+#define FQ_KERNEL192 extern "C" __global__ __launch_bounds__(192)
 #define FQ_WAVE 64
 #define FQ_LANE ((u32)(threadIdx.x & 63u))
 #define FQ_BLOCK ((u32)blockIdx.x)
@@ -94,9 +100,11 @@ FQ_DEV double ema_update(double avg, double level) { return __dadd_rn(__dmul_rn(
 #include <string.h>
 #define FQ_DEV static inline
 #define FQ_DEVN static
+#define FQ_ROLE static
 #define FQ_KERNEL static
 #define FQ_KERNEL64 static
 #define FQ_KERNEL320 static
+#define FQ_KERNEL192 static
 #define FQ_WAVE 1
 #define FQ_LANE 0u
 #define FQ_BLOCK (fq_emu_block)

@@ -84,6 +84,9 @@ int fqsx_dna_stats(fqsx_dna *, uint64_t out[48]);
  * kernels; out[3..5] = their launch counts. */
 int fqsx_dna_set_profiling(fqsx_dna *, int enable);
 int fqsx_dna_kernel_times(fqsx_dna *, double out[6]);
+/* Diagnostic builds (-DFQSX_TIMING) only: per-launch, per-worker clock stamps of the five roles of the encode kernel,
+ * out[launch][worker][8] in 10 ns ticks; returns the number of launches copied (always 0 in the product build). */
+int fqsx_dna_trace(fqsx_dna *, uint64_t *out, uint32_t max_launches);
 
 /* Quality stream on the GPU: replaces CQualityCompressor::Init / Compress for all T
  * workers of a block (fqs/quality.h:43-50, fqs/quality.cpp:32-71,152-175; called from fqs/application.cpp:641).

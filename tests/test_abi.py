@@ -29,7 +29,9 @@ def test_contains_gfx950_code_object(libpath):
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-S", libpath], capture_output=True, text=True).stdout
     assert ".hip_fatbin" in out
     blob = open(libpath, "rb").read()
-    assert b"gfx950" in blob and b"k_encode_segment" in blob
+    for kernel in (b"k_encode_se_sorted", b"k_encode_se_orig", b"k_encode_pe_sorted", b"k_decode_se_sorted", b"k_insert_phase", b"k_qual_encode"):
+        assert kernel in blob, kernel
+    assert b"gfx950" in blob
 
 
 def test_fails_loudly_without_gpu(libpath):

@@ -1,0 +1,48 @@
+"""Diagnostic (timing build): which role of which worker ends an encode launch last.  Runs the bench workload's first
+blocks through tools/libfqsx_timing.so and reads the per-launch role time stamps (fqsx_dna_trace).
+usage: python tools/gpu_roles.py [n_blocks=100] [len=150] [T=64]"""
+import ctypes as C, os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.codec import DnaCodec
+from fqsqueezer_amd.synth import synth_reads, read_id
+
+nblk = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+G, gs = (7500000, 8) if L == 150 else (5000000, 5)
+reads = synth_reads(1000000, L, G, 2)
+rec = hp.Records([read_id(i) for i in range(len(reads))], reads, reads)
+header = hp.make_header(T, "se_sorted", gs)
+blocks = hp.form_blocks(rec, "se_sorted")[:nblk]
+lib = os.path.join(ROOT, "tools", "libfqsx_timing.so")
+c = DnaCodec(header, lib_path=lib)
+segs = []   # (block, n_segments)
+for g, idx in enumerate(blocks):
+    bases, off = hp.block_arrays(rec, idx)
+    before = c.kernel_times()["encode_launches"] if False else None
+    c.encode_block(bases, off, g)
+c._lib.fqsx_dna_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+c._lib.fqsx_dna_trace.restype = C.c_int
+buf = np.zeros((4096, T, 8), dtype=np.uint64)
+n = c._lib.fqsx_dna_trace(c._h, buf.ctypes.data, 4096)
+tr = buf[:n].astype(np.int64)
+start = tr[:, :, 0].min(axis=1, keepdims=True)          # launch start = earliest resolve start
+names = ["head", "resolve", "coder", "scout", "inserter"]
+ends = (tr[:, :, 1:6] - start[:, :, None]) * 0.01        # us
+ends[tr[:, :, 1:6] == 0] = 0
+launch_len = ends.max(axis=(1, 2))
+last_worker = ends.max(axis=2).argmax(axis=1)
+last_role = np.array([ends[i, last_worker[i]].argmax() for i in range(n)])
+wend = ends.max(axis=2)                                  # per worker: its last role's end
+res = {"launches": int(n), "mean_launch_us": float(launch_len.mean()), "mean_worker_end_us": float(wend.mean()),
+       "mean_worker_over_launch": float((wend.mean(axis=1) / launch_len).mean()),
+       "last_role_histogram": {names[k]: int((last_role == k).sum()) for k in range(5)},
+       "mean_end_us_by_role": {names[k]: float(ends[:, :, k].mean()) for k in range(5)},
+       "slowest_worker_end_us_by_role": {names[k]: float(np.mean([ends[i, last_worker[i], k] for i in range(n)])) for k in range(5)},
+       "resolve_reads_done_us_mean": float(((tr[:, :, 6] - start) * 0.01).mean()),
+       "p50_p90_p99_launch_us": [float(np.percentile(launch_len, q)) for q in (50, 90, 99)]}
+# the 2-read warm-up launches only (blocks 0..69 have 30 launches each)
+print(json.dumps(res))

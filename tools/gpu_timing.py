@@ -12,9 +12,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 lib = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else os.path.join(ROOT, "tools", "libfqsx_timing.so")
 max_blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 1 << 30   # only the first blocks of the file
-reads = synth_reads(1000000, 100, 5000000, 2)[:n]
+L = int(sys.argv[5]) if len(sys.argv) > 5 else 150           # read length: 150 = the metric's workload, 100 = BASELINE configs[1]
+G, gs = (7500000, 8) if L == 150 else (5000000, 5)
+reads = synth_reads(1000000, L, G, 2)[:n]
 rec = hp.Records([read_id(i) for i in range(n)], reads, reads)
-header = hp.make_header(T, "se_sorted", 5)
+header = hp.make_header(T, "se_sorted", gs)
 blocks = hp.form_blocks(rec, "se_sorted")
 c = DnaCodec(header, lib_path=lib)
 c.set_profiling(True)
@@ -36,7 +38,7 @@ cn["slow: pushes+repairs s"] = st["timers"][25] * 1e-8
 for k, nm in enumerate(["code_run: S probes s", "code_run: same-slot+validate s", "code_run: avg loop s", "code_run: commit+rc s", "code_keys s"]):
     cn[nm] = st["timers"][27 + k] * 1e-8
 tm = [x * 1e-8 for x in st["timers"][:10]]
-print(f"{n} reads T={T}: wall {dt:.2f}s  {n*100/dt/1e6:.2f} Mbases/s  kernels: {kt}")
+print(f"{n} reads T={T}: wall {dt:.2f}s  {n*L/dt/1e6:.2f} Mbases/s  kernels: {kt}")
 print("section seconds summed over workers:", {k: round(v, 3) for k, v in zip(names, tm)})
 tot = tm[0] or 1
 print("shares of worker time:", {k: round(v / tot, 3) for k, v in zip(names, tm)})
