@@ -11,10 +11,12 @@
 #define FQSX_RR 6u
 #define FQSX_SW 4u    // Hamming-1 sweeps the scout wave keeps in flight (one probe of each per lane)
 #define FQSX_SCR 3u   // scout ring: chunks the scout wave may be ahead of their release
+#define FQSX_RQ 256u  // entries of the range-coder queue (power of two)
 // One stage-P chunk: everything about positions i0..i0+n-1 of a read that does not depend on the adaptive models,
 // computed one position per lane under the assumption "no k-mer correction since the k-mers stage P started from".
 struct SpecBuf {
   u32 h_read, h_i0, h_n;       // scout chunks: read index within the launch, first position, positions
+  u32 h_epoch;                 // ... and the restart epoch of the k-mer state they were rolled from (see ScoutReq)
   u32 h_pq_lo[2];              // list entries (b, s) below these were in the local tables when the chunk's probes started
   u32 h_np, h_nlp;             // probes issued (global, local) ...
   u64 h_ns, h_nls;             // ... and slots scanned, accounted when the chunk is used
@@ -59,6 +61,7 @@ struct SpecBuf {
 // entries, the rolling k-mers after the prefix and the read's letter histogram.
 #define FQSX_HD_RAW 56u
 struct HeadRec {
+  u32 idx;                     // read (index within the launch) the record describes; ~0 while it is being written
   u32 n_raw, same, n_run, n_p;
   u32 hist[4];
   u64 raw[FQSX_HD_RAW][2];     // freq | cum << 32, total
@@ -75,10 +78,30 @@ struct WgShared {
   u64 bk_key[256];             // probe batch: normalised k-mers
   u32 bk_res[256][4];          // probe batch: counts
   u8 bk_dir[256];              // probe batch: orientation
-  SpecBuf sb[1 + FQSX_SCR];    // [0] filled by the resolving wave itself, [1..] ring filled by the scout wave
+  union {   // the scout ring exists in single-end sorted mode only, the paired-end scratch in the paired-end modes only
+    SpecBuf sb[1 + FQSX_SCR];  // [0] filled by the resolving wave itself, [1..] ring filled by the scout wave
+    struct {
+      SpecBuf sb_self_;        // (= sb[0])
+      u8 r2c[FQSX_RD_LDS];     // paired-end: codes of the second mate
+      u64 pe_cand[512];        // paired-end: candidate partner b-mers (value | count << 2k)
+      u64 pe_top[64];
+      u64 pe_bk[3][64];        // paired-end insert batch (key, value, weight)
+    };
+  };
   u32 sc_ready, sc_taken;      // scout chunks published / released (free-running); chunk c lives in sb[1 + c % FQSX_SCR]
   u32 sc_skip;                 // reads below this index (within the launch) need no further scout chunks
   u32 sc_hd_taken;             // read heads the scout wave is done with
+  // Restart of the scout wave after a k-mer correction: the resolving wave posts the exact state after the chunk it
+  // has just committed (sc_req, then sc_req_seq = the new epoch); the scout wave drops what it is doing, goes back
+  // to that read and rolls the rest of it from the posted state.  Chunks carry the epoch they were made under.
+  u32 sc_req_seq;
+  u32 sc_dead;                 // the scout wave has given up for this launch (it found itself behind the resolving wave)
+  struct ScoutReq {
+    u32 read, i0, cor_pos, n_run;
+    u64 kdir[6], krc[6];
+    u32 kcur[6];
+    u64 s_let[4];
+  } sc_req;
   u64 lev_tmp[10];             // level keys of a position coded outside the fast path
   // fast_run: per-position results of the lane-parallel context search / model stage
   u32 fr_idx[64], fr_c0[64], fr_thr[64], fr_vis[64];   // final slot, its counter, threshold to re-validate (or ~0), slots visited
@@ -88,10 +111,6 @@ struct WgShared {
   u32 fr_f[64], fr_c[64], fr_t[64];                    // range-coder triple of the position (GPU: lane registers)
 #endif
   u8 fr_lvl[64], fr_bad[64];
-  u8 r2c[FQSX_RD_LDS];         // paired-end: codes of the second mate
-  u64 pe_cand[512];            // paired-end: candidate partner b-mers (value | count << 2k)
-  u64 pe_top[64];
-  u64 pe_bk[3][64];            // paired-end insert batch (key, value, weight)
   u64 pq_key[2][FQSX_PQ];      // LDS mirror of the most recent b / s list entries (ring indexed by list position)
   u64 ib_pos[64];              // insert_batch: target slot per lane
   u32 qm_bits[4][128];         // quiet_miss_mask: 4096-bit sets of the sibling groups of recent list entries (b dir, b rc, s dir, s rc)
@@ -105,6 +124,11 @@ struct WgShared {
   u8 cq_kind[FQSX_CQ];         // SK_* | SK_RESET
   u8 cq_rsym[FQSX_CQ];
   u32 cq_tail, cq_head, cq_done;   // entries published / consumed (free-running); producer finished
+  // range-coder queue (six-wave kernel): the finished (freq, cum, total, reciprocal) of every symbol in stream order,
+  // from the wave that runs the context models to the wave that runs the range coder
+  u32 rq_f[FQSX_RQ], rq_c[FQSX_RQ], rq_t[FQSX_RQ];
+  u64 rq_m[FQSX_RQ];
+  u32 rq_tail, rq_head, rq_done;
 };
 #ifndef FQSX_EMU
 static_assert(sizeof(WgShared) <= 160u * 1024u, "WgShared must fit the 160 KB of LDS of a gfx950 CU");
@@ -178,10 +202,13 @@ struct Wk {
   bool scout;                           // stage P of clean chunks comes from the scout wave
   bool sc_abandoned;                    // ... but no longer for the current read (a k-mer correction happened)
   u32 sc_read;                          // index of the current read within the launch
+  u32 sc_epoch;                         // restart epoch this wave is in (resolving wave: the one it expects chunks of)
   u32 sc_taken;                         // scout chunks released so far
   HeadRec *rec;                         // read-head wave: where the head's output goes (null: code / push directly)
   bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
   u32 cq_tail, cq_head;                 // this wave's copy of its own queue index
+  bool rcq;                             // coding steps go to the range-coder queue (another wave runs the coder proper)
+  u32 rq_tail;                          // ... this wave's copy of its index
   u64 c_r_sym;                          // coder: ctx_r_sym, the last 8 rank-0 flags (dna.cpp:664-671)
   u64 st[ST_N];
   u64 tm[32];
@@ -819,7 +846,30 @@ FQ_DEV u64 div_u64_small(u64 x, u32 d) { return div_u64_rd(x, d, recip_u16(d)); 
 // Integer only and wave-uniform: the whole dependent chain of a symbol runs on the scalar unit (low / range live in
 // scalar registers, see enc_open).  m is computed off the chain where the caller can (one lane per position in code_run).
 FQ_DEV u64 recip64_u16(u32 d) { return div_u64_rd(~0ull, d, recip_u16(d)); }
+// model wave -> range-coder wave: room for `need` more entries
+FQ_DEV bool rq_wait_space(Wk &w, u32 need) {
+  if (w.rq_tail - lds_load_acq(&w.sm->rq_head) + need <= FQSX_RQ) return true;
+  TM_BEGIN(t_rq);
+  u32 spins = 0;
+  while (w.rq_tail - lds_load_acq(&w.sm->rq_head) + need > FQSX_RQ) {
+    fq_sleep();
+    if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; return false; }   // never spin forever on the GPU
+  }
+  TM_END(w, TM_CQWAIT, t_rq);
+  return true;
+}
 FQ_DEV void rc_encode_m(Wk &w, u32 freq, u32 cum, u32 tot, u64 m) {
+  if (w.rcq) {   // hand the step to the range-coder wave
+    if (!rq_wait_space(w, 1)) return;
+    WgShared *sm = w.sm;
+    const u32 e = w.rq_tail & (FQSX_RQ - 1);
+    FQ_SYNC();
+    if (FQ_LANE == 0) { sm->rq_f[e] = freq; sm->rq_c[e] = cum; sm->rq_t[e] = tot; sm->rq_m[e] = m; }
+    FQ_SYNC();
+    w.rq_tail += 1;
+    lds_store_rel(&sm->rq_tail, w.rq_tail);
+    return;
+  }
   const u64 Top = 0x00ffffffffffffULL, M = 0xff00000000000000ULL;
   freq = uniform32(freq); cum = uniform32(cum); tot = uniform32(tot); m = uniform64(m);
   u64 low = w.enc.low;
@@ -848,11 +898,14 @@ FQ_DEV void rc_encode_rd(Wk &w, u32 freq, u32 cum, u32 tot, double rd) {
 // producer side of the coding queue: wait until `need` more entries fit
 FQ_DEV bool cq_wait_space(Wk &w, u32 need) {
   if (!w.piped) return true;
+  if (w.cq_tail - lds_load_acq(&w.sm->cq_head) + need <= FQSX_CQ) return true;
+  TM_BEGIN(t_cq);
   u32 spins = 0;
   while (w.cq_tail - lds_load_acq(&w.sm->cq_head) + need > FQSX_CQ) {
     fq_sleep();
     if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; return false; }   // never spin forever on the GPU
   }
+  TM_END(w, TM_CQWAIT, t_cq);
   return true;
 }
 FQ_DEV void cq_publish(Wk &w, u32 n) {
@@ -1509,7 +1562,7 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
   const u32 pi = lane / 3, r3 = lane - 3 * pi;
   const u32 shd = 62 - 2 * pi, shr = 64 - 2 * g.k + 2 * pi;
   while (cm) {
-    if (lds_load_acq(&w.sm->sc_skip) > w.sc_read) break;   // the read was finished without the scout: nobody will look
+    if (lds_load_acq(&w.sm->sc_skip) > w.sc_read || lds_load_acq(&w.sm->sc_req_seq) != w.sc_epoch) break;   // nobody will look at this chunk any more
     u32 js[FQSX_SW];
     bool ok[FQSX_SW];
 #pragma unroll
@@ -2368,11 +2421,23 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len) {
   w.st[ST_CTX] += wave_sum32(vis_sum);
   // ---- the range coder, in position order
 #if FQ_WAVE > 1
-  for (u32 t = 0; t < L; ++t) {
-    const u64 m = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(lane_m >> 32), t) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)lane_m, t);
-    rc_encode_m(w, (u32)__builtin_amdgcn_readlane((int)lane_f, t), (u32)__builtin_amdgcn_readlane((int)lane_c, t),
-                (u32)__builtin_amdgcn_readlane((int)lane_t, t), m);
-  }
+  if (w.rcq) {   // the run's steps go to the range-coder wave, one lane per position
+    if (rq_wait_space(w, L)) {
+      const u32 t = FQ_LANE;
+      if (t < L) {
+        const u32 e = (w.rq_tail + t) & (FQSX_RQ - 1);
+        sm->rq_f[e] = lane_f; sm->rq_c[e] = lane_c; sm->rq_t[e] = lane_t; sm->rq_m[e] = lane_m;
+      }
+      FQ_SYNC();
+      w.rq_tail += L;
+      lds_store_rel(&sm->rq_tail, w.rq_tail);
+    }
+  } else
+    for (u32 t = 0; t < L; ++t) {
+      const u64 m = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(lane_m >> 32), t) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)lane_m, t);
+      rc_encode_m(w, (u32)__builtin_amdgcn_readlane((int)lane_f, t), (u32)__builtin_amdgcn_readlane((int)lane_c, t),
+                  (u32)__builtin_amdgcn_readlane((int)lane_t, t), m);
+    }
 #else
   for (u32 t = 0; t < L; ++t) rc_encode(w, sm->fr_f[t], sm->fr_c[t], sm->fr_t[t]);
 #endif
@@ -2495,7 +2560,7 @@ FQ_DEV bool scout_take(Wk &w, u32 i, u32 n) {
     u32 spins = 0;
     while (lds_load_acq(&sm->sc_ready) == w.sc_taken) {
       fq_sleep();
-      if (++spins > (1u << 22)) {   // never spin forever on the GPU: go on without the scout for this read
+      if (lds_load_acq(&sm->sc_dead) || ++spins > (1u << 22)) {   // never spin forever on the GPU: go on without the scout for this read
         w.sc_abandoned = true;
         lds_store_rel(&sm->sc_skip, w.sc_read + 1);
         return false;
@@ -2503,12 +2568,28 @@ FQ_DEV bool scout_take(Wk &w, u32 i, u32 n) {
     }
     SpecBuf *b = &sm->sb[1 + w.sc_taken % FQSX_SCR];
     const u32 r = b->h_read;
-    if ((i32)(r - w.sc_read) < 0) { scout_release(w); continue; }   // left over from a read that was finished without the scout
+    // left over from before a restart, or from a read that was finished without the scout
+    if (b->h_epoch != w.sc_epoch || (i32)(r - w.sc_read) < 0) { scout_release(w); continue; }
     if (r == w.sc_read && b->h_i0 == i && b->h_n == n) { w.sb = b; return true; }
     w.sc_abandoned = true;
     lds_store_rel(&sm->sc_skip, w.sc_read + 1);
     return false;
   }
+}
+// The resolving wave has corrected k-mers: hand the scout wave the exact state before position i0 of the current read
+FQ_DEV void scout_restart(Wk &w, u32 i0) {
+  WgShared *sm = w.sm;
+  FQ_SYNC();
+  if (FQ_LANE == 0) {
+    WgShared::ScoutReq &q = sm->sc_req;
+    q.read = w.sc_read; q.i0 = i0; q.cor_pos = w.cor_pos; q.n_run = w.N_run;
+    const Kmer *k[6] = {&w.pm, &w.sm_, &w.bm, &w.pm_u, &w.sm_u, &w.bm_u};
+    for (u32 x = 0; x < 6; ++x) { q.kdir[x] = k[x]->dir; q.krc[x] = k[x]->rc; q.kcur[x] = k[x]->cur; }
+    for (u32 x = 0; x < 4; ++x) q.s_let[x] = w.s_let[x];
+  }
+  FQ_SYNC();
+  w.sc_epoch += 1;
+  lds_store_rel(&sm->sc_req_seq, w.sc_epoch);
 }
 
 // compress_suffix, dna.cpp:674-877, as chunks of stage P (parallel) -> stage C (the serial loop below:
@@ -2694,7 +2775,6 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           }
         }
         TM_END(w, TM_SPRE, t_code);
-        TM_BEGIN(t_sc);
         // code the symbol (dna.cpp:737-801)
         if (level != LV_NONE && nrun_here < 2) {
           int cor_dist = level == LV_PMER ? (int)cfg->pmer : level == LV_SMER ? (int)cfg->smer : (int)cfg->bmer;
@@ -2713,8 +2793,6 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           if (FQ_LANE == 0) w.sb->sp_kind[j] = SK_LETTER_PENDING;
           FQ_SYNC();
         }
-        TM_END(w, TM_SCODE, t_sc);
-        TM_BEGIN(t_spo);
         // mailbox entries and context repair (dna.cpp:803-874)
         const bool lvl_sbm = level == LV_SMER || level == LV_BMER || level == LV_MIXED;
         if (loaded) {
@@ -2779,7 +2857,6 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
             }
           }
         }
-        TM_END(w, TM_SPOST, t_spo);
         TM_END(w, TM_SLOW, t_code);
       }
       m = j + 1;
@@ -2794,10 +2871,9 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       replace_last_all(w, sym == 4 ? 0 : sym);
       w.N_run = sym == 4 ? w.N_run + 1 : 0;
     }
-    if (dirty && w.scout && !w.sc_abandoned) {   // the scout's clean-read assumption no longer holds for this read
-      w.sc_abandoned = true;
-      lds_store_rel(&sm->sc_skip, w.sc_read + 1);   // (before the release below: a scout woken by it must see the skip)
-    }
+    // the scout's chunks of this read were rolled from k-mers that have just been corrected: it starts again from here
+    // (posted before the release below: a scout woken by that must see the request)
+    if (dirty && w.scout && !w.sc_abandoned && i + m < size) scout_restart(w, i + m);
     if (pre) scout_release(w);
     i += m;
   }
@@ -2910,6 +2986,9 @@ FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx) {
 // The coder wave of the two-wave encode kernel: drains the coding queue while the other wave of the workgroup
 // resolves the reads.  Nothing the resolving wave decides depends on the context models, the level averages or the
 // range coder, so this wave owns them (and the worker's output stream) outright; the hand-off is the LDS queue.
+// SPLIT (six-wave kernel): this wave runs the context models and the level averages only and hands every coding step
+// to the range-coder wave (rc_segment_body), which owns the coder state and the output stream.
+template <bool SPLIT>
 FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg, u32 launch = 0) {
   Wk w;
   w.cfg = &cfg;
@@ -2929,8 +3008,12 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
   w.scout = false;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
   for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
-  if (seg == 0) enc_open(w, 0, 0xff00000000000000ULL, 0, cfg);   // application.cpp:624-628
-  else enc_open(w, ws->rc_low, ws->rc_range, ws->out_len, cfg);
+  w.rcq = SPLIT;
+  w.rq_tail = 0;
+  if (!SPLIT) {
+    if (seg == 0) enc_open(w, 0, 0xff00000000000000ULL, 0, cfg);   // application.cpp:624-628
+    else enc_open(w, ws->rc_low, ws->rc_range, ws->out_len, cfg);
+  }
   w.avg_code = ws->avg_code; w.avg_letters = ws->avg_letters;
   u32 head = 0, spins = 0;
   TM_BEGIN(t_all);
@@ -2946,15 +3029,89 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
       spins = 0;
     } else if (done) break;
     else {
+      TM_BEGIN(t_idle);
       fq_sleep();
       if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+      TM_END(w, TM_CODER_IDLE, t_idle);
     }
   }
   TM_END(w, TM_P2, t_all);   // launch start to the last symbol coded (compare with the resolving wave's TM_TOTAL)
   TM_STAMP(cfg, tid, launch, 3);
+  if (SPLIT) {
+    FQ_SYNC();
+    lds_store_rel(&sm->rq_done, 1u);   // everything is queued: let the range-coder wave finish
+  } else {
+    enc_close(w);
+    ws->rc_low = w.enc.low; ws->rc_range = w.enc.range; ws->out_len = w.enc.len;
+  }
+  ws->avg_code = w.avg_code; ws->avg_letters = w.avg_letters;
+  if (FQ_LANE == 0) {
+    for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
+#ifdef FQSX_TIMING
+    for (u32 i = 0; i < 32; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
+#endif
+  }
+  if (w.err) *cfg.err = w.err;
+}
+
+// The range-coder wave of the six-wave kernel: the strictly sequential tail of the pipeline -- one coding step per
+// symbol (Encode, sub_rc.h:60-77) on wave-uniform state, byte output -- fed with finished (freq, cum, total, reciprocal)
+// entries through the LDS queue.  It owns the coder state and the worker's output stream.
+FQ_DEV void rc_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg, u32 launch = 0) {
+  Wk w;
+  w.cfg = &cfg;
+  w.sm = sm;
+  w.tid = tid;
+  w.mode = 0;
+  WState *ws = cfg.ws + tid;
+  w.ws = ws;
+  w.err = 0;
+  w.piped = false;
+  w.lqh = false;
+  w.rec = nullptr;
+  w.rcq = false;
+  w.scout = false;
+  for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
+  for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
+  if (seg == 0) enc_open(w, 0, 0xff00000000000000ULL, 0, cfg);   // application.cpp:624-628
+  else enc_open(w, ws->rc_low, ws->rc_range, ws->out_len, cfg);
+  u32 head = 0, spins = 0;
+  for (;;) {
+    const u32 done = lds_load_acq(&sm->rq_done);   // read before the tail: once set, the tail is final
+    const u32 tail = lds_load_acq(&sm->rq_tail);
+    if (tail != head) {
+      TM_BEGIN(t_rc);
+      const u32 n = tail - head < FQ_WAVE ? tail - head : FQ_WAVE;
+#if FQ_WAVE > 1
+      // one entry per lane, then the steps in order from the lanes' registers
+      const u32 e = (head + (FQ_LANE < n ? FQ_LANE : 0u)) & (FQSX_RQ - 1);
+      const u32 lf = sm->rq_f[e], lc = sm->rq_c[e], lt = sm->rq_t[e];
+      const u64 lm = sm->rq_m[e];
+      for (u32 t = 0; t < n; ++t) {
+        const u64 m = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(lm >> 32), t) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)lm, t);
+        rc_encode_m(w, (u32)__builtin_amdgcn_readlane((int)lf, t), (u32)__builtin_amdgcn_readlane((int)lc, t),
+                    (u32)__builtin_amdgcn_readlane((int)lt, t), m);
+      }
+#else
+      for (u32 t = 0; t < n; ++t) {
+        const u32 e = (head + t) & (FQSX_RQ - 1);
+        rc_encode_m(w, sm->rq_f[e], sm->rq_c[e], sm->rq_t[e], sm->rq_m[e]);
+      }
+#endif
+      head += n;
+      FQ_SYNC();
+      lds_store_rel(&sm->rq_head, head);
+      TM_END(w, TM_CR_RC, t_rc);
+      spins = 0;
+    } else if (done) break;
+    else {
+      fq_sleep();
+      if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+    }
+  }
+  TM_STAMP(cfg, tid, launch, 7);
   enc_close(w);
   ws->rc_low = w.enc.low; ws->rc_range = w.enc.range; ws->out_len = w.enc.len;
-  ws->avg_code = w.avg_code; ws->avg_letters = w.avg_letters;
   if (FQ_LANE == 0) {
     for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
 #ifdef FQSX_TIMING
@@ -3024,6 +3181,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
   w.err = 0;
   w.piped = false;
   w.lqh = false;
+  w.rcq = false;
   w.scout = false;
   w.sb = &sm->sb[0];
   w.cq_head = w.cq_tail = 0;
@@ -3049,7 +3207,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
     w.rec = rec;
     w.rdp = sm->rd[idx & 1];
     FQ_SYNC();
-    if (FQ_LANE == 0) { rec->n_raw = 0; rec->n_p = 0; }
+    if (FQ_LANE == 0) { rec->idx = ~0u; rec->n_raw = 0; rec->n_p = 0; }
     FQ_SYNC();
     const u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
     const u8 *prev = nullptr;
@@ -3069,6 +3227,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
       rec->kdir[0] = w.pm.dir; rec->krc[0] = w.pm.rc; rec->kcur[0] = w.pm.cur;
       rec->kdir[1] = w.sm_.dir; rec->krc[1] = w.sm_.rc; rec->kcur[1] = w.sm_.cur;
       rec->kdir[2] = w.bm.dir; rec->krc[2] = w.bm.rc; rec->kcur[2] = w.bm.cur;
+      rec->idx = idx;
     }
     FQ_SYNC();
     lds_store_rel(&sm->hd_ready, idx + 1);
@@ -3098,6 +3257,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
   w.ws = ws;
   w.err = 0;
   w.piped = false;
+  w.rcq = false;
   w.lqh = true;    // (reads the inserter wave's progress)
   w.rec = nullptr;
   w.scout = false;
@@ -3114,46 +3274,97 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
   if (stop > last) stop = last;
   u32 made = 0;
   bool quit = false;
-  for (u64 i = cur; i < stop && !quit; ++i) {
-    const u32 idx = (u32)(i - cur);
+  w.sc_epoch = 0;
+  const u32 n_seg = (u32)(stop > cur ? stop - cur : 0);
+  u32 idx = 0;          // read the wave is working on (index within the launch)
+  bool restart = false; // a request of the resolving wave is to be taken up (sc_req)
+  while (!quit) {
     u32 spins = 0;
-    while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
+    u32 base_pos = cfg.pmer;   // the k-mers in w stand before this position of the read
+    if (idx >= n_seg && !restart) {
+      // every read has its chunks; stay until the resolving wave has finished the last read (it may still ask for a restart)
+      if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; continue; }
+      if ((i32)(lds_load_acq(&sm->hd_taken) - n_seg) >= 0 || lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_skip) >= n_seg) break;
       fq_sleep();
-      if (lds_load_acq(&sm->cq_done) || ++spins > (1u << 23)) { quit = true; break; }
+      continue;
     }
-    if (quit) break;
+    if (!restart) {
+      TM_BEGIN(t_w1);
+      while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
+        if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
+        fq_sleep();
+        if (lds_load_acq(&sm->cq_done) || ++spins > (1u << 23)) { quit = true; break; }
+      }
+      TM_END(w, TM_SCOUT_WAIT, t_w1);
+      if (quit) break;
+    }
+    if (!restart && lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) restart = true;
+    if (restart) {   // go back to the read the request names, to the exact state it carries
+      restart = false;
+      w.sc_epoch = lds_load_acq(&sm->sc_req_seq);
+      const WgShared::ScoutReq &q = sm->sc_req;
+      idx = uniform32(q.read);
+      base_pos = uniform32(q.i0);
+      Kmer *k[6] = {&w.pm, &w.sm_, &w.bm, &w.pm_u, &w.sm_u, &w.bm_u};
+      for (u32 x = 0; x < 6; ++x) { k[x]->dir = uniform64(q.kdir[x]); k[x]->rc = uniform64(q.krc[x]); k[x]->cur = uniform32(q.kcur[x]); }
+      w.cor_pos = uniform32(q.cor_pos);
+      w.N_run = uniform32(q.n_run);
+      for (u32 x = 0; x < 4; ++x) w.s_let[x] = uniform64(q.s_let[x]);
+      if (idx >= n_seg) break;   // (cannot happen)
+      // The records of this read and the next one are still in place while the resolving wave is inside this read
+      // (hd_taken); from now on this wave's own progress word protects them again.
+      FQ_SYNC();
+      lds_store_rel(&sm->sc_hd_taken, idx);
+    }
     const HeadRec *rec = &sm->hd[idx & 1];
-    if (!rec->same) {
-      const u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
+    const bool rec_same = uniform32(rec->same) != 0;   // (wave-uniform values: kept in scalar registers)
+    const u32 hist[4] = {uniform32(rec->hist[0]), uniform32(rec->hist[1]), uniform32(rec->hist[2]), uniform32(rec->hist[3])};
+    const u64 hk_dir[3] = {uniform64(rec->kdir[0]), uniform64(rec->kdir[1]), uniform64(rec->kdir[2])};
+    const u64 hk_rc[3] = {uniform64(rec->krc[0]), uniform64(rec->krc[1]), uniform64(rec->krc[2])};
+    const u32 hk_cur[3] = {uniform32(rec->kcur[0]), uniform32(rec->kcur[1]), uniform32(rec->kcur[2])}, h_nrun = uniform32(rec->n_run);
+    FQ_SYNC();
+    if (uniform32(rec->idx) != idx) {   // the record has been reused: this wave took up a request after the resolving wave had left the read
+      lds_store_rel(&sm->sc_dead, 1u);
+      lds_store_rel(&sm->sc_hd_taken, 0x7fffffffu);   // (the read-head wave no longer waits for this one)
+      break;
+    }
+    if (!rec_same) {
+      const u64 ri = cur + idx;
+      const u64 o0 = cfg.read_off[ri], o1 = cfg.read_off[ri + 1];
       const u8 *p = cfg.bases + o0;
       const u32 size = (u32)(o1 - o0);
       w.rdp = sm->rd[idx & 1];
-      w.pm.dir = rec->kdir[0]; w.pm.rc = rec->krc[0]; w.pm.cur = rec->kcur[0];
-      w.sm_.dir = rec->kdir[1]; w.sm_.rc = rec->krc[1]; w.sm_.cur = rec->kcur[1];
-      w.bm.dir = rec->kdir[2]; w.bm.rc = rec->krc[2]; w.bm.cur = rec->kcur[2];
-      w.pm_u = w.pm; w.sm_u = w.sm_; w.bm_u = w.bm;
-      w.cor_pos = 0;
-      w.N_run = rec->n_run;
+      if (base_pos == cfg.pmer) {   // from the head of the read
+        w.pm.dir = hk_dir[0]; w.pm.rc = hk_rc[0]; w.pm.cur = hk_cur[0];
+        w.sm_.dir = hk_dir[1]; w.sm_.rc = hk_rc[1]; w.sm_.cur = hk_cur[1];
+        w.bm.dir = hk_dir[2]; w.bm.rc = hk_rc[2]; w.bm.cur = hk_cur[2];
+        w.pm_u = w.pm; w.sm_u = w.sm_; w.bm_u = w.bm;
+        w.cor_pos = 0;
+        w.N_run = h_nrun;
+      }
       w.sc_read = idx;
-      const u32 hist[4] = {rec->hist[0], rec->hist[1], rec->hist[2], rec->hist[3]};
-      for (u32 i0 = cfg.pmer; i0 < size && !quit; i0 += FQSX_SPEC) {
+      for (u32 i0 = base_pos; i0 < size && !quit && !restart; i0 += FQSX_SPEC) {
         spins = 0;
+        TM_BEGIN(t_w2);
         while (made - lds_load_acq(&sm->sc_taken) >= FQSX_SCR) {   // every ring buffer holds an unreleased chunk
           if (lds_load_acq(&sm->sc_skip) > idx) break;   // nobody will take further chunks of this read (the ring is drained at the next read that uses the scout)
+          if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
           fq_sleep();
           if (lds_load_acq(&sm->cq_done) || ++spins > (1u << 23)) { quit = true; break; }
         }
-        if (quit || lds_load_acq(&sm->sc_skip) > idx) break;
+        TM_END(w, TM_SCOUT_WAIT, t_w2);
+        if (!restart && lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) restart = true;
+        if (quit || restart || lds_load_acq(&sm->sc_skip) > idx) break;
         const u32 n = size - i0 < FQSX_SPEC ? size - i0 : FQSX_SPEC;
         w.sb = &sm->sb[1 + made % FQSX_SCR];
-        speculate(w, p, size, i0, n, false, i0 - cfg.pmer);
+        speculate(w, p, size, i0, n, false, i0 - base_pos);
 #if FQ_WAVE > 1
-        if (i0 == cfg.pmer) scout_early(w, n);
+        if (i0 == base_pos) scout_early(w, n);   // (the look-ups of positions whose b-mer is still partial, if any)
         const u32 front0 = scout_rough_first(w, n);
 #else
         const u32 front0 = FQSX_SPEC;
 #endif
-        if (FQ_LANE == 0) { w.sb->h_read = idx; w.sb->h_i0 = i0; w.sb->h_n = n; w.sb->rr_front = front0; }
+        if (FQ_LANE == 0) { w.sb->h_read = idx; w.sb->h_i0 = i0; w.sb->h_n = n; w.sb->h_epoch = w.sc_epoch; w.sb->rr_front = front0; }
         FQ_SYNC();
         made += 1;
         lds_store_rel(&sm->sc_ready, made);   // the resolving wave may start on the chunk ...
@@ -3161,11 +3372,16 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         scout_rough(w, n);                     // ... while its sweeps are still being probed (rr_front)
 #endif
       }
+      if (restart) continue;
       add_s_letters(w, hist);
     }
     FQ_SYNC();
     lds_store_rel(&sm->sc_hd_taken, idx + 1);
+    ++idx;
   }
+#ifdef FQSX_TIMING
+  if (FQ_LANE == 0 && w.tm[TM_SCOUT_WAIT]) atomic_add64(&ws->stat[16 + TM_SCOUT_WAIT], w.tm[TM_SCOUT_WAIT]);
+#endif
   TM_STAMP(cfg, tid, launch, 4);
 }
 
@@ -3183,6 +3399,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.ws = ws;
   w.err = 0;
   w.piped = piped;
+  w.rcq = false;
   w.lqh = piped;
   w.rec = nullptr;
   w.rdp = sm->rd[0];
@@ -3191,6 +3408,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.scout = heads;
   w.sc_abandoned = false;
   w.sc_read = 0;
+  w.sc_epoch = 0;
   w.sc_taken = 0;
   w.cq_head = w.cq_tail = 0;
   w.c_r_sym = 0;

@@ -1,10 +1,12 @@
 // fqsx_k_se.hip -- the single-end encode kernels.
 //
-// One workgroup = one logical worker.  Sorted order (dna_mode 1, the benchmark's mode): five wavefronts with fixed
-// roles -- wave 0 prepares the head of the next read (duplicate test, p-mer prefix), wave 1 resolves the worker's reads
-// (k-mer tables, counts, corrections, mailboxes) and queues every symbol in LDS, wave 2 codes them (context models +
-// range coder), wave 3 runs stage P (k-mer rolling and table probes, one position per lane) of the chunks ahead,
-// wave 4 applies the worker's local-table inserts.  Original order (dna_mode 0): resolve, coder, inserter.
+// One workgroup = one logical worker.  Sorted order (dna_mode 1, the benchmark's mode): six wavefronts with fixed
+// roles -- read head (duplicate test, p-mer prefix of the next read), scout (stage P: k-mer rolling and table probes,
+// one position per lane, of the chunks ahead), resolve (k-mer tables, counts, corrections, mailboxes; queues every
+// symbol in LDS), models (context search, model statistics, level averages), range coder (the sequential coding step
+// and the output bytes), inserter (the worker's local-table inserts).  The two busiest roles, resolve and models, have
+// a SIMD to themselves (waves 2 and 3); head + range coder share SIMD 0, scout + inserter SIMD 1.
+// Original order (dna_mode 0): resolve, coder (models + range coder), inserter.
 // Every role is a function of its own (FQ_ROLE): own register allocation, own stretch of code.
 #include "fqsx_kernels.h"
 
@@ -12,9 +14,13 @@ template <int MODE> FQ_ROLE void role_resolve(FqArgsP ap) {
   const EncArgs *a = fq_args(ap);
   encode_segment_body<MODE, false, true>(a->cfg, fq_wg(), FQ_BLOCK, a->n_reads, a->S, a->seg, a->pad);
 }
-FQ_ROLE void role_coder(FqArgsP ap) {
+template <bool SPLIT> FQ_ROLE void role_coder(FqArgsP ap) {
   const EncArgs *a = fq_args(ap);
-  coder_segment_body(a->cfg, fq_wg(), FQ_BLOCK, a->seg, a->pad);
+  coder_segment_body<SPLIT>(a->cfg, fq_wg(), FQ_BLOCK, a->seg, a->pad);
+}
+FQ_ROLE void role_rc(FqArgsP ap) {
+  const EncArgs *a = fq_args(ap);
+  rc_segment_body(a->cfg, fq_wg(), FQ_BLOCK, a->seg, a->pad);
 }
 FQ_ROLE void role_inserter(FqArgsP ap) {
   const EncArgs *a = fq_args(ap);
@@ -36,29 +42,30 @@ FQ_DEV void wg_handoff_init() {   // the one workgroup barrier of the kernel: th
     sm->cq_tail = 0; sm->cq_head = 0; sm->cq_done = 0;
     sm->lq_target[0] = sm->lq_target[1] = 0; sm->lq_done[0] = sm->lq_done[1] = 0; sm->lq_quit = 0;
     sm->hd_ready = 0; sm->hd_taken = 0;
-    sm->sc_ready = 0; sm->sc_taken = 0; sm->sc_skip = 0; sm->sc_hd_taken = 0;
+    sm->sc_ready = 0; sm->sc_taken = 0; sm->sc_skip = 0; sm->sc_hd_taken = 0; sm->sc_req_seq = 0; sm->sc_dead = 0;
+    sm->rq_tail = 0; sm->rq_head = 0; sm->rq_done = 0;
   }
   FQ_WG_BARRIER();
 }
-FQ_KERNEL320 void k_encode_se_sorted(EncArgs a) {
+FQ_KERNEL384 void k_encode_se_sorted(EncArgs a) {
   (void)a;
   wg_handoff_init();
-  // (waves 0 and 4 land on the same SIMD: the two least busy roles share it)
-  if (FQ_WAVE_ID == 1) role_resolve<1>(fq_kernarg());
-  else if (FQ_WAVE_ID == 2) role_coder(fq_kernarg());
-  else if (FQ_WAVE_ID == 4) role_inserter(fq_kernarg());
+  if (FQ_WAVE_ID == 2) role_resolve<1>(fq_kernarg());
+  else if (FQ_WAVE_ID == 3) role_coder<true>(fq_kernarg());
+  else if (FQ_WAVE_ID == 1) role_scout(fq_kernarg());
   else if (FQ_WAVE_ID == 0) role_head(fq_kernarg());
-  else role_scout(fq_kernarg());
+  else if (FQ_WAVE_ID == 4) role_rc(fq_kernarg());
+  else role_inserter(fq_kernarg());
 }
 FQ_KERNEL192 void k_encode_se_orig(EncArgs a) {
   (void)a;
   wg_handoff_init();
   if (FQ_WAVE_ID == 0) role_resolve<0>(fq_kernarg());
-  else if (FQ_WAVE_ID == 1) role_coder(fq_kernarg());
+  else if (FQ_WAVE_ID == 1) role_coder<false>(fq_kernarg());
   else role_inserter(fq_kernarg());
 }
 int fqsx_launch_encode_se(hipStream_t s, const EncArgs &a) {
-  if (a.cfg.mode == 1) hipLaunchKernelGGL(k_encode_se_sorted, dim3(a.cfg.T), dim3(320), 0, s, a);
+  if (a.cfg.mode == 1) hipLaunchKernelGGL(k_encode_se_sorted, dim3(a.cfg.T), dim3(384), 0, s, a);
   else hipLaunchKernelGGL(k_encode_se_orig, dim3(a.cfg.T), dim3(192), 0, s, a);
   return (int)hipGetLastError();
 }

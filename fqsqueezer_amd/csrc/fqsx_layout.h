@@ -128,7 +128,8 @@ enum {
 // section timers (only maintained by -DFQSX_TIMING builds)
 enum { TM_TOTAL = 0, TM_SPEC, TM_FAST, TM_SLOW, TM_POST, TM_READ_HEAD, TM_LQ, TM_ROUGH, TM_REPM, TM_FINDC,
        CN_FAST, CN_SLOW, CN_CHUNK, CN_DIRTY, CN_ROUGH, CN_REPM,
-       CN_EXT, CN_GENERIC, CN_LQFLUSH, CN_CONFLICT, CN_LQSTALE, CN_EARLY, CN_P2, TM_P2, TM_SCODE, TM_SPOST, TM_SPRE,
+       CN_EXT, CN_GENERIC, CN_LQFLUSH, CN_CONFLICT, TM_CQWAIT /* resolver waiting for coding-queue space */, CN_EARLY, CN_P2, TM_P2,
+       TM_CODER_IDLE /* coder wave: queue empty */, TM_SCOUT_WAIT /* scout wave: ring full or no read head yet */, TM_SPRE,
        TM_CR_S, TM_CR_MID, TM_CR_AVG, TM_CR_RC, TM_KEYS, TM_N };
 
 struct DevCfg {

@@ -28,21 +28,31 @@ c._lib.fqsx_dna_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 c._lib.fqsx_dna_trace.restype = C.c_int
 buf = np.zeros((4096, T, 8), dtype=np.uint64)
 n = c._lib.fqsx_dna_trace(c._h, buf.ctypes.data, 4096)
+names = ["head", "resolve", "models", "scout", "inserter", "range coder"]
+slots = [1, 2, 3, 4, 5, 7]   # (slot 6: resolving wave, reads done)
+
+
+def report(tr, tag):
+    n = len(tr)
+    start = tr[:, :, 0].min(axis=1, keepdims=True)          # launch start = earliest resolve start
+    ends = (tr[:, :, slots] - start[:, :, None]) * 0.01      # us
+    ends[tr[:, :, slots] == 0] = 0
+    launch_len = ends.max(axis=(1, 2))
+    wend = ends.max(axis=2)                                  # per worker: its last role's end
+    last_worker = wend.argmax(axis=1)
+    last_role = np.array([ends[i, last_worker[i]].argmax() for i in range(n)])
+    res = {"launches": tag, "n": int(n), "mean_launch_us": float(launch_len.mean()), "mean_worker_end_us": float(wend.mean()),
+           "mean_worker_over_launch": float((wend.mean(axis=1) / launch_len).mean()),
+           "last_role_histogram": {names[k]: int((last_role == k).sum()) for k in range(len(names))},
+           "mean_end_us_by_role": {names[k]: round(float(ends[:, :, k].mean()), 1) for k in range(len(names))},
+           "slowest_worker_end_us_by_role": {names[k]: round(float(np.mean([ends[i, last_worker[i], k] for i in range(n)])), 1) for k in range(len(names))},
+           "resolve_reads_done_us_mean": round(float(((tr[:, :, 6] - start) * 0.01).mean()), 1),
+           "p50_p90_p99_launch_us": [round(float(np.percentile(launch_len, q)), 1) for q in (50, 90, 99)]}
+    print(json.dumps(res))
+
+
 tr = buf[:n].astype(np.int64)
-start = tr[:, :, 0].min(axis=1, keepdims=True)          # launch start = earliest resolve start
-names = ["head", "resolve", "coder", "scout", "inserter"]
-ends = (tr[:, :, 1:6] - start[:, :, None]) * 0.01        # us
-ends[tr[:, :, 1:6] == 0] = 0
-launch_len = ends.max(axis=(1, 2))
-last_worker = ends.max(axis=2).argmax(axis=1)
-last_role = np.array([ends[i, last_worker[i]].argmax() for i in range(n)])
-wend = ends.max(axis=2)                                  # per worker: its last role's end
-res = {"launches": int(n), "mean_launch_us": float(launch_len.mean()), "mean_worker_end_us": float(wend.mean()),
-       "mean_worker_over_launch": float((wend.mean(axis=1) / launch_len).mean()),
-       "last_role_histogram": {names[k]: int((last_role == k).sum()) for k in range(5)},
-       "mean_end_us_by_role": {names[k]: float(ends[:, :, k].mean()) for k in range(5)},
-       "slowest_worker_end_us_by_role": {names[k]: float(np.mean([ends[i, last_worker[i], k] for i in range(n)])) for k in range(5)},
-       "resolve_reads_done_us_mean": float(((tr[:, :, 6] - start) * 0.01).mean()),
-       "p50_p90_p99_launch_us": [float(np.percentile(launch_len, q)) for q in (50, 90, 99)]}
-# the 2-read warm-up launches only (blocks 0..69 have 30 launches each)
-print(json.dumps(res))
+report(tr[:min(n, 2100)], "blocks 0..69 (two reads per worker and launch)")
+if nblk > 110 and n > 2100:
+    k = nblk - 100
+    report(tr[n - k:], "blocks >= 100 (one launch per block)")

@@ -22,19 +22,29 @@ c = DnaCodec(header, lib_path=lib)
 c.set_profiling(True)
 t0 = time.time()
 n_done = 0
+st_mid = None
 for g, idx in enumerate(blocks[:max_blocks]):
+    if g == 100:
+        st_mid, kt_mid, n_mid, t_mid = c.stats(), c.kernel_times(), n_done, time.time()
     bases, off = hp.block_arrays(rec, idx)
     c.encode_block(bases, off, g)
     n_done += len(idx)
 n = n_done
 dt = time.time() - t0
 st = c.stats(); kt = c.kernel_times()
+if st_mid is not None and len(sys.argv) > 6 and sys.argv[6] == "steady":   # report blocks >= 100 only
+    st = {k: ([a - b for a, b in zip(v, st_mid[k])] if isinstance(v, list) else v - st_mid[k]) for k, v in st.items()}
+    kt = {k: v - kt_mid[k] for k, v in kt.items()}
+    n -= n_mid
+    dt = time.time() - t_mid
+    print("blocks >= 100 only:")
 names = ["total", "spec", "fast", "slow", "post_q", "read_head", "lq_flush", "rough", "repair_missing", "find_counts"]
-cn = dict(zip(["n_fast", "n_slow", "n_chunk", "n_dirty", "n_rough", "n_repm", "n_ext", "n_generic", "n_lqflush", "n_conflict", "n_lqstale", "n_early", "n_p2"], st["timers"][10:23]))
+cn = dict(zip(["n_fast", "n_slow", "n_chunk", "n_dirty", "n_rough", "n_repm", "n_ext", "n_generic", "n_lqflush", "n_conflict", "_cqwait", "n_early", "n_p2"], st["timers"][10:23]))
+cn["resolver: waiting for coding-queue space s"] = cn.pop("_cqwait") * 1e-8
 cn["coder wave: launch start to last symbol s"] = st["timers"][23] * 1e-8  # vs "total" = the resolving wave's
 cn["slow: resolve counts s"] = st["timers"][26] * 1e-8
-cn["slow: keys+search+encode s"] = st["timers"][24] * 1e-8
-cn["slow: pushes+repairs s"] = st["timers"][25] * 1e-8
+cn["coder wave: idle (queue empty) s"] = st["timers"][24] * 1e-8
+cn["scout wave: waiting (ring full / no head) s"] = st["timers"][25] * 1e-8
 for k, nm in enumerate(["code_run: S probes s", "code_run: same-slot+validate s", "code_run: avg loop s", "code_run: commit+rc s", "code_keys s"]):
     cn[nm] = st["timers"][27 + k] * 1e-8
 tm = [x * 1e-8 for x in st["timers"][:10]]
