@@ -223,6 +223,17 @@ struct fqsx_dna {
   std::vector<u8> h_out;
   std::vector<u64> h_lens;
   std::vector<void *> allocs;
+  // the block being processed (block_prepare -> block_segment ... -> block_finish)
+  u32 cur_n_reads, cur_S, cur_gen;
+  u64 cur_need_lb, cur_need_ls, cur_need_lpe;
+  bool cur_decode;
+  // sharded mode (fqsx_shard_*): exchange scratch
+  u32 shard_rank, shard_world;
+  u8 *d_vmap;
+  u64 *d_xbuf;        // received entries / upsert items
+  u64 xbuf_cap;
+  u32 *d_cglob;       // [3][T][T] the all-reduced count matrix of the phase
+  u64 siv_before[2];
 };
 
 namespace {
@@ -463,10 +474,9 @@ int launch_segment(fqsx_dna *c, bool decode, u32 n_reads, u32 S, u32 seg) {
   return FQSX_OK;
 }
 
-// decode: dec_streams/dec_lens (host) are the T input streams, bases_out (host) receives the block
-int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u64 *h_off, u32 n_reads, u32 generation,
-                      const u8 **streams, u64 *lens, const u8 *const *dec_streams = nullptr, const u64 *dec_lens = nullptr,
-                      u8 *bases_out = nullptr) {
+// Sizes the per-block buffers and fixes the block's schedule (number of synchronisation points S)
+int block_prepare(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u64 *h_off, u32 n_reads, u32 generation,
+                  const u8 *const *dec_streams = nullptr, const u64 *dec_lens = nullptr) {
   const bool decode = dec_streams != nullptr;
   const u32 T = c->T;
   DevCfg &cfg = c->cfg;
@@ -596,7 +606,28 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
 #endif
   }
 
-  for (u32 seg = 0; seg <= (u32)S; ++seg) {
+  c->cur_n_reads = n_reads; c->cur_S = (u32)S; c->cur_gen = generation;
+  c->cur_need_lb = need_lb; c->cur_need_ls = need_ls; c->cur_need_lpe = need_lpe;
+  c->cur_decode = decode;
+  return FQSX_OK;
+}
+
+// ClearKmersToHT, dna.cpp:2475-2488 (mailbox counters are rewritten by the next encode launch)
+int clear_local_tables(fqsx_dna *c) {
+  const u64 words = (c->cur_need_lb + c->cur_need_ls) * c->T;
+  const u32 grid = (u32)std::min<u64>(2048, (words + 4095) / 4096 + 1);
+  LAUNCH(c, 2, k_clear_local, grid, 64, c->cfg, c->cur_need_lb * c->T, c->cur_need_ls * c->T);
+  return FQSX_OK;
+}
+
+// One synchronisation segment on one GPU: encode launch, mailbox partition, growth decision, insert phase, clear
+int block_segment(fqsx_dna *c, u32 seg) {
+  const u32 T = c->T, n_reads = c->cur_n_reads;
+  const u64 S = c->cur_S, need_lpe = c->cur_need_lpe;
+  const bool decode = c->cur_decode;
+  DevCfg &cfg = c->cfg;
+  int rc;
+  {
     if ((rc = launch_segment(c, decode, n_reads, (u32)S, seg))) return rc;
     // size the global tables for this phase's inserts (exact per-owner demand)
     const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
@@ -629,13 +660,17 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
     }
     LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg);
     LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg);
-    // ClearKmersToHT, dna.cpp:2475-2488 (mailbox counters are rewritten by the next encode launch)
-    {
-      const u64 words = (need_lb + need_ls) * T;
-      const u32 grid = (u32)std::min<u64>(2048, (words + 4095) / 4096 + 1);
-      LAUNCH(c, 2, k_clear_local, grid, 64, cfg, need_lb * T, need_ls * T);
-    }
+    if ((rc = clear_local_tables(c))) return rc;
   }
+  return FQSX_OK;
+}
+
+int block_finish(fqsx_dna *c, const u64 *h_off, const u8 **streams, u64 *lens, u8 *bases_out) {
+  const u32 T = c->T, n_reads = c->cur_n_reads, generation = c->cur_gen;
+  const bool decode = c->cur_decode;
+  DevCfg &cfg = c->cfg;
+  int rc;
+  void *p = nullptr;
   if (decode) {
     u32 derr = 0;
     if ((rc = d2h_sync(c, &derr, cfg.err, sizeof(u32)))) return rc;
@@ -677,6 +712,17 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
   return FQSX_OK;
 }
 
+// decode: dec_streams/dec_lens (host) are the T input streams, bases_out (host) receives the block
+int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u64 *h_off, u32 n_reads, u32 generation,
+                      const u8 **streams, u64 *lens, const u8 *const *dec_streams = nullptr, const u64 *dec_lens = nullptr,
+                      u8 *bases_out = nullptr) {
+  if (c->shard_world > 1) { g_err = "a sharded codec is driven through fqsx_shard_* (fqsqueezer_amd/sharded.py)"; return FQSX_E_ARG; }
+  int rc = block_prepare(c, d_bases, d_off, h_off, n_reads, generation, dec_streams, dec_lens);
+  for (u32 seg = 0; !rc && seg <= c->cur_S; ++seg) rc = block_segment(c, seg);
+  if (!rc) rc = block_finish(c, h_off, streams, lens, bases_out);
+  return rc;
+}
+
 int create_impl(fqsx_dna *c, const u8 *h) {
   const u32 T = c->T;
   DevCfg &cfg = c->cfg;
@@ -687,6 +733,7 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   cfg.gp = make_geom(cfg.pmer); cfg.gs = make_geom(cfg.smer); cfg.gb = make_geom(cfg.bmer);
   cfg.pmer_mod_shift = 2 * cfg.pmer - 12;          // dna.cpp:2381
   cfg.T_magic = ((1ull << 32) + T - 1) / T;
+  cfg.T_pow2 = (T & (T - 1)) == 0 ? 1u : 0u;
   cfg.ps_nobytes_n = (2 * cfg.pmer + 7) / 8;       // dna.cpp:130
   int rc;
   void *p = nullptr;
@@ -776,6 +823,18 @@ int create_impl(fqsx_dna *c, const u8 *h) {
     if ((rc = dalloc(c, &p, (u64)T * sizeof(u32), true))) return rc;
     cfg.pe_n = (u32 *)p;
   }
+  {  // group order of the partitioned mailboxes: by owner (one GPU)
+    u8 ident[256];
+    for (u32 i = 0; i < 256; ++i) ident[i] = (u8)i;
+    if ((rc = dalloc(c, &p, 256, false))) return rc;
+    c->d_vmap = (u8 *)p;
+    cfg.vmap = c->d_vmap;
+    if ((rc = h2d(c, c->d_vmap, ident, 256))) return rc;
+#ifndef FQSX_EMU
+    HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  }
+  cfg.shard_rank = 0; cfg.shard_world = 1; cfg.shard_cnt = nullptr;
   if ((rc = dalloc(c, &p, sizeof(u32) * 4, true))) return rc;
   cfg.err = (u32 *)p;
 #ifdef FQSX_TIMING
@@ -834,6 +893,11 @@ int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) {
   c->d_compact = nullptr;
   c->compact_cap = 0;
   c->din_cap = c->dout_cap = 0;
+  c->shard_rank = 0; c->shard_world = 1;
+  c->d_vmap = nullptr; c->d_xbuf = nullptr; c->xbuf_cap = 0; c->d_cglob = nullptr;
+  c->cur_n_reads = c->cur_S = c->cur_gen = 0;
+  c->cur_need_lb = c->cur_need_ls = c->cur_need_lpe = 0;
+  c->cur_decode = false;
 #ifndef FQSX_EMU
   HIPCHK(hipStreamCreate(&c->stream));
   HIPCHK(hipEventCreate(&c->ev0));

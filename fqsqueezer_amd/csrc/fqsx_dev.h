@@ -9,14 +9,16 @@
 // ---------------------------------------------------------------------------------------
 // workgroup-shared (LDS) state of one worker
 #define FQSX_RR 6u
-#define FQSX_SW 4u    // Hamming-1 sweeps the scout wave keeps in flight (one probe of each per lane)
-#define FQSX_SCR 3u   // scout ring: chunks the scout wave may be ahead of their release
+#define FQSX_SW 4u    // Hamming-1 sweeps a scout wave keeps in flight (one probe of each per lane)
+#define FQSX_SCR 3u   // scout ring: chunks the scout waves may be ahead of their release
+#define FQSX_NSC 2u   // scout waves of a worker: chunk number c of an epoch is made by scout c % FQSX_NSC, in ring slot c % FQSX_SCR
 #define FQSX_RQ 256u  // entries of the range-coder queue (power of two)
 // One stage-P chunk: everything about positions i0..i0+n-1 of a read that does not depend on the adaptive models,
 // computed one position per lane under the assumption "no k-mer correction since the k-mers stage P started from".
 struct SpecBuf {
   u32 h_read, h_i0, h_n;       // scout chunks: read index within the launch, first position, positions
-  u32 h_epoch;                 // ... and the restart epoch of the k-mer state they were rolled from (see ScoutReq)
+  u32 h_epoch;                 // ... the restart epoch of the k-mer state they were rolled from (see ScoutReq) ...
+  u32 h_pub;                   // ... and, stored last (release), the chunk's sequence number within the epoch + 1
   u32 h_pq_lo[2];              // list entries (b, s) below these were in the local tables when the chunk's probes started
   u32 h_np, h_nlp;             // probes issued (global, local) ...
   u64 h_ns, h_nls;             // ... and slots scanned, accounted when the chunk is used
@@ -88,16 +90,17 @@ struct WgShared {
       u64 pe_bk[3][64];        // paired-end insert batch (key, value, weight)
     };
   };
-  u32 sc_ready, sc_taken;      // scout chunks published / released (free-running); chunk c lives in sb[1 + c % FQSX_SCR]
-  u32 sc_skip;                 // reads below this index (within the launch) need no further scout chunks
-  u32 sc_hd_taken;             // read heads the scout wave is done with
-  // Restart of the scout wave after a k-mer correction: the resolving wave posts the exact state after the chunk it
-  // has just committed (sc_req, then sc_req_seq = the new epoch); the scout wave drops what it is doing, goes back
-  // to that read and rolls the rest of it from the posted state.  Chunks carry the epoch they were made under.
+  u32 sc_taken;                // chunks of the current epoch the resolving wave has released; chunk c lives in sb[1 + c % FQSX_SCR]
+  u32 sc_hd_taken[FQSX_NSC];   // read heads each scout wave is done with
+  // Restart of the scout waves: the resolving wave posts the exact state to go on from (sc_req, then sc_req_seq = the
+  // new epoch) -- after a k-mer correction the state after the chunk it has just committed, after a read it finished
+  // on its own the head of the next read.  Every scout wave drops what it is doing, acknowledges (sc_ack) and, once
+  // all have, rolls on from the posted state; chunk numbers start again at 0 in every epoch.
   u32 sc_req_seq;
-  u32 sc_dead;                 // the scout wave has given up for this launch (it found itself behind the resolving wave)
+  u32 sc_ack[FQSX_NSC];
+  u32 sc_dead;                 // the scout waves have given up for this launch (one found itself behind the resolving wave)
   struct ScoutReq {
-    u32 read, i0, cor_pos, n_run;
+    u32 read, i0, cor_pos, n_run;   // i0 == pmer: from the head of the read (its record), the k-mers below are unused
     u64 kdir[6], krc[6];
     u32 kcur[6];
     u64 s_let[4];
@@ -200,10 +203,10 @@ struct Wk {
   u8 *rdp;                              // LDS staging buffer of the current read's codes
   SpecBuf *sb;                          // stage-P chunk in use
   bool scout;                           // stage P of clean chunks comes from the scout wave
-  bool sc_abandoned;                    // ... but no longer for the current read (a k-mer correction happened)
+  bool sc_abandoned;                    // ... but no longer for the current read (the wave went on without them)
   u32 sc_read;                          // index of the current read within the launch
   u32 sc_epoch;                         // restart epoch this wave is in (resolving wave: the one it expects chunks of)
-  u32 sc_taken;                         // scout chunks released so far
+  u32 sc_taken;                         // scout chunks of the current epoch released so far
   HeadRec *rec;                         // read-head wave: where the head's output goes (null: code / push directly)
   bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
   u32 cq_tail, cq_head;                 // this wave's copy of its own queue index
@@ -391,15 +394,26 @@ FQ_DEV bool km_almost_full(const Kmer &k, const KGeom &g, u32 margin) { return k
 // ---------------------------------------------------------------------------------------
 // k-mer tables
 FQ_DEV u32 mod_T(const DevCfg *cfg, u32 x) {  // x % T for x < 2^14, T <= 255 (exact: x*T < 2^32)
+  if (cfg->T_pow2) return x & (cfg->T - 1);    // (wave-uniform branch: the reference CLI's usual -t 8 / 16 / 32 / 64)
   u32 q = (u32)(((u64)x * cfg->T_magic) >> 32);
   return x - q * cfg->T;
 }
 FQ_DEV u32 sb_owner(const DevCfg *cfg, u64 kmer_norm) { return mod_T(cfg, (u32)((kmer_norm >> 46) & 0x3fffull)); }  // dna.cpp:825
 FQ_DEV u32 p_owner(const DevCfg *cfg, u64 idx) { return mod_T(cfg, (u32)(idx >> cfg->pmer_mod_shift)); }           // dna.cpp:658
 
+// Home slot of a k-mer = hash of its kernel (symbols 2..k-3, <= 46 bits).  The layout is this repo's own (results do
+// not depend on it), so the hash is picked for the GPU: a 32-bit finaliser (two 32-bit multiplies) instead of the
+// 64-bit murmur finaliser (two 64-bit multiplies = a dozen quarter-rate operations per probe).
+FQ_DEV u32 kmer_mix(u64 kern) {
+  u32 x = (u32)kern ^ ((u32)(kern >> 32) * 0x9E3779B1u);
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
 FQ_DEV u64 tab_home(const KTab &t, u64 v) {
   u64 kern = (v >> 4) & ((1ull << (2 * t.k - 8)) - 1ull);
-  return murmur64(kern) & t.cap_mask;
+  return (u64)kmer_mix(kern) & t.cap_mask;
 }
 // one cluster scan: counts of the 4 sibling k-mers (_update_counts_full, ht_kmer.h:205-263), in two parts so that a
 // caller can have the first round trips of several independent scans in flight at once: tab_first issues the loads
@@ -1562,7 +1576,7 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
   const u32 pi = lane / 3, r3 = lane - 3 * pi;
   const u32 shd = 62 - 2 * pi, shr = 64 - 2 * g.k + 2 * pi;
   while (cm) {
-    if (lds_load_acq(&w.sm->sc_skip) > w.sc_read || lds_load_acq(&w.sm->sc_req_seq) != w.sc_epoch) break;   // nobody will look at this chunk any more
+    if (lds_load_acq(&w.sm->sc_req_seq) != w.sc_epoch) break;   // nobody will look at this chunk any more
     u32 js[FQSX_SW];
     bool ok[FQSX_SW];
 #pragma unroll
@@ -2548,48 +2562,43 @@ FQ_DEV u64 quiet_miss_mask(Wk &w, u32 n) {
 }
 #endif
 
-// hand-over of the scout wave's stage-P chunks (see scout_segment_body)
+// hand-over of the scout waves' stage-P chunks (see scout_segment_body)
 FQ_DEV void scout_release(Wk &w) {
   w.sc_taken += 1;
   FQ_SYNC();
   lds_store_rel(&w.sm->sc_taken, w.sc_taken);
 }
-FQ_DEV bool scout_take(Wk &w, u32 i, u32 n) {
+// The scout waves start again: from the exact state before position i0 of read `read` (a k-mer correction), or, with
+// i0 == pmer, from the head of that read (the resolving wave has finished the read before on its own)
+FQ_DEV void scout_restart(Wk &w, u32 read, u32 i0, const u64 s_let[4]) {
   WgShared *sm = w.sm;
-  for (;;) {
-    u32 spins = 0;
-    while (lds_load_acq(&sm->sc_ready) == w.sc_taken) {
-      fq_sleep();
-      if (lds_load_acq(&sm->sc_dead) || ++spins > (1u << 22)) {   // never spin forever on the GPU: go on without the scout for this read
-        w.sc_abandoned = true;
-        lds_store_rel(&sm->sc_skip, w.sc_read + 1);
-        return false;
-      }
-    }
-    SpecBuf *b = &sm->sb[1 + w.sc_taken % FQSX_SCR];
-    const u32 r = b->h_read;
-    // left over from before a restart, or from a read that was finished without the scout
-    if (b->h_epoch != w.sc_epoch || (i32)(r - w.sc_read) < 0) { scout_release(w); continue; }
-    if (r == w.sc_read && b->h_i0 == i && b->h_n == n) { w.sb = b; return true; }
-    w.sc_abandoned = true;
-    lds_store_rel(&sm->sc_skip, w.sc_read + 1);
-    return false;
-  }
-}
-// The resolving wave has corrected k-mers: hand the scout wave the exact state before position i0 of the current read
-FQ_DEV void scout_restart(Wk &w, u32 i0) {
-  WgShared *sm = w.sm;
+  if (lds_load_acq(&sm->sc_dead)) return;
   FQ_SYNC();
   if (FQ_LANE == 0) {
     WgShared::ScoutReq &q = sm->sc_req;
-    q.read = w.sc_read; q.i0 = i0; q.cor_pos = w.cor_pos; q.n_run = w.N_run;
+    q.read = read; q.i0 = i0; q.cor_pos = w.cor_pos; q.n_run = w.N_run;
     const Kmer *k[6] = {&w.pm, &w.sm_, &w.bm, &w.pm_u, &w.sm_u, &w.bm_u};
     for (u32 x = 0; x < 6; ++x) { q.kdir[x] = k[x]->dir; q.krc[x] = k[x]->rc; q.kcur[x] = k[x]->cur; }
-    for (u32 x = 0; x < 4; ++x) q.s_let[x] = w.s_let[x];
+    for (u32 x = 0; x < 4; ++x) q.s_let[x] = s_let[x];
   }
+  w.sc_taken = 0;
   FQ_SYNC();
+  lds_store_rel(&sm->sc_taken, 0u);
   w.sc_epoch += 1;
   lds_store_rel(&sm->sc_req_seq, w.sc_epoch);
+}
+FQ_DEV bool scout_take(Wk &w, u32 i, u32 n) {
+  WgShared *sm = w.sm;
+  SpecBuf *b = &sm->sb[1 + w.sc_taken % FQSX_SCR];
+  u32 spins = 0;
+  // the chunk with this number of this epoch (a slot may still hold the one of an earlier epoch with the same number)
+  while (lds_load_acq(&b->h_pub) != w.sc_taken + 1 || b->h_epoch != w.sc_epoch) {
+    fq_sleep();
+    if (lds_load_acq(&sm->sc_dead) || ++spins > (1u << 22)) { w.sc_abandoned = true; return false; }   // never spin forever on the GPU
+  }
+  if (b->h_read == w.sc_read && b->h_i0 == i && b->h_n == n) { w.sb = b; return true; }
+  w.sc_abandoned = true;   // (cannot happen: the waves enumerate the chunks alike)
+  return false;
 }
 
 // compress_suffix, dna.cpp:674-877, as chunks of stage P (parallel) -> stage C (the serial loop below:
@@ -2873,8 +2882,8 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
     }
     // the scout's chunks of this read were rolled from k-mers that have just been corrected: it starts again from here
     // (posted before the release below: a scout woken by that must see the request)
-    if (dirty && w.scout && !w.sc_abandoned && i + m < size) scout_restart(w, i + m);
-    if (pre) scout_release(w);
+    if (dirty && w.scout && !w.sc_abandoned && i + m < size) scout_restart(w, w.sc_read, i + m, w.s_let);   // (a new epoch: nothing to release)
+    else if (pre) scout_release(w);
     i += m;
   }
 }
@@ -2931,7 +2940,7 @@ FQ_DEV void compress_read(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev
   w.st[ST_BASES] += size;
 }
 // The same with the head taken from the read-head wave's record `idx` (single-end sorted mode of the encode kernel)
-FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx) {
+FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx, bool has_next) {
   WgShared *sm = w.sm;
   TM_BEGIN(t_head);
   u32 spins = 0;
@@ -2971,6 +2980,9 @@ FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx) {
     suffix(w, p, size, false);
     add_s_letters(w, hist);
     w.st[ST_BASES] += size;
+    // the read was (partly) resolved without the scout waves: they take up again at the head of the next one
+    // (posted while this read's record still counts as in use, so that the records they need are in place)
+    if (w.sc_abandoned && has_next) scout_restart(w, idx + 1, w.cfg->pmer, w.s_let);
   }
   FQ_SYNC();
   lds_store_rel(&sm->hd_taken, idx + 1);   // the record and its staging buffer are free again
@@ -3198,7 +3210,10 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
   for (u64 i = cur; i < stop && !w.err; ++i) {
     const u32 idx = (u32)(i - cur);
     u32 spins = 0;
-    while ((i32)(idx - lds_load_acq(&sm->hd_taken)) >= 2 || (i32)(idx - lds_load_acq(&sm->sc_hd_taken)) >= 2) {   // both records in use
+    for (;;) {   // both records in use: by the resolving wave or by a scout wave
+      bool busy = (i32)(idx - lds_load_acq(&sm->hd_taken)) >= 2;
+      for (u32 x = 0; x < FQSX_NSC; ++x) busy |= (i32)(idx - lds_load_acq(&sm->sc_hd_taken[x])) >= 2;
+      if (!busy) break;
       fq_sleep();
       if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
     }
@@ -3239,15 +3254,16 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
   TM_STAMP(cfg, tid, launch, 1);
 }
 
-// The scout wave of the encode kernel (single-end sorted mode): stage P of every chunk of every read, ahead of the
-// resolving wave, under the assumption that the read needs no k-mer correction -- then the rolling k-mers at any
-// position follow from the read's symbols and the state after its prefix (head record), the correction position
-// stays 0, and the letter totals are those of the reads before it.  Chunks go through a small ring of SpecBufs tagged
-// (read, first position); the resolving wave adopts the chunk it is about to process if the tag matches and falls
-// back to its own stage P for the rest of a read once a correction has happened (sc_skip tells the scout to move on).
-// The chunk records which local-list entries were already applied when its probes started, so the resolving wave's
+// The scout waves of the encode kernel (single-end sorted mode): stage P of every chunk of every read, ahead of the
+// resolving wave.  The rolling k-mers at any position of a read follow in closed form from the read's symbols and
+// a base state -- the state after the read's prefix (head record) or, after a k-mer correction, the exact state the
+// resolving wave posts (ScoutReq) -- so the chunks are independent of each other and FQSX_NSC waves make them in
+// turn: all waves walk the same enumeration of (read, chunk), chunk number c of an epoch is made by wave c % FQSX_NSC
+// in ring slot c % FQSX_SCR and published through the slot's own word (h_pub).  A restart starts a new epoch: every
+// wave acknowledges, and none writes a chunk of the new epoch before all have (a slot is never written by two).
+// A chunk records which local-list entries were already applied when its probes started, so the resolving wave's
 // validation of the local probes (pend_conflict) covers exactly the entries the scout may have missed.
-FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, u32 launch = 0) {
+FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_reads, u32 S, u32 seg, u32 me, u32 launch = 0) {
   Wk w;
   w.cfg = &cfg;
   w.sm = sm;
@@ -3272,11 +3288,11 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
   u64 stop = last;
   if (seg < S) stop = ((u64)seg + 1) * (last - first) / ((u64)S + 1) + first + 1;   // application.cpp:643
   if (stop > last) stop = last;
-  u32 made = 0;
   bool quit = false;
   w.sc_epoch = 0;
   const u32 n_seg = (u32)(stop > cur ? stop - cur : 0);
-  u32 idx = 0;          // read the wave is working on (index within the launch)
+  u32 idx = 0;          // read the wave is at (index within the launch)
+  u32 seq = 0;          // number, within the epoch, of the next chunk of the enumeration
   bool restart = false; // a request of the resolving wave is to be taken up (sc_req)
   while (!quit) {
     u32 spins = 0;
@@ -3284,7 +3300,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
     if (idx >= n_seg && !restart) {
       // every read has its chunks; stay until the resolving wave has finished the last read (it may still ask for a restart)
       if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; continue; }
-      if ((i32)(lds_load_acq(&sm->hd_taken) - n_seg) >= 0 || lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_skip) >= n_seg) break;
+      if ((i32)(lds_load_acq(&sm->hd_taken) - n_seg) >= 0 || lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead)) break;
       fq_sleep();
       continue;
     }
@@ -3293,28 +3309,57 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
         if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
         fq_sleep();
-        if (lds_load_acq(&sm->cq_done) || ++spins > (1u << 23)) { quit = true; break; }
+        if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || ++spins > (1u << 23)) { quit = true; break; }
       }
       TM_END(w, TM_SCOUT_WAIT, t_w1);
       if (quit) break;
     }
     if (!restart && lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) restart = true;
-    if (restart) {   // go back to the read the request names, to the exact state it carries
+    bool from_head = true;
+    if (restart) {   // take up the request: acknowledge, and go on only when every scout wave has (no slot is written by two)
       restart = false;
-      w.sc_epoch = lds_load_acq(&sm->sc_req_seq);
+      for (;;) {
+        w.sc_epoch = lds_load_acq(&sm->sc_req_seq);
+        FQ_SYNC();
+        lds_store_rel(&sm->sc_ack[me], w.sc_epoch);
+        bool all = true;
+        spins = 0;
+        for (u32 x = 0; x < FQSX_NSC && !quit; ++x)
+          while (lds_load_acq(&sm->sc_ack[x]) != w.sc_epoch) {
+            if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { all = false; break; }   // a newer request already (cannot happen before this one is served)
+            fq_sleep();
+            if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || ++spins > (1u << 23)) { quit = true; break; }
+          }
+        if (all || quit) break;
+      }
+      if (quit) break;
       const WgShared::ScoutReq &q = sm->sc_req;
       idx = uniform32(q.read);
       base_pos = uniform32(q.i0);
-      Kmer *k[6] = {&w.pm, &w.sm_, &w.bm, &w.pm_u, &w.sm_u, &w.bm_u};
-      for (u32 x = 0; x < 6; ++x) { k[x]->dir = uniform64(q.kdir[x]); k[x]->rc = uniform64(q.krc[x]); k[x]->cur = uniform32(q.kcur[x]); }
-      w.cor_pos = uniform32(q.cor_pos);
-      w.N_run = uniform32(q.n_run);
+      seq = 0;
+      from_head = base_pos == cfg.pmer;
+      if (!from_head) {
+        Kmer *k[6] = {&w.pm, &w.sm_, &w.bm, &w.pm_u, &w.sm_u, &w.bm_u};
+        for (u32 x = 0; x < 6; ++x) { k[x]->dir = uniform64(q.kdir[x]); k[x]->rc = uniform64(q.krc[x]); k[x]->cur = uniform32(q.kcur[x]); }
+        w.cor_pos = uniform32(q.cor_pos);
+        w.N_run = uniform32(q.n_run);
+      }
       for (u32 x = 0; x < 4; ++x) w.s_let[x] = uniform64(q.s_let[x]);
-      if (idx >= n_seg) break;   // (cannot happen)
-      // The records of this read and the next one are still in place while the resolving wave is inside this read
-      // (hd_taken); from now on this wave's own progress word protects them again.
+      if (idx >= n_seg) continue;   // (cannot happen)
+      // The records of this read and the next one are in place while the resolving wave counts as inside the read the
+      // request was posted from (hd_taken); from now on this wave's own progress word protects them again.
       FQ_SYNC();
-      lds_store_rel(&sm->sc_hd_taken, idx);
+      lds_store_rel(&sm->sc_hd_taken[me], idx);
+      if (from_head) {   // the record may not be there yet
+        spins = 0;
+        while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
+          if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
+          fq_sleep();
+          if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || ++spins > (1u << 23)) { quit = true; break; }
+        }
+        if (quit) break;
+        if (restart) continue;
+      }
     }
     const HeadRec *rec = &sm->hd[idx & 1];
     const bool rec_same = uniform32(rec->same) != 0;   // (wave-uniform values: kept in scalar registers)
@@ -3325,7 +3370,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
     FQ_SYNC();
     if (uniform32(rec->idx) != idx) {   // the record has been reused: this wave took up a request after the resolving wave had left the read
       lds_store_rel(&sm->sc_dead, 1u);
-      lds_store_rel(&sm->sc_hd_taken, 0x7fffffffu);   // (the read-head wave no longer waits for this one)
+      for (u32 x = 0; x < FQSX_NSC; ++x) lds_store_rel(&sm->sc_hd_taken[x], 0x7fffffffu);   // (the read-head wave no longer waits for the scouts)
       break;
     }
     if (!rec_same) {
@@ -3334,7 +3379,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       const u8 *p = cfg.bases + o0;
       const u32 size = (u32)(o1 - o0);
       w.rdp = sm->rd[idx & 1];
-      if (base_pos == cfg.pmer) {   // from the head of the read
+      if (from_head) {
         w.pm.dir = hk_dir[0]; w.pm.rc = hk_rc[0]; w.pm.cur = hk_cur[0];
         w.sm_.dir = hk_dir[1]; w.sm_.rc = hk_rc[1]; w.sm_.cur = hk_cur[1];
         w.bm.dir = hk_dir[2]; w.bm.rc = hk_rc[2]; w.bm.cur = hk_cur[2];
@@ -3343,20 +3388,21 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         w.N_run = h_nrun;
       }
       w.sc_read = idx;
-      for (u32 i0 = base_pos; i0 < size && !quit && !restart; i0 += FQSX_SPEC) {
+      for (u32 i0 = base_pos; i0 < size && !quit && !restart; i0 += FQSX_SPEC, ++seq) {
+        if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
+        if (seq % FQSX_NSC != me) continue;   // another wave's chunk
         spins = 0;
         TM_BEGIN(t_w2);
-        while (made - lds_load_acq(&sm->sc_taken) >= FQSX_SCR) {   // every ring buffer holds an unreleased chunk
-          if (lds_load_acq(&sm->sc_skip) > idx) break;   // nobody will take further chunks of this read (the ring is drained at the next read that uses the scout)
+        while ((i32)(seq - lds_load_acq(&sm->sc_taken)) >= (i32)FQSX_SCR) {   // the chunk's ring slot still holds an unreleased one
           if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
           fq_sleep();
-          if (lds_load_acq(&sm->cq_done) || ++spins > (1u << 23)) { quit = true; break; }
+          if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || ++spins > (1u << 23)) { quit = true; break; }
         }
         TM_END(w, TM_SCOUT_WAIT, t_w2);
-        if (!restart && lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) restart = true;
-        if (quit || restart || lds_load_acq(&sm->sc_skip) > idx) break;
+        if (quit || restart) break;
         const u32 n = size - i0 < FQSX_SPEC ? size - i0 : FQSX_SPEC;
-        w.sb = &sm->sb[1 + made % FQSX_SCR];
+        w.sb = &sm->sb[1 + seq % FQSX_SCR];
+        lds_store_rel(&w.sb->h_pub, 0u);   // (the slot may hold a chunk of the same number from an earlier epoch)
         speculate(w, p, size, i0, n, false, i0 - base_pos);
 #if FQ_WAVE > 1
         if (i0 == base_pos) scout_early(w, n);   // (the look-ups of positions whose b-mer is still partial, if any)
@@ -3366,23 +3412,22 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
 #endif
         if (FQ_LANE == 0) { w.sb->h_read = idx; w.sb->h_i0 = i0; w.sb->h_n = n; w.sb->h_epoch = w.sc_epoch; w.sb->rr_front = front0; }
         FQ_SYNC();
-        made += 1;
-        lds_store_rel(&sm->sc_ready, made);   // the resolving wave may start on the chunk ...
+        lds_store_rel(&w.sb->h_pub, seq + 1);   // the resolving wave may start on the chunk ...
 #if FQ_WAVE > 1
-        scout_rough(w, n);                     // ... while its sweeps are still being probed (rr_front)
+        scout_rough(w, n);                       // ... while its sweeps are still being probed (rr_front)
 #endif
       }
-      if (restart) continue;
+      if (restart || quit) continue;
       add_s_letters(w, hist);
     }
     FQ_SYNC();
-    lds_store_rel(&sm->sc_hd_taken, idx + 1);
+    lds_store_rel(&sm->sc_hd_taken[me], idx + 1);
     ++idx;
   }
 #ifdef FQSX_TIMING
   if (FQ_LANE == 0 && w.tm[TM_SCOUT_WAIT]) atomic_add64(&ws->stat[16 + TM_SCOUT_WAIT], w.tm[TM_SCOUT_WAIT]);
 #endif
-  TM_STAMP(cfg, tid, launch, 4);
+  if (me == 0) TM_STAMP(cfg, tid, launch, 4);
 }
 
 // piped: this wave is the resolving half of a multi-wave worker (see coder_segment_body).
@@ -3485,7 +3530,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   } else if (heads)
     for (u64 i = cur; i < stop && !w.err; ++i) {
       u64 o0 = cfg.read_off[i], o1 = cfg.read_off[i + 1];
-      compress_read_rec(w, cfg.bases + o0, (u32)(o1 - o0), (u32)(i - cur));
+      compress_read_rec(w, cfg.bases + o0, (u32)(o1 - o0), (u32)(i - cur), i + 1 < stop);
     }
   else if (!paired)
     for (u64 i = cur; i < stop && !w.err; ++i) {
@@ -3642,6 +3687,9 @@ FQ_DEV void insert_batch_k(const DevCfg &cfg, SM *sm, const KTab &t, u32 tid, u6
 
 // ---- stable partition of the mailbox lists by owner -----------------------------------------
 FQ_DEV u32 mail_owner(const DevCfg &cfg, u32 kind, u64 x) { return kind == MAIL_P ? p_owner(&cfg, x) : sb_owner(&cfg, x); }
+// group index of an entry in the partitioned mailbox (the owner itself unless the run is sharded over GPUs)
+FQ_DEV u32 mail_group(const DevCfg &cfg, u32 kind, u64 x) { return cfg.vmap[mail_owner(cfg, kind, x)]; }
+FQ_DEV bool shard_mine(const DevCfg &cfg, u32 w) { return cfg.shard_world <= 1 || w % cfg.shard_world == cfg.shard_rank; }
 
 // tile `blk` = (source, tile): histogram of owners
 FQ_DEV void part_count_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *hist /*LDS[256]*/) {
@@ -3650,7 +3698,7 @@ FQ_DEV void part_count_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *hist /*LD
   const u32 n = m.n[s], lo = t * FQSX_TILE, hi = n < lo + FQSX_TILE ? n : lo + FQSX_TILE;
   for (u32 d = FQ_LANE; d < 256; d += FQ_WAVE) hist[d] = 0;
   FQ_SYNC();
-  for (u32 e = lo + FQ_LANE; e < hi; e += FQ_WAVE) lds_inc32(&hist[mail_owner(cfg, kind, m.list[(u64)s * m.cap + e])]);
+  for (u32 e = lo + FQ_LANE; e < hi; e += FQ_WAVE) lds_inc32(&hist[mail_group(cfg, kind, m.list[(u64)s * m.cap + e])]);
   FQ_SYNC();
   for (u32 d = FQ_LANE; d < T; d += FQ_WAVE) m.tile_hist[(u64)blk * T + d] = hist[d];
 }
@@ -3670,11 +3718,15 @@ FQ_DEV void part_scan_body(const DevCfg &cfg, u32 kind, u32 d) {
 }
 FQ_DEV void part_dstoff_body(const DevCfg &cfg, u32 kind) {
   const Mail &m = cfg.mail[kind];
-  if (FQ_LANE == 0) {
-    u32 run = 0;
-    for (u32 d = 0; d < cfg.T; ++d) { m.dst_off[d] = run; run += m.dst_tot[d]; }
-    m.dst_off[cfg.T] = run;
+  u32 run = 0;   // exclusive scan over the owners, a wave's worth at a time
+  for (u32 base = 0; base < cfg.T; base += FQ_WAVE) {
+    const u32 d = base + FQ_LANE;
+    const u32 v = d < cfg.T ? m.dst_tot[d] : 0;
+    const u32 ex = wave_excl_scan32(v) + run;
+    if (d < cfg.T) m.dst_off[d] = ex;
+    run += wave_sum32(v);
   }
+  if (FQ_LANE == 0) m.dst_off[cfg.T] = run;
 }
 // tile `blk`: stable scatter into the owners' groups
 FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor /*LDS[256]*/, u32 *ld /*LDS[64]*/) {
@@ -3690,7 +3742,7 @@ FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor 
     u32 d = 0xffffffffu;
     if (e < hi) {
       x = m.list[(u64)s * m.cap + e];
-      d = mail_owner(cfg, kind, x);
+      d = mail_group(cfg, kind, x);
     }
     ld[FQ_LANE] = d;
     FQ_SYNC();

@@ -23,7 +23,7 @@ template <int MODE> FQ_DEV void encode_pe_kernel_body() {
     sm->cq_tail = 0; sm->cq_head = 0; sm->cq_done = 0;
     sm->lq_target[0] = sm->lq_target[1] = 0; sm->lq_done[0] = sm->lq_done[1] = 0; sm->lq_quit = 0;
     sm->hd_ready = 0; sm->hd_taken = 0;
-    sm->sc_ready = 0; sm->sc_taken = 0; sm->sc_skip = 0; sm->sc_hd_taken = 0; sm->sc_req_seq = 0; sm->sc_dead = 0;
+    sm->sc_taken = 0; sm->sc_req_seq = 0; sm->sc_dead = 0;
   }
   FQ_WG_BARRIER();
   if (FQ_WAVE_ID == 0) role_resolve_pe<MODE>(fq_kernarg());

@@ -139,6 +139,8 @@ struct DevCfg {
   u32 pmer_mod_shift;          // dna.cpp:2381
   u32 ps_nobytes_n;            // alphabet of prefix_sorted_no_bytes, dna.cpp:130
   u64 T_magic;                 // ceil(2^32 / T): x % T for x < 2^14 without a division
+  u32 T_pow2;                  // T is a power of two (then x % T is a mask)
+  u32 pad0_;
   u64 *siv;                    // 4^pmer 2-bit counters
   u64 *siv_stats;              // [0] no_updates [1] no_filled (bit_vec.h:25-26)
   KTab g_s, g_b;               // owner-sharded global tables (T sub-tables)
@@ -166,6 +168,12 @@ struct DevCfg {
   u64 dcap;
   u32 *err;                    // device error word (0 = ok)
   u64 *trace;                  // -DFQSX_TIMING builds: [launch][worker][8] clock stamps of the roles (else null)
+  // Sharded mode: worker w -- its coder state, RNG streams, local tables and the sub-tables it owns --
+  // lives on rank w % shard_world; every rank holds a read-only replica of all sub-tables.  shard_world == 1: one GPU.
+  u32 shard_rank, shard_world;
+  const u8 *vmap;              // [256] owner -> position of its group in the partitioned mailbox: identity, or rank-major
+                               // (all owners of rank 0, then rank 1, ...) so that what goes to one rank is contiguous
+  u32 *shard_cnt;              // [3][T][T] entries source s pushed for owner o in this phase (own sources; else 0)
 };
 
 enum {

@@ -31,7 +31,7 @@ typedef int32_t i32;
 #define FQ_KERNEL64 extern "C" __global__ __launch_bounds__(64)
 #define FQ_KERNEL320 extern "C" __global__ __launch_bounds__(320)
 #define FQ_KERNEL192 extern "C" __global__ __launch_bounds__(192)
-#define FQ_KERNEL384 extern "C" __global__ __launch_bounds__(384)
+#define FQ_KERNEL512 extern "C" __global__ __launch_bounds__(512)
 #define FQ_WAVE 64
 #define FQ_LANE ((u32)(threadIdx.x & 63u))
 #define FQ_BLOCK ((u32)blockIdx.x)
@@ -106,7 +106,7 @@ FQ_DEV double ema_update(double avg, double level) { return __dadd_rn(__dmul_rn(
 #define FQ_KERNEL64 static
 #define FQ_KERNEL320 static
 #define FQ_KERNEL192 static
-#define FQ_KERNEL384 static
+#define FQ_KERNEL512 static
 #define FQ_WAVE 1
 #define FQ_LANE 0u
 #define FQ_BLOCK (fq_emu_block)

@@ -43,6 +43,30 @@ def synth_reads(n_reads: int, read_len: int, genome_len: int, seed: int,
     return out
 
 
+def synth_two_haplotypes(n_reads: int, read_len: int, genome_len: int, seed: int, snp_every: int = 150,
+                         sub_rate: float = 0.005, n_rate: float = 0.001) -> np.ndarray:
+    """Very deep coverage of a small genome with two haplotypes (a substitution every `snp_every` bases): k-mer counters
+    run into saturation, both alleles of a site reach the counter maximum (counts_level_t::mixed), the probabilistic
+    counters work above their thresholds.  Same read model as synth_reads."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    a = rng.integers(0, 4, size=genome_len, dtype=np.uint8)
+    b = a.copy()
+    sites = np.arange(snp_every // 2, genome_len, snp_every)
+    b[sites] = (b[sites] + 1 + rng.integers(0, 3, size=len(sites), dtype=np.uint8)) & 3
+    hap = np.stack([_ACGT[a], _ACGT[b]])
+    pos = rng.integers(0, genome_len - read_len + 1, size=n_reads, dtype=np.int64)
+    which = rng.integers(0, 2, size=n_reads, dtype=np.int64)
+    strand = rng.integers(0, 2, size=n_reads, dtype=np.uint8)
+    ar = np.arange(read_len, dtype=np.int64)
+    r = hap[which[:, None], pos[:, None] + ar[None, :]]
+    r = np.where(strand[:, None] == 1, _COMP[r[:, ::-1]], r)
+    u = rng.random(size=(n_reads, read_len))
+    alt = _ACGT[rng.integers(0, 4, size=(n_reads, read_len), dtype=np.uint8)]
+    r = np.where(u < sub_rate, alt, r)
+    r = np.where((u >= sub_rate) & (u < sub_rate + n_rate), np.uint8(ord("N")), r)
+    return np.ascontiguousarray(r)
+
+
 def synth_quals(n_reads: int, read_len: int, seed: int) -> np.ndarray:
     rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
     return _QUALS[rng.integers(0, len(_QUALS), size=(n_reads, read_len), dtype=np.uint8)]

@@ -59,6 +59,7 @@ struct Mt19937 {
 // CCounterIncrementer, utils.h:256-335
 struct CounterInc {
   Mt19937 mt;
+  u64 draws = 0;   // random numbers consumed (counters above the threshold)
   u32 thr, mult, maxv;
   std::vector<u32> map;
   void reset(u32 thr_, u32 mult_, u32 maxv_) {  // utils.h:294-312
@@ -74,6 +75,7 @@ struct CounterInc {
   }
   u32 inc1(u32 c) {  // utils.h:314-325
     if (c <= thr) return c + 1;
+    ++draws;
     return (mt.next() % (mult * (c - thr)) == 0) ? c + 1 : c;
   }
   u32 decode(u32 v) const {  // utils.h:264-270
@@ -87,6 +89,7 @@ struct CounterInc {
     u32 pos = (u32)(std::upper_bound(map.begin() + thr, map.begin() + end_dist, real) - 1 - map.begin());
     if (pos >= maxv) return maxv;
     u32 rest = real - map[pos];
+    ++draws;
     if (mt.next() % (map[(size_t)pos + 1] - map[pos]) < rest) ++pos;
     return pos;
   }
@@ -177,6 +180,7 @@ static inline u64 murmur64(u64 h) {  // ht_kmer.h:123-127, context_hm.h:81-85
 
 struct Counters {
   u64 probes = 0, slots = 0, inserts = 0, siv_words = 0, ctx = 0, coded = 0, lprobes = 0, linserts = 0;
+  u64 lv[6] = {0, 0, 0, 0, 0, 0};   // find_counts results per counts_level_t (none, pmer, smer, bmer, mixed, bmer_unc)
 };
 
 struct KTable {
@@ -824,7 +828,12 @@ struct Worker {
     return KTable::non_empty(counts);
   }
 
-  u32 find_counts(u32 counts[4]) {  // dna.cpp:457-502
+  u32 find_counts(u32 counts[4]) {
+    const u32 l = find_counts_(counts);
+    sh->cnt.lv[l] += 1;
+    return l;
+  }
+  u32 find_counts_(u32 counts[4]) {  // dna.cpp:457-502
     counts[0] = counts[1] = counts[2] = counts[3] = 0;
     u32 bmargin = sh->kl.bmer - sh->kl.smer - 1;
     u32 smargin = sh->kl.smer - sh->kl.pmer + 1;
@@ -1523,6 +1532,11 @@ const uint8_t *fqo_stream(fqo_codec *c, uint32_t worker, uint64_t *len) {
   return c->w[worker]->rc.out.data();
 }
 
+void fqo_levels(fqo_codec *c, uint64_t o[10]) {
+  for (int i = 0; i < 6; ++i) o[i] = c->sh.cnt.lv[i];
+  o[6] = o[7] = o[8] = o[9] = 0;
+  for (auto *w : c->w) { o[6] += w->cinc_b.draws; o[7] += w->cinc_s.draws; o[8] += w->cinc_lb.draws; o[9] += w->cinc_ls.draws; }
+}
 void fqo_counters(fqo_codec *c, uint64_t o[8]) {
   const Counters &k = c->sh.cnt;
   o[0] = k.probes; o[1] = k.slots; o[2] = k.inserts; o[3] = k.siv_words;

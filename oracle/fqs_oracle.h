@@ -50,6 +50,10 @@ int fqo_decode_block(fqo_codec *, const uint8_t *const *streams, const uint64_t 
  * [4] context look-ups [5] symbols range-coded [6] local-table probes
  * [7] local inserts */
 void fqo_counters(fqo_codec *, uint64_t out[8]);
+/* Coverage of the rarely taken branches: [0..5] find_counts results per counts_level_t (none, pmer, smer, bmer,
+ * mixed, bmer_unc; defs.h:45, dna.cpp:457-502), [6..9] random draws of cinc_b / cinc_s / cinc_lb / cinc_ls (counters
+ * above their thresholds, utils.h:272-325). */
+void fqo_levels(fqo_codec *, uint64_t out[10]);
 
 /* Quality stream (CQualityCompressor, quality.cpp:152-175): same header bytes
  * (quality_mode = byte 6, quality_thr = byte 8), same worker partition, no synchronisation points. */

@@ -45,6 +45,7 @@ def lib():
         _lib.fqo_qual_stream.restype = C.POINTER(C.c_uint8)
         _lib.fqo_qual_stream.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
         _lib.fqo_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        _lib.fqo_levels.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _lib.fqo_kat_mt19937.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         _lib.fqo_kat_cinc.argtypes = [C.c_uint32] * 4 + [C.c_void_p] * 3
         _lib.fqo_kat_rc.restype = C.c_uint64
@@ -89,6 +90,11 @@ class OracleCodec:
         a = (C.c_uint64 * 8)()
         lib().fqo_counters(self._h, a)
         return dict(zip(["probes", "slots", "inserts", "siv_words", "ctx", "coded", "lprobes", "linserts"], list(a)))
+
+    def levels(self):
+        a = (C.c_uint64 * 10)()
+        lib().fqo_levels(self._h, a)
+        return dict(zip(["none", "pmer", "smer", "bmer", "mixed", "bmer_unc", "draws_b", "draws_s", "draws_lb", "draws_ls"], list(a)))
 
     def close(self):
         if self._h:

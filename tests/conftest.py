@@ -52,7 +52,11 @@ def digest_records(meta):
     from fqsqueezer_amd import hostpipe as hp
     from fqsqueezer_amd.synth import read_id, synth_quals, synth_reads
     n, L = meta["reads"], meta["len"]
-    reads = synth_reads(n, L, meta["genome"], meta["seed"])
+    if meta.get("synth") == "two_haplotypes":
+        from fqsqueezer_amd.synth import synth_two_haplotypes
+        reads = synth_two_haplotypes(n, L, meta["genome"], meta["seed"])
+    else:
+        reads = synth_reads(n, L, meta["genome"], meta["seed"])
     return hp.Records([read_id(i) for i in range(n)], reads, synth_quals(n, L, meta["seed"]))
 
 
@@ -134,6 +138,17 @@ def check_full_file_digest(data: bytes, json_name: str):
             assert h.hexdigest() == ref[str(sid)], f"{json_name}: block {g}: {names[sid]} stream differs from the reference"
     assert len(data) == d["file_bytes"]
     assert hashlib.sha256(data).hexdigest() == d["file_sha256"]
+
+
+def pe_digest_records(meta):
+    """the two mate files of a paired-end digest fixture (tools/make_golden.py c14 / c15)"""
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.synth import read_id, synth_ids_varied, synth_pairs, synth_quals
+    n, seed = meta["pairs"], meta["seed"]
+    r1, r2 = synth_pairs(n, meta["len"], meta["genome"], seed)
+    ids1 = synth_ids_varied(n, seed, 1) if meta["varied_ids"] else [read_id(i, 1) for i in range(n)]
+    ids2 = synth_ids_varied(n, seed, 2) if meta["varied_ids"] else [read_id(i, 2) for i in range(n)]
+    return (hp.Records(ids1, r1, synth_quals(n, meta["len"], seed)), hp.Records(ids2, r2, synth_quals(n, meta["len"], seed + 1)))
 
 
 def c5_records():

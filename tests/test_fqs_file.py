@@ -6,7 +6,9 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import EMU_LIB, GOLD, IM, QM, ROOT, c1_records, c4_records, c10_records, c11_records, check_full_file_digest
+import json
+
+from conftest import EMU_LIB, GOLD, IM, QM, ROOT, c1_records, c4_records, c10_records, c11_records, check_full_file_digest, digest_records, pe_digest_records
 from fqsqueezer_amd import hostpipe as hp
 from fqsqueezer_amd.fqsfile import compress_records, compress_records_pe
 
@@ -84,3 +86,22 @@ def test_gpu_file_identical_to_reference_and_decodes(tmp_path):
         rec = c4_records()
         got = _decode_with_reference(compress_records(rec, 64, "s", 1), tmp_path)
         assert got[:len(rec)] == [rec.seq[int(i)] for i in np.concatenate(hp.sorted_order(rec))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c14_pe150_s_q8_t8.json", "c15_pe150_s_oo_t4.json"])
+def test_gpu_paired_end_150bp_files_match_reference(name):
+    """BASELINE configs[2]'s shape (150 bp pairs, -om s -qm 8; 100 k pairs, T = 8) and configs[4]'s modes (-qm o -im o):
+    every stream of every block, then the whole file, against the reference's own file."""
+    d = json.load(open(os.path.join(GOLD, name)))
+    r1, r2 = pe_digest_records(d)
+    check_full_file_digest(compress_records_pe(r1, r2, d["threads"], d["om"], d["gs"], quality_mode=QM[d["qm"]], id_mode=IM[d["im"]]), name)
+
+
+@pytest.mark.gpu
+def test_gpu_sorted_order_of_1M_reads_is_the_reference_order():
+    """N3 against the reference itself: the GPU sort pre-pass orders the metric's 1 M x 150 bp file; the id stream (which
+    sees the order of equal reads too) and the DNA stream of the resulting file match the reference's `-om s -im o` file."""
+    name = "c16_1M150_s_ids_t8.json"
+    d = json.load(open(os.path.join(GOLD, name)))
+    check_full_file_digest(compress_records(digest_records(d), d["threads"], "s", d["gs"], quality_mode="none", id_mode="lossless"), name)

@@ -92,6 +92,13 @@ def test_hip_matches_reference_1M_150bp_bit_exact(t):
     assert st["bases"] <= 150_000_000 and st["coded"] > 120_000_000
 
 
+@pytest.mark.parametrize("om", ["o", "s"])
+def test_hip_matches_reference_saturated_counters(om):
+    """c13: counters at their maxima, counts_level_t::mixed / bmer_unc, probabilistic increments on s-mers (the oracle
+    test of the same fixture asserts that these branches are reached)."""
+    check_against_digest(gpu, f"c13_sat_{om}_t4.json")
+
+
 def test_hip_matches_oracle_many_workers_and_tiny_blocks():
     from oracle.pyoracle import OracleCodec
     rec = c4_records()

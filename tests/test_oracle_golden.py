@@ -47,6 +47,18 @@ def test_oracle_matches_reference_1M(t):
     check_against_digest(OracleCodec, f"c2_1M_s_t{t}.json")
 
 
+@pytest.mark.parametrize("om", ["o", "s"])
+def test_oracle_matches_reference_saturated_counters(om):
+    """~12000x coverage of a two-haplotype genome: the fixture provably reaches the rarely taken branches -- both alleles
+    of a site at the counter maximum (counts_level_t::mixed, dna.cpp:470-480), the uncorrected b-mer level (:489) and
+    the probabilistic counters above their thresholds (utils.h:272-325) -- and the oracle still matches the reference."""
+    codec = check_against_digest(OracleCodec, f"c13_sat_{om}_t4.json")
+    lv = codec.levels()
+    assert lv["mixed"] > 1000 and lv["bmer_unc"] > 0 and lv["draws_b"] > 1_000_000 and lv["draws_s"] > 1_000_000 and lv["draws_lb"] > 100_000
+    if om == "o":
+        assert lv["pmer"] > 100_000
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("t", [8, 64])
 def test_oracle_matches_reference_1M_150bp(t):

@@ -19,6 +19,13 @@ Fixtures (data only -- inputs are re-generated deterministically by fqsqueezer_a
   c3_50k150_s_t8.json       50k x 150bp, G=250kbp, seed 3, -om s -gs 8 (150 bp metric shape)
   c12_1M150_s_t{8,64}.json  1M x 150bp, G=7.5Mbp, seed 2, -om s -gs 8: the workload BASELINE.json's metric is quoted on
                             (bench.py's default), per-block SHA-256 of the reference DNA streams
+  c13_sat_{o,s}_t4.json     counter saturation: 300k (-om o, G=2.5kbp) / 500k (-om s, G=2kbp) x 100bp on a two-haplotype genome at
+                            ~12000x coverage (synth_two_haplotypes, seed 13): counts_level_t::mixed, bmer_unc, cinc_b / cinc_s above
+                            their thresholds (asserted through the oracle's fqo_levels)
+  c14_pe150_s_q8_t8.json    100k pairs x 150bp, G=1.5Mbp, seed 14, -p -om s -qm 8 -im n -gs 2 (BASELINE configs[2]'s shape): all streams
+  c15_pe150_s_oo_t4.json    20k pairs x 150bp, G=300kbp, seed 15, varied ids, -p -om s -qm o -im o -gs 1 (configs[4]'s modes): all streams
+  c16_1M150_s_ids_t8.json   the c12 input with -om s -im o -qm n -t 8: meta / id / DNA digests -- pins the sorted read ORDER
+                            (incl. the order of equal reads, which only the id stream sees) at 1 M reads
 Usage: python tools/make_golden.py [--work /tmp/w] [--only c1|c2|c3]
 """
 import argparse, hashlib, json, os, subprocess, sys
@@ -193,6 +200,12 @@ def main():
                                     "threads": t, "paired": True}), open(os.path.join(GOLD, f"c11_pe_full_{tag}.json"), "w"))
     if a.only in ("", "c12"):
         c12(a)
+    if a.only in ("", "c13"):
+        c13(a)
+    if a.only in ("", "c14"):
+        c14_c15(a)
+    if a.only in ("", "c16"):
+        c16(a)
     if a.only in ("", "c3"):
         fq = os.path.join(a.work, "c3.fq")
         if not os.path.exists(fq):
@@ -212,6 +225,70 @@ def c12(a):
         run_ref(fq, out, "s", t, 8, a.work)
         meta = {"reads": 1000000, "len": 150, "genome": 7500000, "seed": 2, "gs": 8, "om": "s", "threads": t}
         json.dump(digest(out, meta), open(os.path.join(GOLD, f"c12_1M150_s_t{t}.json"), "w"))
+
+
+def fdigest(path, meta):
+    """per-block SHA-256 of every stored stream + digest of the whole file"""
+    data = open(path, "rb").read()
+    header, blocks = hp.parse_fqs(data)
+    d = dict(meta, header=header.hex(), n_blocks=len(blocks), file_sha256=hashlib.sha256(data).hexdigest(), file_bytes=len(data), blocks=[])
+    for b in blocks:
+        e = {"n_reads": b.n_reads}
+        for sid in hp.stored_streams(header):
+            h = hashlib.sha256()
+            for st in b.streams:
+                h.update(st[sid])
+            e[str(sid)] = h.hexdigest()
+        d["blocks"].append(e)
+    return d
+
+
+def write_fq_ids(path, ids, reads, quals):
+    with open(path, "wb") as f:
+        for i in range(len(ids)):
+            f.write(ids[i] + b"\n" + reads[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n")
+
+
+def c13(a):
+    from fqsqueezer_amd.synth import synth_two_haplotypes
+    for om, n, G in (("o", 300000, 2500), ("s", 500000, 2000)):
+        fq = os.path.join(a.work, f"c13_{om}.fq")
+        if not os.path.exists(fq):
+            write_fastq(fq, synth_two_haplotypes(n, 100, G, 13), seed=13)
+        out = os.path.join(a.work, f"c13_{om}_t4.fqs")
+        run_ref(fq, out, om, 4, 1, a.work)
+        meta = {"reads": n, "len": 100, "genome": G, "seed": 13, "gs": 1, "om": om, "threads": 4, "synth": "two_haplotypes"}
+        json.dump(digest(out, meta), open(os.path.join(GOLD, f"c13_sat_{om}_t4.json"), "w"))
+
+
+def c14_c15(a):
+    from fqsqueezer_amd.synth import synth_ids_varied, synth_pairs, synth_quals, read_id
+    for tag, npairs, G, seed, gs, qm, im, t, varied in (("c14_pe150_s_q8_t8", 100000, 1500000, 14, 2, "8", "n", 8, False),
+                                                        ("c15_pe150_s_oo_t4", 20000, 300000, 15, 1, "o", "o", 4, True)):
+        r1, r2 = synth_pairs(npairs, 150, G, seed)
+        f1, f2 = os.path.join(a.work, tag + "_1.fq"), os.path.join(a.work, tag + "_2.fq")
+        ids1 = synth_ids_varied(npairs, seed, 1) if varied else [read_id(i, 1) for i in range(npairs)]
+        ids2 = synth_ids_varied(npairs, seed, 2) if varied else [read_id(i, 2) for i in range(npairs)]
+        write_fq_ids(f1, ids1, r1, synth_quals(npairs, 150, seed))
+        write_fq_ids(f2, ids2, r2, synth_quals(npairs, 150, seed + 1))
+        out = os.path.join(a.work, tag + ".fqs")
+        subprocess.check_call([REF, "e", "-p", "-om", "s", "-t", str(t), "-gs", str(gs), "-qm", qm, "-im", im, "-v", "0",
+                               "-tmp", os.path.join(a.work, "tmpc_"), "-out", out, f1, f2], stdout=subprocess.DEVNULL)
+        meta = {"pairs": npairs, "len": 150, "genome": G, "seed": seed, "gs": gs, "om": "s", "qm": qm, "im": im, "threads": t,
+                "paired": True, "varied_ids": varied}
+        json.dump(fdigest(out, meta), open(os.path.join(GOLD, tag + ".json"), "w"))
+
+
+def c16(a):
+    fq = os.path.join(a.work, "c12.fq")
+    if not os.path.exists(fq):
+        write_fastq(fq, synth_reads(1000000, 150, 7500000, 2), seed=2)
+    out = os.path.join(a.work, "c16_s_ids_t8.fqs")
+    if not os.path.exists(out):
+        subprocess.check_call([REF, "e", "-s", "-om", "s", "-t", "8", "-gs", "8", "-qm", "n", "-im", "o", "-v", "0",
+                               "-tmp", os.path.join(a.work, "tmpi_"), "-out", out, fq], stdout=subprocess.DEVNULL)
+    meta = {"reads": 1000000, "len": 150, "genome": 7500000, "seed": 2, "gs": 8, "om": "s", "qm": "n", "im": "o", "threads": 8}
+    json.dump(fdigest(out, meta), open(os.path.join(GOLD, "c16_1M150_s_ids_t8.json"), "w"))
 
 
 def ragged():
