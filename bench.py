@@ -54,6 +54,10 @@ def main() -> None:
     ap.add_argument("--no-pcie", action="store_true", help="skip the extra host-buffer (PCIe-inclusive) pass")
     ap.add_argument("--no-t255", action="store_true", help="skip the extra pass with 255 workers")
     ap.add_argument("--concurrent", type=int, default=4, help="extra pass: this many codec instances at once (0/1 = skip)")
+    ap.add_argument("--no-rows", action="store_true", help="skip the extra passes over the other rows (decoder, quality, PE, original order)")
+    ap.add_argument("--sharded", action="store_true",
+                    help="ONE file sharded over the N GPUs (workers w %% N on rank w, RCCL all-to-all of the mailboxes, "
+                         "replica refresh; fqsqueezer_amd/sharded.py) instead of N independent files: strong scaling")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,8 +73,15 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the FQSX DNA path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1 or a.sharded:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29543")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if a.sharded:
+        return sharded_main(a, rank, local_rank, world)
 
     # ---- synthetic input, host preparation (not timed): binning + sort + block formation
     seed = 2 + rank
@@ -142,12 +153,12 @@ def main() -> None:
     _, st, kt = one_step(profile=True)
     alg = algorithmic_bytes(st)
     enc_s, ins_s = kt["encode_ms"] / 1e3, kt["insert_ms"] / 1e3
-    dominant = "k_encode_segment" if enc_s >= ins_s else "k_insert_phase"
+    dominant = "k_encode_se_sorted" if enc_s >= ins_s else "k_insert_phase"
     dom_s = max(enc_s, ins_s)
     dom_launches = kt["encode_launches"] if enc_s >= ins_s else kt["insert_launches"]
     # bytes attributable to the dominant kernel
     ins_bytes = 28.0 * st["gins"] + 4.0 * st["gins_slot"]
-    dom_bytes = alg - ins_bytes if dominant == "k_encode_segment" else ins_bytes
+    dom_bytes = alg - ins_bytes if dominant == "k_encode_se_sorted" else ins_bytes
     achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6), "traffic": None, "kernel": dominant,
@@ -222,6 +233,13 @@ def main() -> None:
             traffic = None
     roofline["traffic"] = traffic
 
+    # ---- the rows beside the headline path (other dna_modes): 300 k x 150 bp each, extras of the N=1 line
+    rows = None
+    if world == 1 and not a.no_rows:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_rows
+        rows = bench_rows.measure(300_000, a.len, a.threads, local_rank)
+
     # ---- CPU baseline on a bounded sample of the same workload (rank 0, N=1 only)
     cpu = None
     if not a.no_cpu_baseline and world == 1:
@@ -234,12 +252,65 @@ def main() -> None:
         "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2+rank), -om s -gs {a.gs} -qm n -im n",
                    "workers_T": a.threads, "blocks": len(blocks), "per_gpu": "one independent file per GPU"},
         "bits_per_base": round(8.0 * dna_bytes / n_bases, 5), "steady_state": steady, "pcie_inclusive_mbases_s": pcie, "workers_255": t255, "concurrent_files": conc,
-        "roofline": roofline, "cpu_baseline": cpu,
+        "other_rows": rows, "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sharded_main(a, rank, local_rank, world):
+    """--sharded: ONE file (seed 2) over the N GPUs, strong scaling: workers w % N on rank w, per-phase RCCL all-to-all
+    of the mailboxes + replica refresh (fqsqueezer_amd/sharded.py).  The blocks are handed over as host buffers (the
+    sharded entry point uploads them), so `value` includes that copy.  Streams are bit-identical to the one-GPU run's."""
+    import torch
+    import torch.distributed as dist
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.sharded import ShardedDnaCodec
+    from fqsqueezer_amd.synth import read_id, synth_quals, synth_reads
+    reads = synth_reads(a.reads, a.len, a.genome, 2)
+    rec = hp.Records([read_id(i) for i in range(a.reads)], reads, synth_quals(a.reads, a.len, 2))
+    header = hp.make_header(a.threads, "se_sorted", a.gs)
+    host_blocks = [hp.block_arrays(rec, idx) for idx in hp.form_blocks(rec, "se_sorted")]
+    n_bases = int(a.reads) * int(a.len)
+    traffic = {}
+
+    def one_step():
+        c = ShardedDnaCodec(header, rank, world, device=local_rank)
+        nb = 0
+        for g, (bases, off) in enumerate(host_blocks):
+            nb += sum(len(x) for x in c.encode_block(bases, off, g).values())
+        traffic.update(c.traffic)
+        c.close()
+        return nb
+
+    for _ in range(a.warmup):
+        one_step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mine = 0
+    for _ in range(a.steps):
+        mine = one_step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tot = torch.tensor([mine], dtype=torch.int64, device="cuda")
+    dist.all_reduce(tot)
+    if rank == 0:
+        elapsed = float(t.item())
+        print(json.dumps({
+            "metric": "Mbases/s compressed (DNA stream, SE sorted)", "value": round(n_bases * a.steps / elapsed / 1e6, 4), "unit": "Mbases/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2), -om s -gs {a.gs} -qm n -im n", "workers_T": a.threads,
+                       "blocks": len(host_blocks), "per_gpu": f"one file sharded over {world} GPU(s): workers w % {world}, RCCL all-to-all of the mailboxes per phase"},
+            "bits_per_base": round(8.0 * int(tot.item()) / n_bases, 5),
+            "exchange_rank0_per_file": traffic, "roofline": None, "cpu_baseline": None}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def cpu_baseline(a, hp, reads, rec):

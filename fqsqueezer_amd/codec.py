@@ -256,6 +256,15 @@ class QualCodec:
             raise FqsxError(f"fqsx_qual_encode_block: {rc}: {self._lib.fqsx_last_error().decode()}")
         return [C.string_at(self._streams[w], self._lens[w]) if self._lens[w] else b"" for w in range(self.T)]
 
+    def encode_block_dev(self, d_quals_ptr: int, d_off_ptr: int, read_off: np.ndarray) -> int:
+        """Device-resident entry point; returns the total stream bytes of the block."""
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        self._lib.fqsx_qual_encode_block_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        rc = self._lib.fqsx_qual_encode_block_dev(self._h, d_quals_ptr, d_off_ptr, read_off.ctypes.data, len(read_off) - 1, self._streams, self._lens)
+        if rc:
+            raise FqsxError(f"fqsx_qual_encode_block_dev: {rc}: {self._lib.fqsx_last_error().decode()}")
+        return sum(self._lens[w] for w in range(self.T))
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._lib.fqsx_qual_destroy(self._h)

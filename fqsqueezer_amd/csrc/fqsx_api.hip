@@ -183,6 +183,158 @@ FQ_KERNEL void k_rehash_ctx(const u64 *o, u64 ocap_mask, u64 *n, u64 ncap_mask, 
   }
 }
 
+// ---- sharded mode: what is exchanged between the GPUs of a node ---------------------------------
+// C[kind][s][o] = entries source s pushed for owner o in this phase (after k_part_count, before k_part_scan turns the
+// tile counts into offsets); rows of workers that live elsewhere stay zero, so a sum over the ranks gives the matrix
+FQ_KERNEL64 void k_shard_counts(DevCfg cfg) {   // grid = 3 * T: (kind, source)
+  const u32 T = cfg.T, kind = FQ_BLOCK / T, s = FQ_BLOCK % T;
+  const Mail &m = cfg.mail[kind];
+  for (u32 o = FQ_LANE; o < T; o += FQ_WAVE) {
+    u32 n = 0;
+    if (shard_mine(cfg, s))
+      for (u32 t = 0; t < m.n_tiles; ++t) n += m.tile_hist[((u64)s * m.n_tiles + t) * T + cfg.vmap[o]];
+    cfg.shard_cnt[((u64)kind * T + s) * T + o] = n;
+  }
+}
+// Received entries -> this rank's owners' groups in (owner, source, push) order (the order InsertKmersToHT drains
+// its column in).  recv = the chunks of ranks 0..G-1 one after the other; the chunk of rank q holds, for every owner
+// of this rank in ascending order, the entries of q's sources in ascending order.  C = the summed count matrix.
+FQ_KERNEL64 void k_shard_merge(DevCfg cfg, u32 kind, const u64 *recv, const u32 *C) {   // grid = T (owner)
+  FQ_SHARED u32 col[256], pre[256];
+  const u32 T = cfg.T, G = cfg.shard_world, me = cfg.shard_rank, o = FQ_BLOCK;
+  const Mail &m = cfg.mail[kind];
+  const u32 *Ck = C + (u64)kind * T * T;
+  const u32 n_own = (T - me + G - 1) / G;   // owners of this rank: me, me + G, ...
+  // group offsets: this rank's owners in ascending order, the others empty
+  u32 dst = 0, tot = 0;
+  for (u32 jb = 0; jb < n_own; jb += FQ_WAVE) {
+    const u32 j = jb + FQ_LANE, o2 = me + j * G;
+    u32 n = 0;
+    if (j < n_own)
+      for (u32 s = 0; s < T; ++s) n += Ck[(u64)s * T + o2];
+    dst += wave_sum32(j < n_own && o2 < o ? n : 0u);
+    tot += wave_sum32(j < n_own && o2 == o ? n : 0u);
+  }
+  if (FQ_LANE == 0) {
+    m.dst_off[o] = dst;
+    m.dst_tot[o] = tot;
+    if (o == T - 1) m.dst_off[T] = dst + tot;
+  }
+  if (o % G != me) return;
+  // this owner's column and its prefix over the sources
+  u32 run = 0;
+  for (u32 sb = 0; sb < T; sb += FQ_WAVE) {
+    const u32 s = sb + FQ_LANE;
+    const u32 v = s < T ? Ck[(u64)s * T + o] : 0u;
+    const u32 ex = wave_excl_scan32(v) + run;
+    if (s < T) { col[s] = v; pre[s] = ex; }
+    run += wave_sum32(v);
+  }
+  FQ_SYNC();
+  u32 chunk0 = 0;   // start of rank q's chunk in recv
+  for (u32 q = 0; q < G; ++q) {
+    // entries of q's chunk that belong to owners before o, and the chunk's size
+    u32 before = 0, size = 0;
+    for (u32 jb = 0; jb < n_own; jb += FQ_WAVE) {
+      const u32 j = jb + FQ_LANE, o2 = me + j * G;
+      u32 n = 0;
+      if (j < n_own)
+        for (u32 s = q; s < T; s += G) n += Ck[(u64)s * T + o2];
+      before += wave_sum32(j < n_own && o2 < o ? n : 0u);
+      size += wave_sum32(j < n_own ? n : 0u);
+    }
+    u32 src = chunk0 + before;
+    for (u32 s = q; s < T; s += G) {
+      const u32 n = col[s], d = dst + pre[s];
+      for (u32 e = FQ_LANE; e < n; e += FQ_WAVE) m.sorted[d + e] = recv[src + e];
+      src += n;
+    }
+    chunk0 += size;
+  }
+}
+// After the insert phase: what the replicas on the other ranks have to take over.  One item per applied entry of this
+// rank's owners (duplicates carry the same final value): s-/b-mers the table slot (k-mer << cbits | count), p-mers
+// (index << 2 | final 2-bit value).  grid-stride over the merged list.
+FQ_KERNEL void k_shard_collect(DevCfg cfg, u32 kind, u64 *out) {
+  const Mail &m = cfg.mail[kind];
+  const u32 total = m.dst_off[cfg.T];
+#ifndef FQSX_EMU
+  const u32 stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
+#else
+  const u32 stride = 1, first = 0;
+#endif
+  for (u32 e = first; e < total; e += stride) {
+    const u64 x = m.sorted[e];
+    if (kind == MAIL_P) { out[e] = (x << 2) | siv_test(&cfg, x); continue; }
+    const KTab &t = kind == MAIL_S ? cfg.g_s : cfg.g_b;
+    const u64 *sl = t.slots + (u64)sb_owner(&cfg, x) * t.stride;
+    const u64 v = x >> (64 - 2 * t.k);
+    u64 p = tab_home(t, v), item = 0;
+    for (u64 n = 0; n <= t.cap_mask; ++n) {
+      const u64 it = sl[p];
+      if (!it) break;
+      if ((it >> t.cbits) == v) { item = it; break; }
+      p = (p + 1) & t.cap_mask;
+    }
+    out[e] = item;
+  }
+}
+// ... and their application to this rank's replica of another rank's sub-tables (layout-free: find or claim the slot)
+FQ_KERNEL void k_shard_apply(DevCfg cfg, u32 kind, const u64 *items, u32 n) {
+#ifndef FQSX_EMU
+  const u32 stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
+#else
+  const u32 stride = 1, first = 0;
+#endif
+  for (u32 e = first; e < n; e += stride) {
+    const u64 item = items[e];
+    if (kind == MAIL_P) {
+      const u64 idx = item >> 2, val = item & 3;
+      u64 *wp = cfg.siv + (idx >> 5);
+      const u32 sh = 2 * (u32)(idx & 31);
+      u64 old = *wp;
+      for (;;) {   // the field only grows
+        if (((old >> sh) & 3) >= val) break;
+        const u64 seen = atomic_cas64(wp, old, (old & ~(3ull << sh)) | (val << sh));
+        if (seen == old) break;
+        old = seen;
+      }
+      continue;
+    }
+    if (!item) continue;
+    const KTab &t = kind == MAIL_S ? cfg.g_s : cfg.g_b;
+    const u64 v = item >> t.cbits;
+    const u32 sub = sb_owner(&cfg, v << (64 - 2 * t.k));
+    u64 *sl = t.slots + (u64)sub * t.stride;
+    u64 p = tab_home(t, v);
+    for (u64 k = 0; k <= t.cap_mask; ++k) {
+      u64 it = sl[p];
+      if (!it) {
+        const u64 seen = atomic_cas64(&sl[p], 0, item);
+        if (seen == 0) {
+#ifndef FQSX_EMU
+          atomicAdd(&t.filled[sub], 1u);
+#else
+          t.filled[sub] += 1;
+#endif
+          break;
+        }
+        it = seen;
+      }
+      if ((it >> t.cbits) == v) {   // (counts of a k-mer only grow: the larger value is the later one)
+        u64 old = it;
+        while ((old & ((1ull << t.cbits) - 1ull)) < (item & ((1ull << t.cbits) - 1ull))) {
+          const u64 seen = atomic_cas64(&sl[p], old, item);
+          if (seen == old) break;
+          old = seen;
+        }
+        break;
+      }
+      p = (p + 1) & t.cap_mask;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // backend
 #ifndef FQSX_EMU
@@ -982,6 +1134,178 @@ int fqsx_dna_decode_block(fqsx_dna *c, const uint8_t *const *streams, const uint
   return encode_block_impl(c, nullptr, c->d_off, off, n_reads, generation, nullptr, nullptr, streams, lens, bases_out);
 }
 
+// ---- sharded mode: one synchronisation phase in steps, with the collectives in between left to the caller ----------
+// (fqsqueezer_amd/sharded.py drives these with torch.distributed: RCCL on GPUs, gloo for the emulation build).
+// Pointers marked [codec] are in the codec's memory space: device memory for the HIP build.
+int fqsx_shard_config(fqsx_dna *c, uint32_t rank, uint32_t world) {
+  if (!c || world == 0 || rank >= world || world > c->T) { g_err = "bad rank / world size"; return FQSX_E_ARG; }
+  if (c->paired && world > 1) { g_err = "the sharded mode covers the single-end modes"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  const u32 T = c->T;
+  c->shard_rank = rank; c->shard_world = world;
+  c->cfg.shard_rank = rank; c->cfg.shard_world = world;
+  // groups of the partitioned mailboxes in rank-major order: what goes to one rank is contiguous
+  u8 vm[256];
+  for (u32 i = 0; i < 256; ++i) vm[i] = (u8)i;
+  u32 v = 0;
+  for (u32 q = 0; q < world; ++q)
+    for (u32 o = q; o < T; o += world) vm[o] = (u8)v++;
+  int rc;
+  void *p = nullptr;
+  if ((rc = h2d(c, c->d_vmap, vm, 256))) return rc;
+  if (!c->cfg.shard_cnt) {
+    if ((rc = dalloc(c, &p, 3ull * T * T * sizeof(u32), true))) return rc;
+    c->cfg.shard_cnt = (u32 *)p;
+    if ((rc = dalloc(c, &p, 3ull * T * T * sizeof(u32), true))) return rc;
+    c->d_cglob = (u32 *)p;
+  }
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  return FQSX_OK;
+}
+
+int fqsx_shard_begin_block(fqsx_dna *c, const uint8_t *bases /*[codec]*/, const uint64_t *off /*[codec]*/, const uint64_t *h_off,
+                           uint32_t n_reads, uint32_t generation, uint32_t *n_segments) {
+  if (!c || !bases || !off || !h_off || !n_segments) { g_err = "null argument"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  int rc = block_prepare(c, bases, off, h_off, n_reads, generation);
+  *n_segments = c->cur_S + 1;
+  return rc;
+}
+
+// encode launch of segment `seg` for this rank's workers, then the per-(source, owner) counts of their mailboxes
+int fqsx_shard_encode(fqsx_dna *c, uint32_t seg, uint32_t *counts /*[codec] [3][T][T]*/) {
+  if (!c || !counts) { g_err = "null argument"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  const u32 T = c->T;
+  DevCfg &cfg = c->cfg;
+  int rc;
+  if ((rc = launch_segment(c, false, c->cur_n_reads, c->cur_S, seg))) return rc;
+  const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
+  LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
+  LAUNCH(c, 2, k_shard_counts, 3 * T, 64, cfg);
+  if ((rc = d2d(c, counts, cfg.shard_cnt, 3ull * T * T * sizeof(u32)))) return rc;
+  u32 err = 0;
+  if ((rc = d2h_sync(c, &err, cfg.err, sizeof(u32)))) return rc;
+  if (err) { g_err = "device error " + std::to_string(err) + " in encode kernel"; return FQSX_E_DEVICE; }
+  return FQSX_OK;
+}
+
+// the entries of this rank's workers in send order (destination rank, owner, source, push) -> send[kind]
+int fqsx_shard_pack(fqsx_dna *c, const uint32_t *counts_sum /*[codec] summed over ranks*/, uint64_t *const send[3] /*[codec]*/) {
+  if (!c || !counts_sum || !send) { g_err = "null argument"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  const u32 T = c->T;
+  DevCfg &cfg = c->cfg;
+  int rc;
+  if ((rc = d2d(c, c->d_cglob, counts_sum, 3ull * T * T * sizeof(u32)))) return rc;
+  const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
+  LAUNCH(c, 2, k_part_scan, 3 * T, 64, cfg);
+  LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand);
+  LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg);
+  std::vector<u32> tot(3 * (T + 1));
+  for (u32 k = 0; k < 3; ++k)
+    if ((rc = d2h_sync(c, tot.data() + k * (T + 1), cfg.mail[k].dst_off, (T + 1) * sizeof(u32)))) return rc;
+  for (u32 k = 0; k < 3; ++k) {
+    const u64 n = tot[k * (T + 1) + T];
+    if (n && (rc = d2d(c, send[k], cfg.mail[k].sorted, n * sizeof(u64)))) return rc;
+  }
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  return FQSX_OK;
+}
+
+// received entries (chunks of ranks 0..G-1 back to back) -> this rank's owners' groups; need[0/1] = this rank's table
+// demand for the s- / b-mer tables (occupied + incoming slots of its fullest sub-table)
+int fqsx_shard_merge(fqsx_dna *c, const uint64_t *const recv[3] /*[codec]*/, uint64_t need[2]) {
+  if (!c || !recv || !need) { g_err = "null argument"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  const u32 T = c->T;
+  DevCfg &cfg = c->cfg;
+  int rc;
+  for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_shard_merge, T, 64, cfg, k, recv[k], (const u32 *)c->d_cglob);
+  need[0] = need[1] = 0;
+  std::vector<u32> tot(T), fil(T);
+  for (int which = 0; which < 2; ++which) {
+    const KTab &t = which ? cfg.g_b : cfg.g_s;
+    if ((rc = d2h_sync(c, tot.data(), cfg.mail[which ? MAIL_B : MAIL_S].dst_tot, T * sizeof(u32)))) return rc;
+    if ((rc = d2h_sync(c, fil.data(), t.filled, T * sizeof(u32)))) return rc;
+    for (u32 o = 0; o < T; ++o) need[which] = std::max<u64>(need[which], (u64)tot[o] + fil[o]);
+  }
+  return FQSX_OK;
+}
+
+// the insert phase of this rank's owners (after every rank has agreed on the tables' demand), then one item per
+// applied entry for the other ranks' replicas; siv_delta = this rank's contribution to (no_updates, no_filled)
+int fqsx_shard_insert(fqsx_dna *c, uint64_t need_s, uint64_t need_b, uint64_t *const items[3] /*[codec]*/, uint64_t siv_delta[2]) {
+  if (!c || !items || !siv_delta) { g_err = "null argument"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  const u32 T = c->T;
+  DevCfg &cfg = c->cfg;
+  int rc;
+  if (need_s * 2 > c->gs_cap && (rc = grow_global(c, cfg.g_s, c->gs_cap, pow2_at_least(need_s * 2 + 2)))) return rc;
+  if (need_b * 2 > c->gb_cap && (rc = grow_global(c, cfg.g_b, c->gb_cap, pow2_at_least(need_b * 2 + 2)))) return rc;
+  if ((rc = d2h_sync(c, c->siv_before, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
+  LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg);
+  u64 after[2];
+  if ((rc = d2h_sync(c, after, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
+  siv_delta[0] = after[0] - c->siv_before[0];
+  siv_delta[1] = after[1] - c->siv_before[1];
+  for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_shard_collect, REHASH_GRID, 256, cfg, k, items[k]);
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  return FQSX_OK;
+}
+
+// another rank's items of one kind into this rank's replica
+int fqsx_shard_apply(fqsx_dna *c, uint32_t kind, const uint64_t *items /*[codec]*/, uint64_t n) {
+  if (!c || kind > 2 || (!items && n)) { g_err = "bad argument"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  if (n) LAUNCH(c, 2, k_shard_apply, REHASH_GRID, 256, c->cfg, kind, items, (u32)n);
+  return FQSX_OK;
+}
+
+// end of the phase: the p-mer vector's statistics become the sum over the ranks, the local tables are cleared
+int fqsx_shard_end_phase(fqsx_dna *c, const uint64_t siv_delta_sum[2]) {
+  if (!c || !siv_delta_sum) { g_err = "null argument"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  int rc;
+  u64 now[2] = {c->siv_before[0] + siv_delta_sum[0], c->siv_before[1] + siv_delta_sum[1]};
+  if ((rc = h2d(c, c->cfg.siv_stats, now, 2 * sizeof(u64)))) return rc;
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  return clear_local_tables(c);
+}
+
+// streams of the block (only those of this rank's workers are meaningful)
+int fqsx_shard_finish_block(fqsx_dna *c, const uint64_t *h_off, const uint8_t **streams, uint64_t *lens) {
+  if (!c || !h_off || !streams || !lens) { g_err = "null argument"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  return block_finish(c, h_off, streams, lens, nullptr);
+}
+
 int fqsx_dna_stats(fqsx_dna *c, uint64_t out[48]) {
   if (!c || !out) return FQSX_E_ARG;
   LAUNCH(c, 2, k_gather_stats, 1, 64, c->cfg, c->d_lens + c->T);
@@ -1133,9 +1457,21 @@ int fqsx_qual_create(const uint8_t *h, int device, fqsx_qual **out) {
   return FQSX_OK;
 }
 
+static int qual_encode_impl(fqsx_qual *q, const uint8_t *quals, const uint8_t *d_quals, const uint64_t *d_off_in, const uint64_t *off,
+                            uint32_t n_reads, const uint8_t **streams, uint64_t *lens);
 int fqsx_qual_encode_block(fqsx_qual *q, const uint8_t *quals, const uint64_t *off, uint32_t n_reads, const uint8_t **streams,
                            uint64_t *lens) {
   if (!q || !quals || !off || !streams || !lens) { g_err = "null argument"; return FQSX_E_ARG; }
+  return qual_encode_impl(q, quals, nullptr, nullptr, off, n_reads, streams, lens);
+}
+int fqsx_qual_encode_block_dev(fqsx_qual *q, const uint8_t *d_quals, const uint64_t *d_off, const uint64_t *h_off, uint32_t n_reads,
+                               const uint8_t **streams, uint64_t *lens) {
+  if (!q || !d_quals || !d_off || !h_off || !streams || !lens) { g_err = "null argument"; return FQSX_E_ARG; }
+  return qual_encode_impl(q, nullptr, d_quals, d_off, h_off, n_reads, streams, lens);
+}
+// quals (host) or d_quals / d_off_in (already in device memory); off = host copy of the offsets
+static int qual_encode_impl(fqsx_qual *q, const uint8_t *quals, const uint8_t *d_quals, const uint64_t *d_off_in, const uint64_t *off,
+                            uint32_t n_reads, const uint8_t **streams, uint64_t *lens) {
   fqsx_dna *c = &q->mem;
   QualCfg &cfg = q->cfg;
   const u32 T = q->T;
@@ -1178,12 +1514,17 @@ int fqsx_qual_encode_block(fqsx_qual *q, const uint8_t *quals, const uint64_t *o
     if ((rc = dalloc(c, &p, need_out * T, false))) return rc;
     cfg.out = (u8 *)p; cfg.out_cap = q->out_cap = need_out;
   }
-  if (nq > q->q_cap) { dfree(c, q->d_q); if ((rc = dalloc(c, &p, nq + nq / 4, false))) return rc; q->d_q = (u8 *)p; q->q_cap = nq + nq / 4; }
-  if (no > q->off_cap) { dfree(c, q->d_off); if ((rc = dalloc(c, &p, no + no / 4, false))) return rc; q->d_off = (u64 *)p; q->off_cap = no + no / 4; }
-  if ((rc = h2d(c, q->d_q, quals, off[n_reads]))) return rc;
-  if ((rc = h2d(c, q->d_off, off, no))) return rc;
-  cfg.quals = q->d_q;
-  cfg.off = q->d_off;
+  if (d_quals) {
+    cfg.quals = d_quals;
+    cfg.off = d_off_in;
+  } else {
+    if (nq > q->q_cap) { dfree(c, q->d_q); if ((rc = dalloc(c, &p, nq + nq / 4, false))) return rc; q->d_q = (u8 *)p; q->q_cap = nq + nq / 4; }
+    if (no > q->off_cap) { dfree(c, q->d_off); if ((rc = dalloc(c, &p, no + no / 4, false))) return rc; q->d_off = (u64 *)p; q->off_cap = no + no / 4; }
+    if ((rc = h2d(c, q->d_q, quals, off[n_reads]))) return rc;
+    if ((rc = h2d(c, q->d_off, off, no))) return rc;
+    cfg.quals = q->d_q;
+    cfg.off = q->d_off;
+  }
   LAUNCH(c, 0, k_qual_encode, T, 64, cfg, n_reads);
   if ((rc = d2h_sync(c, q->h_lens.data(), cfg.lens, T * sizeof(u64)))) return rc;
   u32 err = 0;

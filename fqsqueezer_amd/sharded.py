@@ -1,0 +1,140 @@
+"""One .fqs file's DNA path sharded over the GPUs of a node (BASELINE configs[3]).
+
+Logical worker w of the T the bitstream fixes -- its coder state, RNG streams, local tables and the k-mer sub-tables it
+owns (owner = function of the k-mer's prefix, fqs/dna.cpp:825; p-mers: index range, :658) -- lives on rank w % world,
+one process per GPU.  Every rank holds a replica of all sub-tables for the look-ups.  One synchronisation phase of the
+reference (the T x T mailboxes of fqs/application.h:56-59, applied by their owners in fqs/dna.cpp:2393-2472) becomes:
+
+    encode (own workers)                                     fqsx_shard_encode
+    all-reduce  per-(source, owner) entry counts, 3 T^2 u32  -> every rank knows every transfer size
+    pack own workers' entries by (rank, owner, source, push)  fqsx_shard_pack
+    all-to-all  the three mailboxes (u64 keys)                -> keys reach the rank of their owner, in (source, push) order
+    merge into the owners' groups                             fqsx_shard_merge
+    all-reduce(max) table demand                              -> all replicas grow alike
+    insert phase of own owners (their RNG streams stay here)  fqsx_shard_insert
+    all-gather  one (k-mer, final count) item per applied key -> the other replicas take the owners' new slot values over
+    apply to the replicas                                     fqsx_shard_apply
+    all-reduce  p-mer vector statistics; clear local tables   fqsx_shard_end_phase
+
+The collectives are torch.distributed's: backend "nccl" is RCCL over xGMI on MI355X (tensors in HBM, no host staging);
+the world_size-2 CPU test runs the same driver over gloo with the emulation build of the kernels.  The per-worker
+streams are bit-identical to the one-GPU run's (tests/test_sharded_cpu.py), so the file a sharded run writes is the
+same file.  With T <= 255 workers already concurrent on one GPU this mode cannot be faster than one GPU for one file
+(DESIGN.md section 4 has the measured / counted overhead); replicas (bench.py --gpus N) remain the throughput mode.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .codec import DnaCodec, FqsxError
+
+
+class ShardedDnaCodec:
+    def __init__(self, header: bytes, rank: int, world: int, device: int = 0, lib_path: Optional[str] = None,
+                 tensor_device: Optional[torch.device] = None, group=None, apply_own: bool = False):
+        self.codec = DnaCodec(header, device=device, lib_path=lib_path)
+        self._lib, self._h, self.T = self.codec._lib, self.codec._h, self.codec.T
+        self.rank, self.world, self.group = rank, world, group
+        self.apply_own = apply_own   # tests: also run the replica update on this rank's own items (must change nothing)
+        # exchange buffers live in the codec's memory space: HBM for the HIP build, host memory for the emulation build
+        self.dev = tensor_device if tensor_device is not None else torch.device("cuda", device)
+        L = self._lib
+        L.fqsx_shard_config.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.fqsx_shard_begin_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.fqsx_shard_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.fqsx_shard_pack.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.fqsx_shard_merge.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.fqsx_shard_insert.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.fqsx_shard_apply.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+        L.fqsx_shard_end_phase.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.fqsx_shard_finish_block.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        self._ck(L.fqsx_shard_config(self._h, rank, world), "fqsx_shard_config")
+        self.own_workers = list(range(rank, self.T, world))
+        # accounting of what crosses the links (bytes this rank sends, collectives issued)
+        self.traffic = {"phases": 0, "collectives": 0, "all_to_all_bytes": 0, "all_gather_bytes": 0, "all_reduce_bytes": 0}
+
+    def _ck(self, rc: int, what: str) -> None:
+        if rc:
+            raise FqsxError(f"{what}: {rc}: {self._lib.fqsx_last_error().decode()}")
+
+    def _ptrs(self, tensors):
+        return (C.c_void_p * 3)(*[t.data_ptr() for t in tensors])
+
+    def encode_block(self, bases: np.ndarray, read_off: np.ndarray, generation: int) -> Dict[int, bytes]:
+        """All ranks call this with the same block; returns {worker: DNA stream} for this rank's workers."""
+        T, G, me, L, dev = self.T, self.world, self.rank, self._lib, self.dev
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        t_bases = torch.from_numpy(bases).to(dev)
+        t_off = torch.from_numpy(read_off.view(np.int64)).to(dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        nseg = C.c_uint32()
+        self._ck(L.fqsx_shard_begin_block(self._h, t_bases.data_ptr(), t_off.data_ptr(), read_off.ctypes.data, len(read_off) - 1,
+                                          generation, C.byref(nseg)), "fqsx_shard_begin_block")
+        for seg in range(nseg.value):
+            self._phase(seg)
+        streams = (C.c_void_p * T)()
+        lens = (C.c_uint64 * T)()
+        self._ck(L.fqsx_shard_finish_block(self._h, read_off.ctypes.data, streams, lens), "fqsx_shard_finish_block")
+        return {w: (C.string_at(streams[w], lens[w]) if lens[w] else b"") for w in self.own_workers}
+
+    def _sync(self):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+
+    def _phase(self, seg: int) -> None:
+        T, G, me, L, dev, tr = self.T, self.world, self.rank, self._lib, self.dev, self.traffic
+        counts = torch.zeros(3 * T * T, dtype=torch.int32, device=dev)
+        self._sync()
+        self._ck(L.fqsx_shard_encode(self._h, seg, counts.data_ptr()), "fqsx_shard_encode")
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
+        self._sync()
+        Cm = counts.cpu().numpy().reshape(3, T, T).astype(np.int64)   # [kind][source][owner]
+        # transfer sizes: what rank q's workers pushed for rank r's owners
+        vol = np.stack([[[int(Cm[k][q::G][:, r::G].sum()) for r in range(G)] for q in range(G)] for k in range(3)])   # [kind][from][to]
+        send = [torch.empty(max(1, int(vol[k][me].sum())), dtype=torch.int64, device=dev) for k in range(3)]
+        self._sync()
+        self._ck(L.fqsx_shard_pack(self._h, counts.data_ptr(), self._ptrs(send)), "fqsx_shard_pack")
+        recv = []
+        for k in range(3):
+            n_out, n_in = [int(x) for x in vol[k][me]], [int(x) for x in vol[k][:, me]]
+            r = torch.empty(max(1, sum(n_in)), dtype=torch.int64, device=dev)
+            dist.all_to_all_single(r[:sum(n_in)], send[k][:sum(n_out)], n_in, n_out, group=self.group)
+            recv.append(r)
+            tr["all_to_all_bytes"] += 8 * (sum(n_out) - n_out[me])
+        self._sync()
+        need = (C.c_uint64 * 2)()
+        self._ck(L.fqsx_shard_merge(self._h, self._ptrs(recv), need), "fqsx_shard_merge")
+        t_need = torch.tensor([need[0], need[1]], dtype=torch.int64, device=dev)
+        dist.all_reduce(t_need, op=dist.ReduceOp.MAX, group=self.group)
+        self._sync()
+        n_items = [[int(vol[k][:, q].sum()) for q in range(G)] for k in range(3)]   # entries applied by rank q's owners
+        items = [torch.zeros(max(1, max(n_items[k])), dtype=torch.int64, device=dev) for k in range(3)]   # padded to the largest
+        delta = (C.c_uint64 * 2)()
+        self._ck(L.fqsx_shard_insert(self._h, int(t_need[0].item()), int(t_need[1].item()), self._ptrs(items), delta), "fqsx_shard_insert")
+        for k in range(3):
+            parts = [torch.empty_like(items[k]) for _ in range(G)]
+            dist.all_gather(parts, items[k], group=self.group)
+            self._sync()
+            for q in range(G):
+                if (q != me or self.apply_own) and n_items[k][q]:
+                    self._ck(L.fqsx_shard_apply(self._h, k, parts[q].data_ptr(), n_items[k][q]), "fqsx_shard_apply")
+            self._sync()
+            tr["all_gather_bytes"] += 8 * n_items[k][me] * (G - 1)
+        t_delta = torch.tensor([delta[0], delta[1]], dtype=torch.int64, device=dev)
+        dist.all_reduce(t_delta, op=dist.ReduceOp.SUM, group=self.group)
+        self._sync()
+        tot = (C.c_uint64 * 2)(int(t_delta[0].item()), int(t_delta[1].item()))
+        self._ck(L.fqsx_shard_end_phase(self._h, tot), "fqsx_shard_end_phase")
+        tr["phases"] += 1
+        tr["collectives"] += 1 + 3 + 1 + 3 + 1
+        tr["all_reduce_bytes"] += 4 * 3 * T * T + 16 + 16
+
+    def close(self) -> None:
+        self.codec.close()

@@ -79,6 +79,25 @@ int fqsx_dna_decode_block(fqsx_dna *, const uint8_t *const *streams, const uint6
  * [16..47] in-kernel section timers / event counts (10 ns ticks, only in -DFQSX_TIMING diagnostic builds) */
 int fqsx_dna_stats(fqsx_dna *, uint64_t out[48]);
 
+/* Sharded mode (reference: the T x T mailboxes of fqs/application.h:56-59 and their owner-side
+ * application, fqs/dna.cpp:825-847, :2393-2472): logical worker w -- coder state, RNG streams, local tables and the
+ * sub-tables it owns -- lives on rank w % world; every rank keeps a replica of all sub-tables for the look-ups.
+ * One synchronisation phase = encode -> [all-reduce of the per-(source, owner) counts] -> pack -> [all-to-all of the three
+ * mailboxes] -> merge -> [all-reduce(max) of the table demand] -> insert -> [all-gather of the applied items] -> apply ->
+ * [all-reduce of the p-mer statistics] -> end_phase; the bracketed collectives are the caller's (RCCL over xGMI through
+ * torch.distributed in fqsqueezer_amd/sharded.py).  The streams are bit-identical to the one-GPU run's.
+ * Pointers marked [codec] are in the codec's memory space (device memory). */
+int fqsx_shard_config(fqsx_dna *, uint32_t rank, uint32_t world);
+int fqsx_shard_begin_block(fqsx_dna *, const uint8_t *bases /*[codec]*/, const uint64_t *read_off /*[codec]*/, const uint64_t *h_read_off,
+                           uint32_t n_reads, uint32_t generation, uint32_t *n_segments);
+int fqsx_shard_encode(fqsx_dna *, uint32_t seg, uint32_t *counts /*[codec] [3][T][T]*/);
+int fqsx_shard_pack(fqsx_dna *, const uint32_t *counts_sum /*[codec]*/, uint64_t *const send[3] /*[codec]*/);
+int fqsx_shard_merge(fqsx_dna *, const uint64_t *const recv[3] /*[codec]*/, uint64_t need[2]);
+int fqsx_shard_insert(fqsx_dna *, uint64_t need_s, uint64_t need_b, uint64_t *const items[3] /*[codec]*/, uint64_t siv_delta[2]);
+int fqsx_shard_apply(fqsx_dna *, uint32_t kind, const uint64_t *items /*[codec]*/, uint64_t n);
+int fqsx_shard_end_phase(fqsx_dna *, const uint64_t siv_delta_sum[2]);
+int fqsx_shard_finish_block(fqsx_dna *, const uint64_t *h_read_off, const uint8_t **streams, uint64_t *lens);
+
 /* Kernel timing: when enabled every launch is bracketed by HIP events on the codec's stream.
  * out[0..2] = accumulated milliseconds of the encode-segment, insert-phase and all other
  * kernels; out[3..5] = their launch counts. */
@@ -96,6 +115,9 @@ typedef struct fqsx_qual fqsx_qual;
 int fqsx_qual_create(const uint8_t *header17, int device, fqsx_qual **out);
 int fqsx_qual_encode_block(fqsx_qual *, const uint8_t *quals, const uint64_t *read_off, uint32_t n_reads,
                            const uint8_t **streams, uint64_t *lens);
+/* Same with the block already resident in device memory (d_quals / d_read_off device pointers, h_read_off the host copy). */
+int fqsx_qual_encode_block_dev(fqsx_qual *, const uint8_t *d_quals, const uint64_t *d_read_off, const uint64_t *h_read_off,
+                               uint32_t n_reads, const uint8_t **streams, uint64_t *lens);
 void fqsx_qual_destroy(fqsx_qual *);
 
 /* Host-side (CPU) read-length stream that accompanies every DNA stream in the container

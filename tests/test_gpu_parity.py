@@ -143,6 +143,30 @@ def test_gpu_encode_decode_round_trip_many_workers():
         assert np.array_equal(dec.decode_block(streams, off, g), np.asarray(bases)), f"block {g} did not round-trip"
 
 
+def test_sharded_path_on_the_gpu_matches_plain_run():
+    """The sharded mode's kernels (count matrix, rank-major pack, merge, item collection, replica update) on the real GPU:
+    a world of one rank over RCCL -- every collective degenerates, every kernel runs (the replica update on the rank's
+    own items, which must change nothing).  The multi-rank exchange itself is covered on CPU (tests/test_sharded_cpu.py)."""
+    import torch
+    import torch.distributed as dist
+    from fqsqueezer_amd.sharded import ShardedDnaCodec
+    from fqsqueezer_amd.synth import synth_reads
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    reads = synth_reads(20000, 100, 150000, 37)
+    rec = hp.Records([b"@r%d" % i for i in range(len(reads))], reads, reads)
+    header = hp.make_header(16, "se_sorted", 1)
+    sh, one = ShardedDnaCodec(header, 0, 1, device=0, apply_own=True), gpu(header)
+    for g, idx in enumerate(hp.form_blocks(rec, "se_sorted")[:60]):
+        bases, off = hp.block_arrays(rec, idx)
+        mine, ref = sh.encode_block(bases, off, g), one.encode_block(bases, off, g)
+        assert [mine[w] for w in range(16)] == ref, f"block {g}"
+    assert sh.traffic["phases"] >= 60
+    dist.destroy_process_group()
+
+
 def test_device_and_host_entry_points_agree():
     import torch
     rec = c1_records()

@@ -1,0 +1,58 @@
+"""Sharded mode: workers w % world on rank w, mailboxes routed to their owners' rank by all-to-all,
+replicas refreshed from the owners -- world_size 2 / 3 on the gloo backend with the emulated kernels.  Every worker's
+DNA stream must be bit-identical to the one-process run's (and hence to the reference's, to which that run is pinned)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+WORKER = r'''
+import os, sys, hashlib
+sys.path.insert(0, os.environ["FQSX_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.codec import DnaCodec
+from fqsqueezer_amd.sharded import ShardedDnaCodec
+from fqsqueezer_amd.synth import synth_reads
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = os.environ["FQSX_EMU_LIB"]
+T, mode = int(os.environ["FQSX_T"]), os.environ["FQSX_MODE"]
+reads = synth_reads(6000, 90, 40000, 31)           # ~13x coverage: misses, hits, corrections, table growth
+rec = hp.Records([b"@r%d" % i for i in range(len(reads))], reads, reads)
+header = hp.make_header(T, mode, 1)
+order = np.concatenate(hp.sorted_order(rec)) if mode == "se_sorted" else np.arange(len(reads))
+blocks = [order[lo:lo + 600] for lo in range(0, len(order), 600)]        # ten blocks, several segments each
+sh = ShardedDnaCodec(header, rank, world, lib_path=lib, tensor_device=torch.device("cpu"))
+one = DnaCodec(header, lib_path=lib)                # the one-process run, for comparison (every rank runs it)
+h = hashlib.sha256()
+for g, idx in enumerate(blocks):
+    bases, off = hp.block_arrays(rec, idx)
+    mine = sh.encode_block(bases, off, g)
+    ref = one.encode_block(bases, off, g)
+    assert sorted(mine) == list(range(rank, T, world))
+    for w, s in mine.items():
+        assert s == ref[w], f"rank {rank}: block {g} worker {w} differs from the one-process run"
+        h.update(s)
+lst = [None] * world
+dist.all_gather_object(lst, (h.hexdigest(), sh.traffic))
+if rank == 0:
+    assert sh.traffic["phases"] > len(blocks) and sh.traffic["all_to_all_bytes"] > 0
+    print("SHARDED_OK", world, T, mode, lst[0][1])
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,T,mode,port", [(2, 5, "se_sorted", 29531), (3, 4, "se_original", 29532)])
+def test_sharded_streams_identical_to_one_process_run(tmp_path, built, world, T, mode, port):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, FQSX_ROOT=ROOT, FQSX_EMU_LIB=os.path.join(ROOT, "tests", "emu", "libfqsx_emu.so"), FQSX_T=str(T), FQSX_MODE=mode)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "SHARDED_OK" in r.stdout

@@ -18,7 +18,7 @@ timeout -k 10 1500 python bench.py > $O/bench.log 2>&1; echo "bench rc=$?" >> $O
 tail -2 $O/bench.log
 [ "$3" = "nopmc" ] && exit 0
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie --no-t255 --concurrent 0"
+B="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie --no-t255 --no-rows --concurrent 0"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \; ; rm -rf $O/stats
 timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1

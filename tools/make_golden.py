@@ -26,6 +26,8 @@ Fixtures (data only -- inputs are re-generated deterministically by fqsqueezer_a
   c15_pe150_s_oo_t4.json    20k pairs x 150bp, G=300kbp, seed 15, varied ids, -p -om s -qm o -im o -gs 1 (configs[4]'s modes): all streams
   c16_1M150_s_ids_t8.json   the c12 input with -om s -im o -qm n -t 8: meta / id / DNA digests -- pins the sorted read ORDER
                             (incl. the order of equal reads, which only the id stream sees) at 1 M reads
+  c17_1M150_gs3100_s_t8.json  the c12 input at the DEFAULT geometry -gs 3100 (k = 13/18/21/27; BASELINE configs[3]'s geometry on a 1 M-read
+                            prefix-sized file): DNA digests; the reference needs ~45 GiB and ~10 min (only with --only c17)
 Usage: python tools/make_golden.py [--work /tmp/w] [--only c1|c2|c3]
 """
 import argparse, hashlib, json, os, subprocess, sys
@@ -206,6 +208,8 @@ def main():
         c14_c15(a)
     if a.only in ("", "c16"):
         c16(a)
+    if a.only == "c17":
+        c17(a)
     if a.only in ("", "c3"):
         fq = os.path.join(a.work, "c3.fq")
         if not os.path.exists(fq):
@@ -289,6 +293,16 @@ def c16(a):
                                "-tmp", os.path.join(a.work, "tmpi_"), "-out", out, fq], stdout=subprocess.DEVNULL)
     meta = {"reads": 1000000, "len": 150, "genome": 7500000, "seed": 2, "gs": 8, "om": "s", "qm": "n", "im": "o", "threads": 8}
     json.dump(fdigest(out, meta), open(os.path.join(GOLD, "c16_1M150_s_ids_t8.json"), "w"))
+
+
+def c17(a):
+    fq = os.path.join(a.work, "c12.fq")
+    if not os.path.exists(fq):
+        write_fastq(fq, synth_reads(1000000, 150, 7500000, 2), seed=2)
+    out = os.path.join(a.work, "c17_s_t8.fqs")
+    run_ref(fq, out, "s", 8, 3100, a.work)
+    meta = {"reads": 1000000, "len": 150, "genome": 7500000, "seed": 2, "gs": 3100, "om": "s", "threads": 8}
+    json.dump(digest(out, meta), open(os.path.join(GOLD, "c17_1M150_gs3100_s_t8.json"), "w"))
 
 
 def ragged():
