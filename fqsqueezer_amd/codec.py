@@ -127,12 +127,12 @@ class DnaCodec:
         return out[:int(read_off[-1])]
 
     def stats(self) -> dict:
-        a = (C.c_uint64 * 48)()
+        a = (C.c_uint64 * 64)()
         rc = self._lib.fqsx_dna_stats(self._h, a)
         if rc:
             raise FqsxError(f"fqsx_dna_stats: {rc}: {self._lib.fqsx_last_error().decode()}")
         d = dict(zip(STAT_NAMES, list(a)))
-        d["timers"] = list(a)[16:48]
+        d["timers"] = list(a)[16:64]
         return d
 
     def set_profiling(self, on: bool) -> None:

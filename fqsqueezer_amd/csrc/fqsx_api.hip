@@ -63,7 +63,7 @@ FQ_KERNEL64 void k_finish_block(DevCfg cfg, u64 *lens /*[T+1]*/) {
 }
 // gathers the per-worker accounting counters: out[i] = sum over workers of stat[i]
 FQ_KERNEL64 void k_gather_stats(DevCfg cfg, u64 *out) {
-  for (u32 i = FQ_LANE; i < 48; i += FQ_WAVE) {
+  for (u32 i = FQ_LANE; i < 64; i += FQ_WAVE) {
     u64 s = 0;
     for (u32 t = 0; t < cfg.T; ++t) s += cfg.ws[t].stat[i];
     out[i] = s;
@@ -990,7 +990,7 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   if ((rc = dalloc(c, &p, sizeof(u32) * 4, true))) return rc;
   cfg.err = (u32 *)p;
 #ifdef FQSX_TIMING
-  if ((rc = dalloc(c, &p, (u64)FQSX_TRACE_LAUNCHES * T * 8 * sizeof(u64), true))) return rc;
+  if ((rc = dalloc(c, &p, (u64)FQSX_TRACE_LAUNCHES * T * FQSX_TRACE_W * sizeof(u64), true))) return rc;
   cfg.trace = (u64 *)p;
 #endif
   if ((rc = dalloc(c, &p, (4 * (u64)T + 1) * sizeof(u32), true))) return rc;
@@ -1306,10 +1306,10 @@ int fqsx_shard_finish_block(fqsx_dna *c, const uint64_t *h_off, const uint8_t **
   return block_finish(c, h_off, streams, lens, nullptr);
 }
 
-int fqsx_dna_stats(fqsx_dna *c, uint64_t out[48]) {
+int fqsx_dna_stats(fqsx_dna *c, uint64_t out[64]) {
   if (!c || !out) return FQSX_E_ARG;
   LAUNCH(c, 2, k_gather_stats, 1, 64, c->cfg, c->d_lens + c->T);
-  return d2h_sync(c, out, c->d_lens + c->T, 48 * sizeof(u64));
+  return d2h_sync(c, out, c->d_lens + c->T, 64 * sizeof(u64));
 }
 
 // timing builds: the role time stamps of the first `max_launches` encode launches ([launch][worker][8], 10 ns ticks);
@@ -1317,7 +1317,7 @@ int fqsx_dna_stats(fqsx_dna *c, uint64_t out[48]) {
 int fqsx_dna_trace(fqsx_dna *c, uint64_t *out, uint32_t max_launches) {
   if (!c || !out || !c->cfg.trace) return 0;
   u32 n = (u32)std::min<u64>(std::min<u64>(c->k_n[0], FQSX_TRACE_LAUNCHES), max_launches);
-  if (n && d2h_sync(c, out, c->cfg.trace, (u64)n * c->T * 8 * sizeof(u64))) return 0;
+  if (n && d2h_sync(c, out, c->cfg.trace, (u64)n * c->T * FQSX_TRACE_W * sizeof(u64))) return 0;
   return (int)n;
 }
 

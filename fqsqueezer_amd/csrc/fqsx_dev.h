@@ -11,7 +11,7 @@
 #define FQSX_RR 6u
 #define FQSX_SW 4u    // Hamming-1 sweeps a scout wave keeps in flight (one probe of each per lane)
 #define FQSX_SCR 3u   // scout ring: chunks the scout waves may be ahead of their release
-#define FQSX_NSC 2u   // scout waves of a worker: chunk number c of an epoch is made by scout c % FQSX_NSC, in ring slot c % FQSX_SCR
+#define FQSX_NSC 3u   // scout waves of a worker: chunk number c of an epoch is made by scout c % FQSX_NSC, in ring slot c % FQSX_SCR
 #define FQSX_RQ 256u  // entries of the range-coder queue (power of two)
 // One stage-P chunk: everything about positions i0..i0+n-1 of a read that does not depend on the adaptive models,
 // computed one position per lane under the assumption "no k-mer correction since the k-mers stage P started from".
@@ -206,6 +206,7 @@ struct Wk {
   bool sc_abandoned;                    // ... but no longer for the current read (the wave went on without them)
   u32 sc_read;                          // index of the current read within the launch
   u32 sc_epoch;                         // restart epoch this wave is in (resolving wave: the one it expects chunks of)
+  bool sc_poll;                         // scout wave: stage P gives up as soon as a restart request is pending
   u32 sc_taken;                         // scout chunks of the current epoch released so far
   HeadRec *rec;                         // read-head wave: where the head's output goes (null: code / push directly)
   bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
@@ -214,16 +215,19 @@ struct Wk {
   u32 rq_tail;                          // ... this wave's copy of its index
   u64 c_r_sym;                          // coder: ctx_r_sym, the last 8 rank-0 flags (dna.cpp:664-671)
   u64 st[ST_N];
-  u64 tm[32];
+  u64 tm[FQSX_TM_SLOTS];
   u32 err;
 };
 // role time stamps of one launch (timing builds): 0 resolve start, 1 head end, 2 resolve end, 3 coder end, 4 scout end,
 // 5 inserter end, 6 resolve: reads done (before the final flush of the local inserts)
 #define FQSX_TRACE_LAUNCHES 4096u
+#define FQSX_TRACE_W 16u   /* 8 clock stamps + 8 per-launch counters of the resolving wave */
 #ifdef FQSX_TIMING
-#define TM_STAMP(cfg, tid, launch, slot) do { if ((cfg).trace && (launch) < FQSX_TRACE_LAUNCHES && FQ_LANE == 0) (cfg).trace[((u64)(launch) * (cfg).T + (tid)) * 8 + (slot)] = fq_clock(); } while (0)
+#define TM_STAMP(cfg, tid, launch, slot) do { if ((cfg).trace && (launch) < FQSX_TRACE_LAUNCHES && FQ_LANE == 0) (cfg).trace[((u64)(launch) * (cfg).T + (tid)) * FQSX_TRACE_W + (slot)] = fq_clock(); } while (0)
+#define TM_TRACE_VAL(cfg, tid, launch, slot, v) do { if ((cfg).trace && (launch) < FQSX_TRACE_LAUNCHES && FQ_LANE == 0) (cfg).trace[((u64)(launch) * (cfg).T + (tid)) * FQSX_TRACE_W + (slot)] = (v); } while (0)
 #else
 #define TM_STAMP(cfg, tid, launch, slot) ((void)0)
+#define TM_TRACE_VAL(cfg, tid, launch, slot, v) ((void)0)
 #endif
 #ifdef FQSX_TIMING
 #define TM_BEGIN(v) u64 v = fq_clock()
@@ -1912,7 +1916,8 @@ FQ_DEV u32 repair_decide(const Wk &w, const C4 &c, u32 sym) {
 // repair decision; it also prepares the position's mailbox entries.
 // The k-mers in w are the state before position i0 - joff (joff = 0: before the chunk itself; the scout wave starts
 // every chunk of a read from the state after the read's prefix).
-FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed, u32 joff = 0) {
+// Returns false if the wave gave the chunk up because a restart request came in (scout waves only).
+FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed, u32 joff = 0) {
   const DevCfg *cfg = w.cfg;
   u64 ns = 0, nls = 0;
   u32 np = 0, nlp = 0;
@@ -1922,6 +1927,7 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
   for (u32 j = FQ_LANE; j < FQSX_SPEC; j += FQ_WAVE) { w.sb->rr_idx[j] = 0xff; w.sb->ep_off[j][0] = 0xff; w.sb->ep_off[j][1] = 0xff; }
   if (FQ_LANE == 0) w.sb->rr_front = FQSX_SPEC;
   const u32 b0 = i0 - joff;   // position the k-mers in w stand before
+  bool gave_up = false;
   for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
     // roll the six k-mers J symbols forward in closed form: only the last min(J, k) new symbols matter
     u64 fw = 0, rv = 0;   // new symbols packed oldest-first (fw) and complemented newest-first (rv)
@@ -1956,6 +1962,7 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
     C4 c;
     c4_zero(c);
     const bool b_full = bm.cur == cfg->gb.k;
+    if (w.sc_poll && lds_load_acq(&w.sm->sc_req_seq) != w.sc_epoch) { gave_up = true; break; }   // (the same answer in every lane that asks)
     if (b_full) {
       bool nd = km_norm_dir(bm, cfg->gb);
       u64 key = nd ? bm.dir : bm.rc;
@@ -2041,11 +2048,13 @@ FQ_DEV void speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
     w.sb->pv_pr[j] = km_aligned_rc(pm);
     w.sb->pv_flag[j] = (u8)pf;
   }
+  if (wave_any(gave_up)) return false;   // (decided for the whole wave: the lanes beyond the chunk did not ask)
   FQ_SYNC();
   np = wave_sum32(np); nlp = wave_sum32(nlp);
   ns = wave_sum64(ns); nls = wave_sum64(nls);
   if (FQ_LANE == 0) { w.sb->h_np = np; w.sb->h_nlp = nlp; w.sb->h_ns = ns; w.sb->h_nls = nls; }
   FQ_SYNC();
+  return true;
 }
 // a stage-P chunk becomes the one the resolving wave works on
 FQ_DEV void spec_adopt(Wk &w) {
@@ -2649,10 +2658,12 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         // letter-coded, stage P's mailbox entries stand (p-mer included), nothing draws from an RNG and no repair
         // can fire (dna.cpp:706-744,776-785,840-874) -- settled for the whole stretch in one lane-parallel step.
         u32 spins = 0, front;
+        TM_BEGIN(t_rrw);
         while ((front = lds_load_acq(&w.sb->rr_front)) <= j) {   // the scout wave may still be sweeping this chunk
           fq_sleep();
           if (++spins > (1u << 22)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
         }
+        TM_END(w, TM_RRWAIT, t_rrw);
         const u32 t = FQ_LANE;
         const bool empty = t < front && t < n && ((Qm >> t) & 1) && w.sb->rr_idx[t] == 0xfe && w.sb->rc_hit[t] == 0;
         const u64 run = wave_ballot(empty) >> j;
@@ -2721,7 +2732,6 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           smj.dir = w.sb->sp_sdir[1][j]; smj.rc = w.sb->sp_src[1][j]; smj.cur = w.sb->sp_scur[1][j];
           bool conflict = pend_conflict(w, 0, cfg->gb, bmj, q_done, j);
           if (!conflict && !(xf & (SX_LB | SX_S))) conflict = pend_conflict(w, 1, cfg->gs, smj, q_done, j);
-          if (conflict) TM_COUNT(w, CN_CONFLICT);
           if (!conflict) {
             resolved = true;
             TM_COUNT(w, CN_EXT);
@@ -2739,10 +2749,12 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
               TM_COUNT(w, CN_ROUGH);
               {   // the scout wave may still be sweeping this chunk
                 u32 spins = 0;
+                TM_BEGIN(t_rrw);
                 while (lds_load_acq(&w.sb->rr_front) <= j) {
                   fq_sleep();
                   if (++spins > (1u << 22)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
                 }
+                TM_END(w, TM_RRWAIT, t_rrw);
               }
               const u32 rr = w.sb->rr_idx[j];
               if (rr != 0xff) rough = rough_merge_pre(w, rr, j, cfg->gb, RNG_B, CINC_B, counts);
@@ -3019,7 +3031,7 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
   w.sb = &sm->sb[0];
   w.scout = false;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
-  for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
+  for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) w.tm[i] = 0;
   w.rcq = SPLIT;
   w.rq_tail = 0;
   if (!SPLIT) {
@@ -3060,7 +3072,7 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
   if (FQ_LANE == 0) {
     for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
 #ifdef FQSX_TIMING
-    for (u32 i = 0; i < 32; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
+    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
 #endif
   }
   if (w.err) *cfg.err = w.err;
@@ -3084,7 +3096,7 @@ FQ_DEV void rc_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg, u
   w.rcq = false;
   w.scout = false;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
-  for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
+  for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) w.tm[i] = 0;
   if (seg == 0) enc_open(w, 0, 0xff00000000000000ULL, 0, cfg);   // application.cpp:624-628
   else enc_open(w, ws->rc_low, ws->rc_range, ws->out_len, cfg);
   u32 head = 0, spins = 0;
@@ -3127,7 +3139,7 @@ FQ_DEV void rc_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg, u
   if (FQ_LANE == 0) {
     for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
 #ifdef FQSX_TIMING
-    for (u32 i = 0; i < 32; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
+    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
 #endif
   }
   if (w.err) *cfg.err = w.err;
@@ -3198,7 +3210,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
   w.sb = &sm->sb[0];
   w.cq_head = w.cq_tail = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
-  for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
+  for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) w.tm[i] = 0;
   const u64 T = cfg.T;
   u64 first = (u64)tid * n_reads / T, last = ((u64)tid + 1) * n_reads / T;   // PartitionForWorkers, reads_block.h:197-214
   if (tid) first &= ~1ull;
@@ -3210,9 +3222,12 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
   for (u64 i = cur; i < stop && !w.err; ++i) {
     const u32 idx = (u32)(i - cur);
     u32 spins = 0;
-    for (;;) {   // both records in use: by the resolving wave or by a scout wave
-      bool busy = (i32)(idx - lds_load_acq(&sm->hd_taken)) >= 2;
-      for (u32 x = 0; x < FQSX_NSC; ++x) busy |= (i32)(idx - lds_load_acq(&sm->sc_hd_taken[x])) >= 2;
+    for (;;) {   // both records in use: by the resolving wave, by a scout wave, or by a restart request not yet taken up
+      bool busy = (i32)(idx - lds_load_acq(&sm->hd_taken)) >= 2;   // (read first: a request is posted before hd_taken moves on)
+      if (!lds_load_acq(&sm->sc_dead)) {
+        const u32 req = lds_load_acq(&sm->sc_req_seq);
+        for (u32 x = 0; x < FQSX_NSC; ++x) busy |= lds_load_acq(&sm->sc_ack[x]) != req || (i32)(idx - lds_load_acq(&sm->sc_hd_taken[x])) >= 2;
+      }
       if (!busy) break;
       fq_sleep();
       if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
@@ -3275,10 +3290,11 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
   w.piped = false;
   w.rcq = false;
   w.lqh = true;    // (reads the inserter wave's progress)
+  w.sc_poll = true;
   w.rec = nullptr;
   w.scout = false;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
-  for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
+  for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) w.tm[i] = 0;
   for (u32 i = 0; i < 4; ++i) w.s_let[i] = ws->s_letters[i];
   const u64 T = cfg.T;
   u64 first = (u64)tid * n_reads / T, last = ((u64)tid + 1) * n_reads / T;   // PartitionForWorkers, reads_block.h:197-214
@@ -3301,7 +3317,9 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       // every read has its chunks; stay until the resolving wave has finished the last read (it may still ask for a restart)
       if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; continue; }
       if ((i32)(lds_load_acq(&sm->hd_taken) - n_seg) >= 0 || lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead)) break;
+      TM_BEGIN(t_id);
       fq_sleep();
+      TM_END(w, TM_SC_IDLE, t_id);
       continue;
     }
     if (!restart) {
@@ -3318,7 +3336,11 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
     bool from_head = true;
     if (restart) {   // take up the request: acknowledge, and go on only when every scout wave has (no slot is written by two)
       restart = false;
-      for (;;) {
+#if FQSX_NSC == FQSX_SCR
+      // every scout wave owns one ring slot (chunk c: wave and slot c % FQSX_NSC): nothing to agree on, go right on
+      w.sc_epoch = lds_load_acq(&sm->sc_req_seq);
+#else
+      for (;;) {   // no slot may be written by two waves: nobody starts the new epoch before all have left the old one
         w.sc_epoch = lds_load_acq(&sm->sc_req_seq);
         FQ_SYNC();
         lds_store_rel(&sm->sc_ack[me], w.sc_epoch);
@@ -3333,6 +3355,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         if (all || quit) break;
       }
       if (quit) break;
+#endif
       const WgShared::ScoutReq &q = sm->sc_req;
       idx = uniform32(q.read);
       base_pos = uniform32(q.i0);
@@ -3350,6 +3373,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       // request was posted from (hd_taken); from now on this wave's own progress word protects them again.
       FQ_SYNC();
       lds_store_rel(&sm->sc_hd_taken[me], idx);
+      lds_store_rel(&sm->sc_ack[me], w.sc_epoch);   // (the read-head wave keeps the records until every scout is here)
       if (from_head) {   // the record may not be there yet
         spins = 0;
         while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
@@ -3403,9 +3427,15 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         const u32 n = size - i0 < FQSX_SPEC ? size - i0 : FQSX_SPEC;
         w.sb = &sm->sb[1 + seq % FQSX_SCR];
         lds_store_rel(&w.sb->h_pub, 0u);   // (the slot may hold a chunk of the same number from an earlier epoch)
-        speculate(w, p, size, i0, n, false, i0 - base_pos);
+        TM_BEGIN(t_sp);
+        const bool whole = speculate(w, p, size, i0, n, false, i0 - base_pos);
+        TM_END(w, TM_SC_SPEC, t_sp);
+        if (!whole) { TM_COUNT(w, CN_SC_ABORT); restart = true; break; }
+        TM_COUNT(w, CN_SC_CHUNK);
 #if FQ_WAVE > 1
+        TM_BEGIN(t_se);
         if (i0 == base_pos) scout_early(w, n);   // (the look-ups of positions whose b-mer is still partial, if any)
+        TM_END(w, TM_SC_EARLY, t_se);
         const u32 front0 = scout_rough_first(w, n);
 #else
         const u32 front0 = FQSX_SPEC;
@@ -3414,7 +3444,9 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         FQ_SYNC();
         lds_store_rel(&w.sb->h_pub, seq + 1);   // the resolving wave may start on the chunk ...
 #if FQ_WAVE > 1
+        TM_BEGIN(t_sr);
         scout_rough(w, n);                       // ... while its sweeps are still being probed (rr_front)
+        TM_END(w, TM_SC_ROUGH, t_sr);
 #endif
       }
       if (restart || quit) continue;
@@ -3424,8 +3456,10 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
     lds_store_rel(&sm->sc_hd_taken[me], idx + 1);
     ++idx;
   }
+  if (lds_load_acq(&sm->sc_dead)) lds_store_rel(&sm->sc_hd_taken[me], 0x7fffffffu);   // (the read-head wave does not wait for a scout that has left)
 #ifdef FQSX_TIMING
-  if (FQ_LANE == 0 && w.tm[TM_SCOUT_WAIT]) atomic_add64(&ws->stat[16 + TM_SCOUT_WAIT], w.tm[TM_SCOUT_WAIT]);
+  if (FQ_LANE == 0)
+    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
 #endif
   if (me == 0) TM_STAMP(cfg, tid, launch, 4);
 }
@@ -3451,6 +3485,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   constexpr bool heads = PIPED && MODE == 1;   // single-end sorted: the read heads come from the read-head wave
   w.sb = &sm->sb[0];
   w.scout = heads;
+  w.sc_poll = false;
   w.sc_abandoned = false;
   w.sc_read = 0;
   w.sc_epoch = 0;
@@ -3458,7 +3493,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.cq_head = w.cq_tail = 0;
   w.c_r_sym = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
-  for (u32 i = 0; i < 32; ++i) w.tm[i] = 0;
+  for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) w.tm[i] = 0;
   TM_BEGIN(t_total);
   TM_STAMP(cfg, tid, launch, 0);
   const u64 T = cfg.T;
@@ -3580,13 +3615,18 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   ws->hidden_updates = w.hidden;
   TM_END(w, TM_TOTAL, t_total);
   TM_STAMP(cfg, tid, launch, 2);
+  // per-launch counters of this wave (timing build): what made the worker slow or fast
+  TM_TRACE_VAL(cfg, tid, launch, 8, w.tm[CN_SLOW]); TM_TRACE_VAL(cfg, tid, launch, 9, w.tm[CN_ROUGH]);
+  TM_TRACE_VAL(cfg, tid, launch, 10, w.tm[CN_DIRTY]); TM_TRACE_VAL(cfg, tid, launch, 11, w.tm[CN_FAST]);
+  TM_TRACE_VAL(cfg, tid, launch, 12, w.tm[TM_RRWAIT]); TM_TRACE_VAL(cfg, tid, launch, 13, w.tm[TM_SPEC]);
+  TM_TRACE_VAL(cfg, tid, launch, 14, w.tm[CN_GENERIC]); TM_TRACE_VAL(cfg, tid, launch, 15, w.tm[TM_LQ]);
   if (!piped) {
     for (u32 i = 0; i < ST_N; ++i) ws->stat[i] += w.st[i];
-    for (u32 i = 0; i < 32; ++i) ws->stat[16 + i] += w.tm[i];
+    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) ws->stat[16 + i] += w.tm[i];
   } else if (FQ_LANE == 0) {   // the coder wave adds to the same counters
     for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
 #ifdef FQSX_TIMING
-    for (u32 i = 0; i < 32; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
+    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
 #endif
   }
   FQ_SYNC();

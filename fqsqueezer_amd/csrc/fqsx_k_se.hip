@@ -69,7 +69,7 @@ FQ_KERNEL512 void k_encode_se_sorted(EncArgs a) {
     case 3: role_coder<true>(fq_kernarg()); break;
     case 4: role_rc(fq_kernarg()); break;
     case 5: role_inserter(fq_kernarg()); break;
-    case 6: break;   // (keeps the resolving wave's SIMD to itself)
+    case 6: role_scout<2>(fq_kernarg()); break;
     default: role_scout<1>(fq_kernarg()); break;
   }
 }

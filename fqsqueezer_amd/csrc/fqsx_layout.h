@@ -107,7 +107,7 @@ struct WState {
   u64 dec_buffer, dec_pos;             // CRangeDecoder (sub_rc.h:154-157) when the codec decodes
   u32 mt_idx[4];                       // cinc_b, cinc_s, cinc_lb, cinc_ls (dna.h:113-116)
   u32 mt[4][624];
-  u64 stat[48];                        // probe/byte accounting, see ST_*; [16..23] in-kernel section times (10 ns ticks)
+  u64 stat[64];                        // probe/byte accounting, see ST_*; [16..63] in-kernel section times (10 ns ticks; timing builds)
 };
 enum { RNG_B = 0, RNG_S = 1, RNG_LB = 2, RNG_LS = 3 };
 enum {
@@ -128,9 +128,12 @@ enum {
 // section timers (only maintained by -DFQSX_TIMING builds)
 enum { TM_TOTAL = 0, TM_SPEC, TM_FAST, TM_SLOW, TM_POST, TM_READ_HEAD, TM_LQ, TM_ROUGH, TM_REPM, TM_FINDC,
        CN_FAST, CN_SLOW, CN_CHUNK, CN_DIRTY, CN_ROUGH, CN_REPM,
-       CN_EXT, CN_GENERIC, CN_LQFLUSH, CN_CONFLICT, TM_CQWAIT /* resolver waiting for coding-queue space */, CN_EARLY, CN_P2, TM_P2,
+       CN_EXT, CN_GENERIC, CN_LQFLUSH, TM_RRWAIT /* resolver waiting for a chunk's sweep frontier */, TM_CQWAIT /* resolver waiting for coding-queue space */, CN_EARLY, CN_P2, TM_P2,
        TM_CODER_IDLE /* coder wave: queue empty */, TM_SCOUT_WAIT /* scout wave: ring full or no read head yet */, TM_SPRE,
-       TM_CR_S, TM_CR_MID, TM_CR_AVG, TM_CR_RC, TM_KEYS, TM_N };
+       TM_CR_S, TM_CR_MID, TM_CR_AVG, TM_CR_RC, TM_KEYS,
+       TM_SC_SPEC /* scout waves: stage P */, TM_SC_EARLY, TM_SC_ROUGH /* ... their sweeps */, TM_SC_IDLE /* ... nothing left to do */, CN_SC_CHUNK, CN_SC_ABORT,
+       TM_N };
+#define FQSX_TM_SLOTS 48
 
 struct DevCfg {
   u32 T, mode;                 // mode 0 = original order, 1 = sorted (params.h:18)

@@ -76,8 +76,8 @@ int fqsx_dna_decode_block(fqsx_dna *, const uint8_t *const *streams, const uint6
  * [0] global probes [1] global slots read [2] local probes [3] local slots read
  * [4] global inserts [5] slots read by them [6] siv words touched [7] context slots read
  * [8] symbols range-coded [9] local inserts [10] mailbox entries [11] input bases
- * [16..47] in-kernel section timers / event counts (10 ns ticks, only in -DFQSX_TIMING diagnostic builds) */
-int fqsx_dna_stats(fqsx_dna *, uint64_t out[48]);
+ * [16..63] in-kernel section timers / event counts (10 ns ticks, only in -DFQSX_TIMING diagnostic builds) */
+int fqsx_dna_stats(fqsx_dna *, uint64_t out[64]);
 
 /* Sharded mode (reference: the T x T mailboxes of fqs/application.h:56-59 and their owner-side
  * application, fqs/dna.cpp:825-847, :2393-2472): logical worker w -- coder state, RNG streams, local tables and the
@@ -104,7 +104,7 @@ int fqsx_shard_finish_block(fqsx_dna *, const uint64_t *h_read_off, const uint8_
 int fqsx_dna_set_profiling(fqsx_dna *, int enable);
 int fqsx_dna_kernel_times(fqsx_dna *, double out[6]);
 /* Diagnostic builds (-DFQSX_TIMING) only: per-launch, per-worker clock stamps of the five roles of the encode kernel,
- * out[launch][worker][8] in 10 ns ticks; returns the number of launches copied (always 0 in the product build). */
+ * out[launch][worker][16]: 8 stamps in 10 ns ticks + 8 per-launch counters of the resolving wave; returns the number of launches copied (always 0 in the product build). */
 int fqsx_dna_trace(fqsx_dna *, uint64_t *out, uint32_t max_launches);
 
 /* Quality stream on the GPU: replaces CQualityCompressor::Init / Compress for all T

@@ -92,6 +92,12 @@ def test_hip_matches_reference_1M_150bp_bit_exact(t):
     assert st["bases"] <= 150_000_000 and st["coded"] > 120_000_000
 
 
+def test_hip_matches_reference_default_geometry_1M():
+    """BASELINE configs[3]'s geometry (-gs 3100: k = 13/18/21/27, 16 GiB p-mer vector, up to 1024-way partial look-ups) on
+    the metric's 1 M x 150 bp file: every block hash-identical to `fqs-1.1 e -t 8 -gs 3100` (which needs 45 GiB and 10 min)."""
+    check_against_digest(gpu, "c17_1M150_gs3100_s_t8.json")
+
+
 @pytest.mark.parametrize("om", ["o", "s"])
 def test_hip_matches_reference_saturated_counters(om):
     """c13: counters at their maxima, counts_level_t::mixed / bmer_unc, probabilistic increments on s-mers (the oracle

@@ -26,7 +26,7 @@ for g, idx in enumerate(blocks):
     c.encode_block(bases, off, g)
 c._lib.fqsx_dna_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 c._lib.fqsx_dna_trace.restype = C.c_int
-buf = np.zeros((4096, T, 8), dtype=np.uint64)
+buf = np.zeros((4096, T, 16), dtype=np.uint64)
 n = c._lib.fqsx_dna_trace(c._h, buf.ctypes.data, 4096)
 names = ["head", "resolve", "models", "scout", "inserter", "range coder"]
 slots = [1, 2, 3, 4, 5, 7]   # (slot 6: resolving wave, reads done)
@@ -48,6 +48,14 @@ def report(tr, tag):
            "slowest_worker_end_us_by_role": {names[k]: round(float(np.mean([ends[i, last_worker[i], k] for i in range(n)])), 1) for k in range(len(names))},
            "resolve_reads_done_us_mean": round(float(((tr[:, :, 6] - start) * 0.01).mean()), 1),
            "p50_p90_p99_launch_us": [round(float(np.percentile(launch_len, q)), 1) for q in (50, 90, 99)]}
+    # what distinguishes the slowest worker of a launch from the average one (resolving wave's per-launch counters)
+    cn = ["slow positions", "sweeps merged", "dirty chunks", "fast positions", "sweep-frontier wait us", "scout wait us", "generic positions", "local-insert wait us"]
+    vals = tr[:, :, 8:16].astype(np.float64)
+    vals[:, :, [4, 5, 7]] *= 0.01
+    res["resolver_counters_mean_worker"] = {cn[k]: round(float(vals[:, :, k].mean()), 2) for k in range(8)}
+    res["resolver_counters_slowest_worker"] = {cn[k]: round(float(np.mean([vals[i, last_worker[i], k] for i in range(n)])), 2) for k in range(8)}
+    rend = ends[:, :, 1]   # resolving wave's end per worker
+    res["corr_resolve_end_with"] = {cn[k]: round(float(np.corrcoef(rend.reshape(-1), vals[:, :, k].reshape(-1))[0, 1]), 3) for k in range(8)}
     print(json.dumps(res))
 
 

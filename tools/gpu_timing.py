@@ -22,6 +22,8 @@ c = DnaCodec(header, lib_path=lib)
 c.set_profiling(True)
 t0 = time.time()
 n_done = 0
+if len(sys.argv) > 6 and sys.argv[6] == "warm":
+    max_blocks = min(max_blocks, 70)
 st_mid = None
 for g, idx in enumerate(blocks[:max_blocks]):
     if g == 100:
@@ -32,6 +34,8 @@ for g, idx in enumerate(blocks[:max_blocks]):
 n = n_done
 dt = time.time() - t0
 st = c.stats(); kt = c.kernel_times()
+if len(sys.argv) > 6 and sys.argv[6] == "warm":
+    max_blocks = min(max_blocks, 70)
 if st_mid is not None and len(sys.argv) > 6 and sys.argv[6] == "steady":   # report blocks >= 100 only
     st = {k: ([a - b for a, b in zip(v, st_mid[k])] if isinstance(v, list) else v - st_mid[k]) for k, v in st.items()}
     kt = {k: v - kt_mid[k] for k, v in kt.items()}
@@ -39,14 +43,18 @@ if st_mid is not None and len(sys.argv) > 6 and sys.argv[6] == "steady":   # rep
     dt = time.time() - t_mid
     print("blocks >= 100 only:")
 names = ["total", "spec", "fast", "slow", "post_q", "read_head", "lq_flush", "rough", "repair_missing", "find_counts"]
-cn = dict(zip(["n_fast", "n_slow", "n_chunk", "n_dirty", "n_rough", "n_repm", "n_ext", "n_generic", "n_lqflush", "n_conflict", "_cqwait", "n_early", "n_p2"], st["timers"][10:23]))
+cn = dict(zip(["n_fast", "n_slow", "n_chunk", "n_dirty", "n_rough", "n_repm", "n_ext", "n_generic", "n_lqflush", "_rrwait", "_cqwait", "n_early", "n_p2"], st["timers"][10:23]))
 cn["resolver: waiting for coding-queue space s"] = cn.pop("_cqwait") * 1e-8
+cn["resolver: waiting for a chunk's sweep frontier s"] = cn.pop("_rrwait") * 1e-8
 cn["coder wave: launch start to last symbol s"] = st["timers"][23] * 1e-8  # vs "total" = the resolving wave's
 cn["slow: resolve counts s"] = st["timers"][26] * 1e-8
 cn["coder wave: idle (queue empty) s"] = st["timers"][24] * 1e-8
 cn["scout wave: waiting (ring full / no head) s"] = st["timers"][25] * 1e-8
 for k, nm in enumerate(["code_run: S probes s", "code_run: same-slot+validate s", "code_run: avg loop s", "code_run: commit+rc s", "code_keys s"]):
     cn[nm] = st["timers"][27 + k] * 1e-8
+for k, nm in enumerate(["scouts: stage P s", "scouts: early look-ups s", "scouts: sweeps s", "scouts: idle at the end s"]):
+    cn[nm] = st["timers"][32 + k] * 1e-8
+cn["scouts: chunks made"], cn["scouts: chunks given up"] = st["timers"][36], st["timers"][37]
 tm = [x * 1e-8 for x in st["timers"][:10]]
 print(f"{n} reads T={T}: wall {dt:.2f}s  {n*L/dt/1e6:.2f} Mbases/s  kernels: {kt}")
 print("section seconds summed over workers:", {k: round(v, 3) for k, v in zip(names, tm)})
