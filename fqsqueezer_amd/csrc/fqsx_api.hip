@@ -55,10 +55,13 @@ FQ_KERNEL64 void k_clear_local(DevCfg cfg, u64 nb_slots, u64 ns_slots) {
   for (u64 i = first; i < ns_slots; i += stride) cfg.l_s.slots[i] = 0;
   for (u64 i = first; i < 2ull * cfg.T; i += stride) cfg.l_s.filled[i] = 0;   // l_s.filled and l_b.filled are adjacent
 }
-FQ_KERNEL64 void k_finish_block(DevCfg cfg, u64 *lens /*[T+1]*/) {
+FQ_KERNEL64 void k_finish_block(DevCfg cfg, u64 *lens /*[T+1]*/, u64 *end /*[2T+1]: lengths, context occupancies, error word*/) {
   if (FQ_LANE == 0) {
     finish_block_body(cfg, FQ_BLOCK);
     lens[FQ_BLOCK] = cfg.ws[FQ_BLOCK].out_len;
+    end[FQ_BLOCK] = cfg.ws[FQ_BLOCK].out_len;
+    end[cfg.T + FQ_BLOCK] = cfg.ctx_filled[FQ_BLOCK];
+    if (FQ_BLOCK == 0) end[2 * cfg.T] = *cfg.err;
   }
 }
 // gathers the per-worker accounting counters: out[i] = sum over workers of stat[i]
@@ -375,6 +378,9 @@ struct fqsx_dna {
   std::vector<u8> h_out;
   std::vector<u64> h_lens;
   std::vector<void *> allocs;
+  u8 *h_pin;          // pinned host scratch for the small device-to-host transfers of the phase loop
+  u64 *d_end;         // block epilogue in one transfer: [T] stream lengths, [T] context-table occupancies, error word
+  bool filled_valid;  // h_filled holds the context-table occupancies as of the end of the last encoded block
   // the block being processed (block_prepare -> block_segment ... -> block_finish)
   u32 cur_n_reads, cur_S, cur_gen;
   u64 cur_need_lb, cur_need_ls, cur_need_lpe;
@@ -441,6 +447,23 @@ int d2d(fqsx_dna *c, void *d, const void *s, u64 bytes) {
   (void)c;
   memcpy(d, s, bytes);
 #endif
+  return FQSX_OK;
+}
+#define FQSX_PIN_BYTES (64u * 1024u)
+// small transfer through the pinned scratch: begin (asynchronous), ... more launches ..., end (waits, copies out)
+int d2h_small_begin(fqsx_dna *c, const void *d, u64 bytes) {
+#ifndef FQSX_EMU
+  HIPCHK(hipMemcpyAsync(c->h_pin, d, bytes, hipMemcpyDeviceToHost, c->stream));
+#else
+  memcpy(c->h_pin, d, bytes);
+#endif
+  return FQSX_OK;
+}
+int d2h_small_end(fqsx_dna *c, void *h, u64 bytes) {
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  memcpy(h, c->h_pin, bytes);
   return FQSX_OK;
 }
 int d2h_sync(fqsx_dna *c, void *h, const void *d, u64 bytes) {
@@ -715,7 +738,8 @@ int block_prepare(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u64 *h
   cfg.l_b.cap_mask = need_lb - 1; cfg.l_b.stride = need_lb;
   cfg.l_s.cap_mask = need_ls - 1; cfg.l_s.stride = need_ls;
   // ---- context tables: every coded symbol creates at most two contexts
-  if ((rc = d2h_sync(c, c->h_filled.data(), cfg.ctx_filled, T * sizeof(u32)))) return rc;
+  if (!c->filled_valid && (rc = d2h_sync(c, c->h_filled.data(), cfg.ctx_filled, T * sizeof(u32)))) return rc;
+  c->filled_valid = false;
   {
     u64 need = 0;
     for (u32 t = 0; t < T; ++t) need = std::max<u64>(need, (u64)c->h_filled[t] + 2 * wbases[t] + 64);
@@ -786,7 +810,10 @@ int block_segment(fqsx_dna *c, u32 seg) {
     LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
     LAUNCH(c, 2, k_part_scan, 3 * T, 64, cfg);
     LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand);
-    if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, (4 * T + 1) * sizeof(u32)))) return rc;
+    // the demand travels to the host while the scatter (which does not depend on the growth decision) runs
+    if ((rc = d2h_small_begin(c, c->d_demand, (4 * T + 1) * sizeof(u32)))) return rc;
+    LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg);
+    if ((rc = d2h_small_end(c, c->h_demand.data(), (4 * T + 1) * sizeof(u32)))) return rc;
     if (c->h_demand[2 * T]) {
       g_err = "device error " + std::to_string(c->h_demand[2 * T]) + " in encode kernel";
       return FQSX_E_DEVICE;
@@ -810,7 +837,6 @@ int block_segment(fqsx_dna *c, u32 seg) {
       if ((rc = dzero(c, cfg.l_pe.val, need_lpe * T * sizeof(u64)))) return rc;
       if ((rc = dzero(c, cfg.l_pe.filled, T * sizeof(u32)))) return rc;
     }
-    LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg);
     LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg);
     if ((rc = clear_local_tables(c))) return rc;
   }
@@ -832,14 +858,18 @@ int block_finish(fqsx_dna *c, const u64 *h_off, const u8 **streams, u64 *lens, u
     }
     return d2h_sync(c, bases_out, cfg.dout, h_off[n_reads]);
   }
-  LAUNCH(c, 2, k_finish_block, T, 64, cfg, c->d_lens);
-  // ---- results
-  if ((rc = d2h_sync(c, c->h_lens.data(), c->d_lens, T * sizeof(u64)))) return rc;
-  u32 err = 0;
-  if ((rc = d2h_sync(c, &err, cfg.err, sizeof(u32)))) return rc;
-  if (err) {
-    g_err = "device error " + std::to_string(err) + " while encoding block " + std::to_string(generation);
-    return FQSX_E_DEVICE;
+  LAUNCH(c, 2, k_finish_block, T, 64, cfg, c->d_lens, c->d_end);
+  // ---- results: stream lengths, context-table occupancies (for the next block's sizing) and the error word at once
+  {
+    std::vector<u64> e(2 * T + 1);
+    if ((rc = d2h_small_begin(c, c->d_end, e.size() * sizeof(u64)))) return rc;
+    if ((rc = d2h_small_end(c, e.data(), e.size() * sizeof(u64)))) return rc;
+    for (u32 t = 0; t < T; ++t) { c->h_lens[t] = e[t]; c->h_filled[t] = (u32)e[T + t]; }
+    c->filled_valid = true;
+    if (e[2 * T]) {
+      g_err = "device error " + std::to_string(e[2 * T]) + " while encoding block " + std::to_string(generation);
+      return FQSX_E_DEVICE;
+    }
   }
   u64 total = 0;
   for (u32 t = 0; t < T; ++t) {
@@ -997,6 +1027,14 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   c->d_demand = (u32 *)p;
   if ((rc = dalloc(c, &p, ((u64)T + 64) * sizeof(u64), true))) return rc;
   c->d_lens = (u64 *)p;
+  if ((rc = dalloc(c, &p, (2 * (u64)T + 1) * sizeof(u64), true))) return rc;
+  c->d_end = (u64 *)p;
+#ifndef FQSX_EMU
+  HIPCHK(hipHostMalloc((void **)&c->h_pin, FQSX_PIN_BYTES));
+#else
+  c->h_pin = (u8 *)malloc(FQSX_PIN_BYTES);
+#endif
+  c->filled_valid = false;
   c->h_demand.assign(4 * T + 1, 0);
   c->h_filled.assign(T, 0);
   c->h_lens.assign(T + 64, 0);
@@ -1046,6 +1084,7 @@ int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) {
   c->compact_cap = 0;
   c->din_cap = c->dout_cap = 0;
   c->shard_rank = 0; c->shard_world = 1;
+  c->h_pin = nullptr; c->d_end = nullptr; c->filled_valid = false;
   c->d_vmap = nullptr; c->d_xbuf = nullptr; c->xbuf_cap = 0; c->d_cglob = nullptr;
   c->cur_n_reads = c->cur_S = c->cur_gen = 0;
   c->cur_need_lb = c->cur_need_ls = c->cur_need_lpe = 0;
@@ -1073,9 +1112,12 @@ void fqsx_dna_destroy(fqsx_dna *c) {
   std::vector<void *> a = c->allocs;
   for (void *p : a) dfree(c, p);
 #ifndef FQSX_EMU
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
+#else
+  free(c->h_pin);
 #endif
   delete c;
 }

@@ -136,6 +136,25 @@ def test_hip_worker_pipeline_matches_oracle_sorted_mode():
             assert a.encode_block(bases, off, g) == b.encode_block(bases, off, g), f"T={T} block {g}"
 
 
+def test_hip_long_reads_with_corrections_followed_by_duplicates():
+    """350 bp reads (six stage-P chunks) with substitutions -- k-mer corrections restart the scouts in mid-read -- each
+    followed by exact duplicates, which the resolving wave finishes without taking a single chunk: the case in which
+    round 1's scout ring could stay full of stale chunks.  Sorted mode, T = 16 and 64, against the oracle."""
+    from oracle.pyoracle import OracleCodec
+    from fqsqueezer_amd.synth import synth_reads
+    base = synth_reads(2500, 350, 60000, 41, sub_rate=0.01)
+    reads = np.repeat(base, 3, axis=0)[: 3 * 2500 : 1]          # every read three times
+    reads = reads[np.random.Generator(np.random.PCG64(5)).permutation(len(reads))]
+    rec = hp.Records([b"@r%d" % i for i in range(len(reads))], reads, reads)
+    for T in (16, 64):
+        header = hp.make_header(T, "se_sorted", 1)
+        a, b = gpu(header), OracleCodec(header)
+        order = np.concatenate(hp.sorted_order(rec))
+        for g, lo in enumerate(range(0, len(order) - 2 * T, 1200)):
+            bases, off = hp.block_arrays(rec, order[lo:lo + 1200])
+            assert a.encode_block(bases, off, g) == b.encode_block(bases, off, g), f"T={T} block {g}"
+
+
 def test_gpu_encode_decode_round_trip_many_workers():
     """encode -> decode entirely on the GPU at T=64 (size-independent property: the block comes back)."""
     from fqsqueezer_amd.synth import synth_reads
