@@ -10,8 +10,8 @@
 // workgroup-shared (LDS) state of one worker
 #define FQSX_RR 6u
 #define FQSX_SW 4u    // Hamming-1 sweeps a scout wave keeps in flight (one probe of each per lane)
-#define FQSX_SCR 3u   // scout ring: chunks the scout waves may be ahead of their release
-#define FQSX_NSC 3u   // scout waves of a worker: chunk number c of an epoch is made by scout c % FQSX_NSC, in ring slot c % FQSX_SCR
+#define FQSX_NSC 3u   // scout waves of a worker (paired-end kernels: 2): chunk number c of an epoch is made by scout c % nsc in ring slot
+#define FQSX_SCR FQSX_NSC   // c % nsc of its own -- a scout wave owns one slot, so a restart needs no hand-shake between the scouts
 #define FQSX_RQ 256u  // entries of the range-coder queue (power of two)
 // One stage-P chunk: everything about positions i0..i0+n-1 of a read that does not depend on the adaptive models,
 // computed one position per lane under the assumption "no k-mer correction since the k-mers stage P started from".
@@ -80,10 +80,10 @@ struct WgShared {
   u64 bk_key[256];             // probe batch: normalised k-mers
   u32 bk_res[256][4];          // probe batch: counts
   u8 bk_dir[256];              // probe batch: orientation
-  union {   // the scout ring exists in single-end sorted mode only, the paired-end scratch in the paired-end modes only
-    SpecBuf sb[1 + FQSX_SCR];  // [0] filled by the resolving wave itself, [1..] ring filled by the scout wave
+  union {   // the paired-end kernels run two scouts: their scratch lies over the third ring slot
+    SpecBuf sb[1 + FQSX_SCR];  // [0] filled by the resolving wave itself, [1..] ring filled by the scout waves
     struct {
-      SpecBuf sb_self_;        // (= sb[0])
+      SpecBuf sb_used_[FQSX_SCR];   // (= sb[0 .. 2])
       u8 r2c[FQSX_RD_LDS];     // paired-end: codes of the second mate
       u64 pe_cand[512];        // paired-end: candidate partner b-mers (value | count << 2k)
       u64 pe_top[64];
@@ -100,7 +100,9 @@ struct WgShared {
   u32 sc_ack[FQSX_NSC];
   u32 sc_dead;                 // the scout waves have given up for this launch (one found itself behind the resolving wave)
   struct ScoutReq {
-    u32 read, i0, cor_pos, n_run;   // i0 == pmer: from the head of the read (its record), the k-mers below are unused
+    u32 read, i0, cor_pos, n_run;
+    u32 flags, size;                // SCQ_*; request mode: length of the sequence being coded
+    u64 p;                          // request mode: its bases in HBM (reads longer than the LDS staging buffer)
     u64 kdir[6], krc[6];
     u32 kcur[6];
     u64 s_let[4];
@@ -169,6 +171,7 @@ FQ_DEV WgShared *fq_wg() { static thread_local WgShared s; return &s; }
 FQ_DEV const EncArgs *fq_args(FqArgsP a) { return a; }
 #endif
 enum { SX_VALID = 1, SX_LB = 2, SX_S = 4, SX_LS = 8 };
+enum { SCQ_FROM_HEAD = 1 /* base state = the read's head record */, SCQ_REVERSED = 2 /* positions count from the end (dna.cpp:750-752) */ };
 enum { SK_NONE = 0, SK_RANK = 1, SK_LETTER = 2, SK_RANK_PENDING = 3, SK_LETTER_PENDING = 4, SK_RAW = 5, SK_KIND_MASK = 7,
        SK_RESET = 8 /* the r_sym history restarts at this entry (first symbol of a compress_suffix call, dna.cpp:676) */ };
 enum { PV_B = 1, PV_S = 2, PV_P = 4, PV_PHID = 8, PV_PCAND = 16 };
@@ -207,6 +210,11 @@ struct Wk {
   u32 sc_read;                          // index of the current read within the launch
   u32 sc_epoch;                         // restart epoch this wave is in (resolving wave: the one it expects chunks of)
   bool sc_poll;                         // scout wave: stage P gives up as soon as a restart request is pending
+  u32 nsc;                              // scout waves (= ring slots) of this kernel
+  bool sc_reqmode;                      // no read-head wave: the scouts serve one request per compress_suffix call
+  const u8 *rq_p;                       // the sequence the current compress_suffix call codes (for the requests)
+  u32 rq_size;
+  bool rq_rev;
   u32 sc_taken;                         // scout chunks of the current epoch released so far
   HeadRec *rec;                         // read-head wave: where the head's output goes (null: code / push directly)
   bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
@@ -2579,13 +2587,14 @@ FQ_DEV void scout_release(Wk &w) {
 }
 // The scout waves start again: from the exact state before position i0 of read `read` (a k-mer correction), or, with
 // i0 == pmer, from the head of that read (the resolving wave has finished the read before on its own)
-FQ_DEV void scout_restart(Wk &w, u32 read, u32 i0, const u64 s_let[4]) {
+FQ_DEV void scout_restart(Wk &w, u32 read, u32 i0, const u64 s_let[4], u32 flags = 0) {
   WgShared *sm = w.sm;
   if (lds_load_acq(&sm->sc_dead)) return;
   FQ_SYNC();
   if (FQ_LANE == 0) {
     WgShared::ScoutReq &q = sm->sc_req;
     q.read = read; q.i0 = i0; q.cor_pos = w.cor_pos; q.n_run = w.N_run;
+    q.flags = flags | (w.rq_rev ? (u32)SCQ_REVERSED : 0u); q.size = w.rq_size; q.p = (u64)w.rq_p;
     const Kmer *k[6] = {&w.pm, &w.sm_, &w.bm, &w.pm_u, &w.sm_u, &w.bm_u};
     for (u32 x = 0; x < 6; ++x) { q.kdir[x] = k[x]->dir; q.krc[x] = k[x]->rc; q.kcur[x] = k[x]->cur; }
     for (u32 x = 0; x < 4; ++x) q.s_let[x] = s_let[x];
@@ -2598,7 +2607,7 @@ FQ_DEV void scout_restart(Wk &w, u32 read, u32 i0, const u64 s_let[4]) {
 }
 FQ_DEV bool scout_take(Wk &w, u32 i, u32 n) {
   WgShared *sm = w.sm;
-  SpecBuf *b = &sm->sb[1 + w.sc_taken % FQSX_SCR];
+  SpecBuf *b = &sm->sb[1 + w.sc_taken % w.nsc];
   u32 spins = 0;
   // the chunk with this number of this epoch (a slot may still hold the one of an earlier epoch with the same number)
   while (lds_load_acq(&b->h_pub) != w.sc_taken + 1 || b->h_epoch != w.sc_epoch) {
@@ -2618,6 +2627,12 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
   WgShared *sm = w.sm;
   bool first = true;   // the r_sym history starts empty (dna.cpp:676)
   u32 i = start_pos ? start_pos : original_order ? cfg->prefix : cfg->pmer;
+  w.rq_p = p; w.rq_size = size; w.rq_rev = reversed;
+  if (w.scout && w.sc_reqmode && i < size) {   // no read-head wave: this call is one request to the scout waves
+    w.sc_read += 1;
+    w.sc_abandoned = false;
+    scout_restart(w, w.sc_read, i, w.s_let);
+  }
   while (i < size && !w.err) {
     const u32 n = size - i < FQSX_SPEC ? size - i : FQSX_SPEC;
     TM_BEGIN(t_sp);
@@ -2994,7 +3009,7 @@ FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx, bool has_ne
     w.st[ST_BASES] += size;
     // the read was (partly) resolved without the scout waves: they take up again at the head of the next one
     // (posted while this read's record still counts as in use, so that the records they need are in place)
-    if (w.sc_abandoned && has_next) scout_restart(w, idx + 1, w.cfg->pmer, w.s_let);
+    if (w.sc_abandoned && has_next) scout_restart(w, idx + 1, w.cfg->pmer, w.s_let, SCQ_FROM_HEAD);
   }
   FQ_SYNC();
   lds_store_rel(&sm->hd_taken, idx + 1);   // the record and its staging buffer are free again
@@ -3291,6 +3306,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
   w.rcq = false;
   w.lqh = true;    // (reads the inserter wave's progress)
   w.sc_poll = true;
+  w.nsc = FQSX_NSC;
   w.rec = nullptr;
   w.scout = false;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
@@ -3334,33 +3350,15 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
     }
     if (!restart && lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) restart = true;
     bool from_head = true;
-    if (restart) {   // take up the request: acknowledge, and go on only when every scout wave has (no slot is written by two)
+    if (restart) {   // take up the request
       restart = false;
-#if FQSX_NSC == FQSX_SCR
-      // every scout wave owns one ring slot (chunk c: wave and slot c % FQSX_NSC): nothing to agree on, go right on
+      // every scout wave owns one ring slot (chunk c: wave and slot c % nsc): nothing to agree on, go right on
       w.sc_epoch = lds_load_acq(&sm->sc_req_seq);
-#else
-      for (;;) {   // no slot may be written by two waves: nobody starts the new epoch before all have left the old one
-        w.sc_epoch = lds_load_acq(&sm->sc_req_seq);
-        FQ_SYNC();
-        lds_store_rel(&sm->sc_ack[me], w.sc_epoch);
-        bool all = true;
-        spins = 0;
-        for (u32 x = 0; x < FQSX_NSC && !quit; ++x)
-          while (lds_load_acq(&sm->sc_ack[x]) != w.sc_epoch) {
-            if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { all = false; break; }   // a newer request already (cannot happen before this one is served)
-            fq_sleep();
-            if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || ++spins > (1u << 23)) { quit = true; break; }
-          }
-        if (all || quit) break;
-      }
-      if (quit) break;
-#endif
       const WgShared::ScoutReq &q = sm->sc_req;
       idx = uniform32(q.read);
       base_pos = uniform32(q.i0);
       seq = 0;
-      from_head = base_pos == cfg.pmer;
+      from_head = (uniform32(q.flags) & SCQ_FROM_HEAD) != 0;
       if (!from_head) {
         Kmer *k[6] = {&w.pm, &w.sm_, &w.bm, &w.pm_u, &w.sm_u, &w.bm_u};
         for (u32 x = 0; x < 6; ++x) { k[x]->dir = uniform64(q.kdir[x]); k[x]->rc = uniform64(q.krc[x]); k[x]->cur = uniform32(q.kcur[x]); }
@@ -3464,6 +3462,99 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
   if (me == 0) TM_STAMP(cfg, tid, launch, 4);
 }
 
+// The scout waves of the kernels without a read-head wave (original order, paired end): every compress_suffix call of
+// the resolving wave -- a read after its prefix, the second mate from its anchor, the part left of the anchor on the
+// reverse complement -- is one request: base state, sequence, direction.  The waves make its chunks in turn (chunk c:
+// wave and ring slot c % nsc) and then wait for the next request; a k-mer correction inside the call is a request
+// of the same kind from the corrected state.
+FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me, u32 nsc, u32 launch = 0) {
+  Wk w;
+  w.cfg = &cfg;
+  w.sm = sm;
+  w.tid = tid;
+  w.mode = 0;
+  w.ws = cfg.ws + tid;
+  w.err = 0;
+  w.piped = false;
+  w.rcq = false;
+  w.lqh = true;    // (reads the inserter wave's progress)
+  w.sc_poll = true;
+  w.rec = nullptr;
+  w.scout = false;
+  w.nsc = nsc;
+  w.rdp = sm->rd[0];
+  for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
+  for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) w.tm[i] = 0;
+  w.sc_epoch = 0;
+  for (;;) {
+    // the next request (or the end of the launch)
+    u32 spins = 0;
+    bool quit = false;
+    while (lds_load_acq(&sm->sc_req_seq) == w.sc_epoch) {
+      if (lds_load_acq(&sm->cq_done)) { quit = true; break; }
+      TM_BEGIN(t_id);
+      fq_sleep();
+      TM_END(w, TM_SC_IDLE, t_id);
+      if (++spins > (1u << 26)) { quit = true; break; }   // never spin forever on the GPU
+    }
+    if (quit) break;
+    w.sc_epoch = lds_load_acq(&sm->sc_req_seq);
+    const WgShared::ScoutReq &q = sm->sc_req;
+    const u32 call = uniform32(q.read), base_pos = uniform32(q.i0), size = uniform32(q.size);
+    const bool reversed = (uniform32(q.flags) & SCQ_REVERSED) != 0;
+    const u8 *p = (const u8 *)uniform64(q.p);
+    Kmer *k[6] = {&w.pm, &w.sm_, &w.bm, &w.pm_u, &w.sm_u, &w.bm_u};
+    for (u32 x = 0; x < 6; ++x) { k[x]->dir = uniform64(q.kdir[x]); k[x]->rc = uniform64(q.krc[x]); k[x]->cur = uniform32(q.kcur[x]); }
+    w.cor_pos = uniform32(q.cor_pos);
+    w.N_run = uniform32(q.n_run);
+    for (u32 x = 0; x < 4; ++x) w.s_let[x] = uniform64(q.s_let[x]);
+    w.sc_read = call;
+    if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) continue;   // (overwritten while it was read: take the newer one)
+    u32 seq = 0;
+    for (u32 i0 = base_pos; i0 < size; i0 += FQSX_SPEC, ++seq) {
+      if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch || lds_load_acq(&sm->cq_done)) break;
+      if (seq % nsc != me) continue;   // another wave's chunk
+      spins = 0;
+      bool stop = false;
+      TM_BEGIN(t_w2);
+      while ((i32)(seq - lds_load_acq(&sm->sc_taken)) >= (i32)nsc) {   // the wave's ring slot still holds an unreleased chunk
+        if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch || lds_load_acq(&sm->cq_done)) { stop = true; break; }
+        fq_sleep();
+        if (++spins > (1u << 23)) { stop = true; break; }   // never spin forever on the GPU
+      }
+      TM_END(w, TM_SCOUT_WAIT, t_w2);
+      if (stop) break;
+      const u32 n = size - i0 < FQSX_SPEC ? size - i0 : FQSX_SPEC;
+      w.sb = &sm->sb[1 + seq % nsc];
+      lds_store_rel(&w.sb->h_pub, 0u);   // (the slot may hold a chunk of the same number from an earlier epoch)
+      TM_BEGIN(t_sp);
+      const bool whole = speculate(w, p, size, i0, n, reversed, i0 - base_pos);
+      TM_END(w, TM_SC_SPEC, t_sp);
+      if (!whole) { TM_COUNT(w, CN_SC_ABORT); break; }
+      TM_COUNT(w, CN_SC_CHUNK);
+#if FQ_WAVE > 1
+      if (i0 == base_pos) scout_early(w, n);   // (the look-ups of positions whose b-mer is still partial, if any)
+      const u32 front0 = scout_rough_first(w, n);
+#else
+      const u32 front0 = FQSX_SPEC;
+#endif
+      if (FQ_LANE == 0) { w.sb->h_read = call; w.sb->h_i0 = i0; w.sb->h_n = n; w.sb->h_epoch = w.sc_epoch; w.sb->rr_front = front0; }
+      FQ_SYNC();
+      lds_store_rel(&w.sb->h_pub, seq + 1);   // the resolving wave may start on the chunk ...
+#if FQ_WAVE > 1
+      TM_BEGIN(t_sr);
+      scout_rough(w, n);                       // ... while its sweeps are still being probed (rr_front)
+      TM_END(w, TM_SC_ROUGH, t_sr);
+#endif
+    }
+  }
+#ifdef FQSX_TIMING
+  if (FQ_LANE == 0)
+    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) if (w.tm[i]) atomic_add64(&w.ws->stat[16 + i], w.tm[i]);
+#endif
+  if (me == 0) TM_STAMP(cfg, tid, launch, 4);
+}
+
 // piped: this wave is the resolving half of a multi-wave worker (see coder_segment_body).
 // MODE (dna_mode), DECODE and PIPED are compile-time constants: every kernel holds only the code of its own mode.
 template <int MODE, bool DECODE, bool PIPED>
@@ -3484,7 +3575,10 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.rdp = sm->rd[0];
   constexpr bool heads = PIPED && MODE == 1;   // single-end sorted: the read heads come from the read-head wave
   w.sb = &sm->sb[0];
-  w.scout = heads;
+  w.scout = PIPED;                        // stage P comes from the scout waves
+  w.sc_reqmode = PIPED && MODE != 1;      // ... which, without a read-head wave, serve one request per compress_suffix call
+  w.nsc = MODE >= 2 ? 2u : FQSX_NSC;
+  w.rq_p = nullptr; w.rq_size = 0; w.rq_rev = false;
   w.sc_poll = false;
   w.sc_abandoned = false;
   w.sc_read = 0;

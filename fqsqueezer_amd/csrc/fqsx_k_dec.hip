@@ -2,16 +2,16 @@
 // logic (the next k-mer depends on the symbol being decoded, so there is no stage P).
 #include "fqsx_kernels.h"
 
-template <int MODE> FQ_ROLE void role_decode(FqArgsP ap) {
-  const EncArgs *a = fq_args(ap);
-  encode_segment_body<MODE, true, false>(a->cfg, fq_wg(), FQ_BLOCK, a->n_reads, a->S, a->seg, a->pad);
+// (one wave per workgroup: no roles to separate, the body is inlined into the kernel, which gets the whole register file)
+template <int MODE> FQ_DEV void decode_kernel_body(const EncArgs &a) {
+  encode_segment_body<MODE, true, false>(a.cfg, fq_wg(), FQ_BLOCK, a.n_reads, a.S, a.seg, a.pad);
 }
 
 #ifndef FQSX_EMU
-FQ_KERNEL64 void k_decode_se_orig(EncArgs a) { (void)a; role_decode<0>(fq_kernarg()); }
-FQ_KERNEL64 void k_decode_se_sorted(EncArgs a) { (void)a; role_decode<1>(fq_kernarg()); }
-FQ_KERNEL64 void k_decode_pe_orig(EncArgs a) { (void)a; role_decode<2>(fq_kernarg()); }
-FQ_KERNEL64 void k_decode_pe_sorted(EncArgs a) { (void)a; role_decode<3>(fq_kernarg()); }
+FQ_KERNEL64 void k_decode_se_orig(EncArgs a) { decode_kernel_body<0>(a); }
+FQ_KERNEL64 void k_decode_se_sorted(EncArgs a) { decode_kernel_body<1>(a); }
+FQ_KERNEL64 void k_decode_pe_orig(EncArgs a) { decode_kernel_body<2>(a); }
+FQ_KERNEL64 void k_decode_pe_sorted(EncArgs a) { decode_kernel_body<3>(a); }
 int fqsx_launch_decode(hipStream_t s, const EncArgs &a) {
   const dim3 g(a.cfg.T), b(64);
   switch (a.cfg.mode) {

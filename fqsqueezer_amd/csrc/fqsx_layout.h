@@ -133,7 +133,11 @@ enum { TM_TOTAL = 0, TM_SPEC, TM_FAST, TM_SLOW, TM_POST, TM_READ_HEAD, TM_LQ, TM
        TM_CR_S, TM_CR_MID, TM_CR_AVG, TM_CR_RC, TM_KEYS,
        TM_SC_SPEC /* scout waves: stage P */, TM_SC_EARLY, TM_SC_ROUGH /* ... their sweeps */, TM_SC_IDLE /* ... nothing left to do */, CN_SC_CHUNK, CN_SC_ABORT,
        TM_N };
+#ifdef FQSX_TIMING
 #define FQSX_TM_SLOTS 48
+#else
+#define FQSX_TM_SLOTS 1   /* (the timers only exist in the diagnostic build) */
+#endif
 
 struct DevCfg {
   u32 T, mode;                 // mode 0 = original order, 1 = sorted (params.h:18)

@@ -187,101 +187,114 @@ FQ_DEV void pe_seed_kmers(Wk &w, const u8 *codes, u32 from, u32 to) {  // dna.cp
   }
 }
 
-// CompressPE, dna.cpp:1790-1880
+// CompressPE, dna.cpp:1790-1880.  The pair is coded in three steps -- first mate; second mate directly, or right of
+// its anchor; the part left of the anchor on the reverse complement -- that share ONE compress_suffix call site (the
+// loop below), so the kernel holds the suffix machinery once, not once per way of calling it.
 FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size2, const u8 *prev, u32 prev_size) {
   const DevCfg *cfg = w.cfg;
   WgShared *sm = w.sm;
   const int k = (int)cfg->bmer;
   const u64 vm = pe_value_mask(cfg);
   if (size1 > FQSX_RD_LDS || size2 > FQSX_RD_LDS) { w.err = FQSX_ERR_PE_READ_TOO_LONG; return; }
-  // first mate
-  compress_read(w, p1, size1, prev, prev_size, true);
-  if (w.err) return;
-  // (a duplicate first mate returns early from the coder but sm->rd was staged before that)
-  // minimizers of the first mate: 4 windows for the look-up (dna.cpp:1761-1769), 3 + 1 for the inserts (:1055-1083)
-  u64 m1[4], a1[3], x1;
-  {
-    int mss = (int)size1 - k + 1, s1 = mss / 4, s2 = 2 * mss / 4, s3 = 3 * mss / 4;
-    m1[0] = pe_find_minimizer(cfg, w.rdp, 0, s1 + k - 1);
-    m1[1] = pe_find_minimizer(cfg, w.rdp, s1, s2 - s1 + k - 1);
-    m1[2] = pe_find_minimizer(cfg, w.rdp, s2, s3 - s2 + k - 1);
-    m1[3] = pe_find_minimizer(cfg, w.rdp, s3, (int)size1 - s3);
-    int a = mss / 3, b = 2 * mss / 3;
-    a1[0] = pe_find_minimizer(cfg, w.rdp, 0, a + k - 1);
-    a1[1] = pe_find_minimizer(cfg, w.rdp, a, b - a + k - 1);
-    a1[2] = pe_find_minimizer(cfg, w.rdp, b, (int)size1 - b);
-    int mid1 = ((int)size1 + k) / 2;
-    x1 = (~pe_find_maximizer(cfg, w.rdp, mid1 - k + 1, (int)size1 - (mid1 - k + 1))) & vm;
-  }
-  // second mate's codes
-  FQ_SYNC();
-  for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) sm->r2c[i] = (u8)dna_code(p2[i]);
-  FQ_SYNC();
-  u64 a2[3], x2;
-  {
-    int mss = (int)size2 - k + 1, a = mss / 3, b = 2 * mss / 3;
-    a2[0] = pe_find_minimizer(cfg, sm->r2c, 0, a + k - 1);
-    a2[1] = pe_find_minimizer(cfg, sm->r2c, a, b - a + k - 1);
-    a2[2] = pe_find_minimizer(cfg, sm->r2c, b, (int)size2 - b);
-    int mid2 = ((int)size2 + k) / 2;
-    x2 = (~pe_find_minimizer(cfg, sm->r2c, mid2 - k + 1, (int)size2 - (mid2 - k + 1))) & vm;  // sic: minimizer (dna.cpp:1087)
-  }
-  // find_minim_cand: global then local table, 4 minimizers each (dna.cpp:1771-1779)
-  u32 nc = 0;
-  for (u32 i = 0; i < 4; ++i) ptab_find(w, cfg->g_pe, pe_owner(cfg, murmur64(m1[i])), m1[i], nc);
-  for (u32 i = 0; i < 4; ++i) ptab_find(w, cfg->l_pe, w.tid, m1[i], nc);
-  int mid = -1;
+  u64 m1[4] = {0, 0, 0, 0}, a1[3] = {0, 0, 0}, x1 = 0, a2[3] = {0, 0, 0}, x2 = 0;
   u32 mpos = 0;
-  if (nc) {
-    const u32 ntop = pe_merge_candidates(w, nc);
-    // first listed candidate occurring in the second mate, and its first position (dna.cpp:1806-1819,974-996)
-    u32 best_c = 0xffffffffu, best_pos = 0;
-    for (u32 base = 0; base < size2; base += FQ_WAVE) {
-      const u32 e = base + FQ_LANE;  // b-mer ending at position e
-      u64 v = 0;
-      bool ok = e < size2 && e + 1 >= (u32)k;
-      if (ok)
-        for (int t = 0; t < k; ++t) {
-          u32 c = sm->r2c[e + 1 - k + t];
-          if (c == 4) ok = false;
-          v = (v << 2) | (c & 3);
-        }
-      ok = ok && pe_valid_minimizer(cfg, v);
-      for (u32 c = 0; c < ntop && c < best_c; ++c) {
-        u64 hit = wave_ballot(ok && v == (sm->pe_top[c] & vm));
-        if (hit) {
-          best_c = c;
-#if FQ_WAVE > 1
-          best_pos = base + ctz64(hit) + 1 - (u32)k;
-#else
-          best_pos = e + 1 - (u32)k;
-#endif
-        }
+  bool anchored = false;
+  for (u32 step = 0; step < 3 && !w.err; ++step) {
+    // what this step's compress_suffix call codes (if any)
+    bool run = false, j_orig = true, j_rev = false, add_hist = false;
+    const u8 *j_p = p2;
+    u32 j_size = size2, j_start = 0, j_hist0 = 0, hist[4] = {0, 0, 0, 0};
+    if (step == 0) {
+      // first mate (CompressDirect / CompressSorted with the duplicate flag, dna.cpp:1795-1799)
+      const bool same = read_head(w, p1, size1, prev, prev_size, true, hist);
+      if (!same) { run = true; j_p = p1; j_size = size1; j_orig = w.mode == 2; add_hist = true; }
+    } else if (step == 1) {
+      // (a duplicate first mate returns early from the coder but sm->rd was staged before that)
+      // minimizers of the first mate: 4 windows for the look-up (dna.cpp:1761-1769), 3 + 1 for the inserts (:1055-1083)
+      {
+        int mss = (int)size1 - k + 1, s1 = mss / 4, s2 = 2 * mss / 4, s3 = 3 * mss / 4;
+        m1[0] = pe_find_minimizer(cfg, w.rdp, 0, s1 + k - 1);
+        m1[1] = pe_find_minimizer(cfg, w.rdp, s1, s2 - s1 + k - 1);
+        m1[2] = pe_find_minimizer(cfg, w.rdp, s2, s3 - s2 + k - 1);
+        m1[3] = pe_find_minimizer(cfg, w.rdp, s3, (int)size1 - s3);
+        int a = mss / 3, b = 2 * mss / 3;
+        a1[0] = pe_find_minimizer(cfg, w.rdp, 0, a + k - 1);
+        a1[1] = pe_find_minimizer(cfg, w.rdp, a, b - a + k - 1);
+        a1[2] = pe_find_minimizer(cfg, w.rdp, b, (int)size1 - b);
+        int mid1 = ((int)size1 + k) / 2;
+        x1 = (~pe_find_maximizer(cfg, w.rdp, mid1 - k + 1, (int)size1 - (mid1 - k + 1))) & vm;
       }
-    }
-    mid = best_c == 0xffffffffu || best_c > 14 ? 15 : (int)best_c;
-    mpos = best_pos;
-  }
-  u16 *sb = small_base(w);
-  if (mid < 0) compress_read(w, p2, size2, nullptr, 0, false);
-  else {
-    sm_encode(w, sb + SM_OFF_MID, SM_NIB_N, 1u << 15, (u32)mid);  // ctx_rc_pe_minimizer_id, dna.cpp:1835
-    if (mid == 15) compress_read(w, p2, size2, nullptr, 0, false);
-    else {
-      // position of the anchor (dna.cpp:1840-1868); models keyed by id (+0x100..0x500 for the escape bytes)
-      u8 *bi = cfg->byte_init + (u64)w.tid * SM_LAZY_ENTRIES + SM_BYTE_ENTRIES;
-      u16 *mp = sb + SM_OFF_MPOS;
+      // second mate's codes
+      FQ_SYNC();
+      for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) sm->r2c[i] = (u8)dna_code(p2[i]);
+      FQ_SYNC();
+      {
+        int mss = (int)size2 - k + 1, a = mss / 3, b = 2 * mss / 3;
+        a2[0] = pe_find_minimizer(cfg, sm->r2c, 0, a + k - 1);
+        a2[1] = pe_find_minimizer(cfg, sm->r2c, a, b - a + k - 1);
+        a2[2] = pe_find_minimizer(cfg, sm->r2c, b, (int)size2 - b);
+        int mid2 = ((int)size2 + k) / 2;
+        x2 = (~pe_find_minimizer(cfg, sm->r2c, mid2 - k + 1, (int)size2 - (mid2 - k + 1))) & vm;  // sic: minimizer (dna.cpp:1087)
+      }
+      // find_minim_cand: global then local table, 4 minimizers each (dna.cpp:1771-1779)
+      u32 nc = 0;
+      for (u32 i = 0; i < 4; ++i) ptab_find(w, cfg->g_pe, pe_owner(cfg, murmur64(m1[i])), m1[i], nc);
+      for (u32 i = 0; i < 4; ++i) ptab_find(w, cfg->l_pe, w.tid, m1[i], nc);
+      int mid = -1;
+      if (nc) {
+        const u32 ntop = pe_merge_candidates(w, nc);
+        // first listed candidate occurring in the second mate, and its first position (dna.cpp:1806-1819,974-996)
+        u32 best_c = 0xffffffffu, best_pos = 0;
+        for (u32 base = 0; base < size2; base += FQ_WAVE) {
+          const u32 e = base + FQ_LANE;  // b-mer ending at position e
+          u64 v = 0;
+          bool ok = e < size2 && e + 1 >= (u32)k;
+          if (ok)
+            for (int t = 0; t < k; ++t) {
+              u32 c = sm->r2c[e + 1 - k + t];
+              if (c == 4) ok = false;
+              v = (v << 2) | (c & 3);
+            }
+          ok = ok && pe_valid_minimizer(cfg, v);
+          for (u32 c = 0; c < ntop && c < best_c; ++c) {
+            u64 hit = wave_ballot(ok && v == (sm->pe_top[c] & vm));
+            if (hit) {
+              best_c = c;
+#if FQ_WAVE > 1
+              best_pos = base + ctz64(hit) + 1 - (u32)k;
+#else
+              best_pos = e + 1 - (u32)k;
+#endif
+            }
+          }
+        }
+        mid = best_c == 0xffffffffu || best_c > 14 ? 15 : (int)best_c;
+        mpos = best_pos;
+      }
+      u16 *sb = small_base(w);
+      if (mid >= 0) sm_encode(w, sb + SM_OFF_MID, SM_NIB_N, 1u << 15, (u32)mid);  // ctx_rc_pe_minimizer_id, dna.cpp:1835
+      if (mid < 0 || mid == 15) {
+        // second mate coded directly: CompressDirect(..., false) -- direct prefix, no duplicate flag (dna.cpp:1836)
+        (void)read_head(w, p2, size2, nullptr, 0, false, hist);
+        run = true; add_hist = true;
+      } else {
+        anchored = true;
+        // position of the anchor (dna.cpp:1840-1868); models keyed by id (+0x100..0x500 for the escape bytes)
+        u8 *bi = cfg->byte_init + (u64)w.tid * SM_LAZY_ENTRIES + SM_BYTE_ENTRIES;
+        u16 *mp = sb + SM_OFF_MPOS;
 #define MPOS_ENC(cls, sym) sm_encode256(w, mp + (u64)((cls) * 16 + mid) * (SM_BYTE_N + 1), bi + ((cls) * 16 + mid), (sym))
-      if (mpos < 254) MPOS_ENC(0, mpos);
-      else if (mpos < 65536) { MPOS_ENC(0, 254); MPOS_ENC(1, mpos >> 8); MPOS_ENC(2, mpos & 0xff); }
-      else { MPOS_ENC(0, 255); MPOS_ENC(3, mpos >> 16); MPOS_ENC(4, (mpos >> 8) & 0xff); MPOS_ENC(5, mpos & 0xff); }
+        if (mpos < 254) MPOS_ENC(0, mpos);
+        else if (mpos < 65536) { MPOS_ENC(0, 254); MPOS_ENC(1, mpos >> 8); MPOS_ENC(2, mpos & 0xff); }
+        else { MPOS_ENC(0, 255); MPOS_ENC(3, mpos >> 16); MPOS_ENC(4, (mpos >> 8) & 0xff); MPOS_ENC(5, mpos & 0xff); }
 #undef MPOS_ENC
-      // CompressDirectWithMinim (dna.cpp:1559-1638): right part forwards from the anchor ...
-      FQ_SYNC();
-      for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) w.rdp[i] = sm->r2c[i];
-      FQ_SYNC();
-      pe_seed_kmers(w, w.rdp, mpos, mpos + (u32)k);
-      suffix(w, p2, size2, true, (u32)k + mpos, false, mpos);
+        // CompressDirectWithMinim (dna.cpp:1559-1638): right part forwards from the anchor ...
+        FQ_SYNC();
+        for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) w.rdp[i] = sm->r2c[i];
+        FQ_SYNC();
+        pe_seed_kmers(w, w.rdp, mpos, mpos + (u32)k);
+        run = true; j_start = (u32)k + mpos; j_hist0 = mpos;
+      }
+    } else if (anchored) {
       // ... then the left part on the reverse complement, anchored at the same b-mer
       const u32 rsz = mpos + (u32)k;
       FQ_SYNC();
@@ -291,7 +304,14 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
       }
       FQ_SYNC();
       pe_seed_kmers(w, w.rdp, 0, (u32)k);
-      suffix(w, p2, rsz, true, (u32)k, true, 0);
+      run = true; j_size = rsz; j_start = (u32)k; j_rev = true;
+    }
+    if (run) suffix(w, j_p, j_size, j_orig, j_start, j_rev, j_hist0);
+    if (w.err) return;
+    if (add_hist) {   // update_s_letters of a directly coded read (dna.cpp:1552-1553,1750-1751)
+      add_s_letters(w, hist);
+      w.st[ST_BASES] += j_size;
+    } else if (step == 2 && anchored) {
       // update_s_letters(p2), dna.cpp:1635
       u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0;
       for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) {

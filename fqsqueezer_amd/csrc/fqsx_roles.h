@@ -1,0 +1,60 @@
+// fqsx_roles.h -- the roles of a worker as functions of their own (FQ_ROLE), shared by the encode kernels
+// (fqsx_k_se.hip, fqsx_k_pe.hip).  One workgroup = one logical worker; wave w runs on SIMD w % 4:
+//   0 read head (single-end sorted only)   1, 7, 6 scouts   2 resolve   3 models   4 range coder   5 local-table inserter
+// so the two busiest roles, resolve and models, share their SIMD only with a scout.
+#pragma once
+#include "fqsx_kernels.h"
+
+template <int MODE> FQ_ROLE void role_resolve(FqArgsP ap) {
+  const EncArgs *a = fq_args(ap);
+  encode_segment_body<MODE, false, true>(a->cfg, fq_wg(), FQ_BLOCK, a->n_reads, a->S, a->seg, a->pad);
+}
+FQ_ROLE void role_models(FqArgsP ap) {
+  const EncArgs *a = fq_args(ap);
+  coder_segment_body<true>(a->cfg, fq_wg(), FQ_BLOCK, a->seg, a->pad);
+}
+FQ_ROLE void role_rc(FqArgsP ap) {
+  const EncArgs *a = fq_args(ap);
+  rc_segment_body(a->cfg, fq_wg(), FQ_BLOCK, a->seg, a->pad);
+}
+FQ_ROLE void role_inserter(FqArgsP ap) {
+  const EncArgs *a = fq_args(ap);
+  inserter_segment_body(a->cfg, fq_wg(), FQ_BLOCK, a->pad);
+}
+FQ_ROLE void role_head(FqArgsP ap) {
+  const EncArgs *a = fq_args(ap);
+  head_segment_body(a->cfg, fq_wg(), FQ_BLOCK, a->n_reads, a->S, a->seg, a->pad);
+}
+template <int ME> FQ_ROLE void role_scout(FqArgsP ap) {   // single-end sorted: the scouts walk the reads behind the read-head wave
+  const EncArgs *a = fq_args(ap);
+  scout_segment_body(a->cfg, fq_wg(), FQ_BLOCK, a->n_reads, a->S, a->seg, (u32)ME, a->pad);
+}
+template <int ME, int NSC> FQ_ROLE void role_scout_req(FqArgsP ap) {   // the other modes: one request per compress_suffix call
+  const EncArgs *a = fq_args(ap);
+  scout_request_body(a->cfg, fq_wg(), FQ_BLOCK, (u32)ME, (u32)NSC, a->pad);
+}
+
+#ifndef FQSX_EMU
+// sharded run: a worker that lives on another GPU only reports empty mailboxes here
+FQ_DEV bool worker_elsewhere(const EncArgs &a) {
+  if (shard_mine(a.cfg, FQ_BLOCK)) return false;
+  if (threadIdx.x == 0) {
+    for (u32 k = 0; k < 3; ++k) a.cfg.mail[k].n[FQ_BLOCK] = 0;
+    if (a.cfg.pe_n) a.cfg.pe_n[FQ_BLOCK] = 0;
+  }
+  return true;
+}
+FQ_DEV void wg_handoff_init() {   // the one workgroup barrier of the kernel: the LDS hand-off words start at zero
+  WgShared *sm = fq_wg();
+  if (threadIdx.x == 0) {
+    sm->cq_tail = 0; sm->cq_head = 0; sm->cq_done = 0;
+    sm->lq_target[0] = sm->lq_target[1] = 0; sm->lq_done[0] = sm->lq_done[1] = 0; sm->lq_quit = 0;
+    sm->hd_ready = 0; sm->hd_taken = 0;
+    sm->sc_taken = 0; sm->sc_req_seq = 0; sm->sc_dead = 0;
+    for (u32 x = 0; x < FQSX_NSC; ++x) { sm->sc_hd_taken[x] = 0; sm->sc_ack[x] = 0; }
+    for (u32 x = 1; x <= FQSX_SCR; ++x) sm->sb[x].h_pub = 0;
+    sm->rq_tail = 0; sm->rq_head = 0; sm->rq_done = 0;
+  }
+  FQ_WG_BARRIER();
+}
+#endif
