@@ -1090,9 +1090,11 @@ int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) {
   c->cur_need_lb = c->cur_need_ls = c->cur_need_lpe = 0;
   c->cur_decode = false;
 #ifndef FQSX_EMU
-  HIPCHK(hipStreamCreate(&c->stream));
-  HIPCHK(hipEventCreate(&c->ev0));
-  HIPCHK(hipEventCreate(&c->ev1));
+  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    g_err = "hipStreamCreate / hipEventCreate failed";
+    delete c;
+    return FQSX_E_HIP;
+  }
 #endif
   int rc = create_impl(c, h);
   if (rc) {
@@ -1350,6 +1352,9 @@ int fqsx_shard_finish_block(fqsx_dna *c, const uint64_t *h_off, const uint8_t **
 
 int fqsx_dna_stats(fqsx_dna *c, uint64_t out[64]) {
   if (!c || !out) return FQSX_E_ARG;
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
   LAUNCH(c, 2, k_gather_stats, 1, 64, c->cfg, c->d_lens + c->T);
   return d2h_sync(c, out, c->d_lens + c->T, 64 * sizeof(u64));
 }

@@ -609,7 +609,7 @@ FQ_DEV void lq_flush(Wk &w, u32 kind) {
     u32 spins = 0;
     while (lds_load_acq(&w.sm->lq_done[qi]) < n) {
       fq_sleep();
-      if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+      if (spin_expired(spins)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
     }
     TM_END(w, TM_LQ, t_lq);
     return;
@@ -879,7 +879,7 @@ FQ_DEV bool rq_wait_space(Wk &w, u32 need) {
   u32 spins = 0;
   while (w.rq_tail - lds_load_acq(&w.sm->rq_head) + need > FQSX_RQ) {
     fq_sleep();
-    if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; return false; }   // never spin forever on the GPU
+    if (spin_expired(spins)) { w.err = FQSX_ERR_PIPE; return false; }   // never spin forever on the GPU
   }
   TM_END(w, TM_CQWAIT, t_rq);
   return true;
@@ -929,7 +929,7 @@ FQ_DEV bool cq_wait_space(Wk &w, u32 need) {
   u32 spins = 0;
   while (w.cq_tail - lds_load_acq(&w.sm->cq_head) + need > FQSX_CQ) {
     fq_sleep();
-    if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; return false; }   // never spin forever on the GPU
+    if (spin_expired(spins)) { w.err = FQSX_ERR_PIPE; return false; }   // never spin forever on the GPU
   }
   TM_END(w, TM_CQWAIT, t_cq);
   return true;
@@ -2612,7 +2612,7 @@ FQ_DEV bool scout_take(Wk &w, u32 i, u32 n) {
   // the chunk with this number of this epoch (a slot may still hold the one of an earlier epoch with the same number)
   while (lds_load_acq(&b->h_pub) != w.sc_taken + 1 || b->h_epoch != w.sc_epoch) {
     fq_sleep();
-    if (lds_load_acq(&sm->sc_dead) || ++spins > (1u << 22)) { w.sc_abandoned = true; return false; }   // never spin forever on the GPU
+    if (lds_load_acq(&sm->sc_dead) || spin_expired(spins)) { w.sc_abandoned = true; return false; }   // never spin forever on the GPU
   }
   if (b->h_read == w.sc_read && b->h_i0 == i && b->h_n == n) { w.sb = b; return true; }
   w.sc_abandoned = true;   // (cannot happen: the waves enumerate the chunks alike)
@@ -2676,7 +2676,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         TM_BEGIN(t_rrw);
         while ((front = lds_load_acq(&w.sb->rr_front)) <= j) {   // the scout wave may still be sweeping this chunk
           fq_sleep();
-          if (++spins > (1u << 22)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+          if (spin_expired(spins)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
         }
         TM_END(w, TM_RRWAIT, t_rrw);
         const u32 t = FQ_LANE;
@@ -2767,7 +2767,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
                 TM_BEGIN(t_rrw);
                 while (lds_load_acq(&w.sb->rr_front) <= j) {
                   fq_sleep();
-                  if (++spins > (1u << 22)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+                  if (spin_expired(spins)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
                 }
                 TM_END(w, TM_RRWAIT, t_rrw);
               }
@@ -2973,7 +2973,7 @@ FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx, bool has_ne
   u32 spins = 0;
   while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
     fq_sleep();
-    if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; return; }   // never spin forever on the GPU
+    if (spin_expired(spins)) { w.err = FQSX_ERR_PIPE; return; }   // never spin forever on the GPU
   }
   const HeadRec *rec = &sm->hd[idx & 1];
   const u32 n_raw = rec->n_raw;
@@ -3070,7 +3070,7 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
     else {
       TM_BEGIN(t_idle);
       fq_sleep();
-      if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+      if (spin_expired(spins)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
       TM_END(w, TM_CODER_IDLE, t_idle);
     }
   }
@@ -3145,7 +3145,7 @@ FQ_DEV void rc_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg, u
     } else if (done) break;
     else {
       fq_sleep();
-      if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+      if (spin_expired(spins)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
     }
   }
   TM_STAMP(cfg, tid, launch, 7);
@@ -3197,7 +3197,7 @@ FQ_DEV void inserter_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 
     if (worked) spins = 0;
     else {
       fq_sleep();
-      if (++spins > (1u << 24)) break;   // never spin forever on the GPU
+      if (spin_expired(spins)) break;   // never spin forever on the GPU
     }
   }
   if (FQ_LANE == 0 && lins) atomic_add64(&cfg.ws[tid].stat[ST_LINS], lins);
@@ -3245,7 +3245,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
       }
       if (!busy) break;
       fq_sleep();
-      if (++spins > (1u << 23)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
+      if (spin_expired(spins)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
     }
     if (w.err) break;
     HeadRec *rec = &sm->hd[idx & 1];
@@ -3343,7 +3343,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
         if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
         fq_sleep();
-        if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || ++spins > (1u << 23)) { quit = true; break; }
+        if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || spin_expired(spins)) { quit = true; break; }
       }
       TM_END(w, TM_SCOUT_WAIT, t_w1);
       if (quit) break;
@@ -3377,7 +3377,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
           if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
           fq_sleep();
-          if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || ++spins > (1u << 23)) { quit = true; break; }
+          if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || spin_expired(spins)) { quit = true; break; }
         }
         if (quit) break;
         if (restart) continue;
@@ -3418,7 +3418,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         while ((i32)(seq - lds_load_acq(&sm->sc_taken)) >= (i32)FQSX_SCR) {   // the chunk's ring slot still holds an unreleased one
           if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
           fq_sleep();
-          if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || ++spins > (1u << 23)) { quit = true; break; }
+          if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || spin_expired(spins)) { quit = true; break; }
         }
         TM_END(w, TM_SCOUT_WAIT, t_w2);
         if (quit || restart) break;
@@ -3495,7 +3495,7 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
       TM_BEGIN(t_id);
       fq_sleep();
       TM_END(w, TM_SC_IDLE, t_id);
-      if (++spins > (1u << 26)) { quit = true; break; }   // never spin forever on the GPU
+      if (spin_expired(spins)) { quit = true; break; }   // never spin forever on the GPU
     }
     if (quit) break;
     w.sc_epoch = lds_load_acq(&sm->sc_req_seq);
@@ -3520,7 +3520,7 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
       while ((i32)(seq - lds_load_acq(&sm->sc_taken)) >= (i32)nsc) {   // the wave's ring slot still holds an unreleased chunk
         if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch || lds_load_acq(&sm->cq_done)) { stop = true; break; }
         fq_sleep();
-        if (++spins > (1u << 23)) { stop = true; break; }   // never spin forever on the GPU
+        if (spin_expired(spins)) { stop = true; break; }   // never spin forever on the GPU
       }
       TM_END(w, TM_SCOUT_WAIT, t_w2);
       if (stop) break;

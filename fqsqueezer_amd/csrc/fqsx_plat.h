@@ -53,6 +53,22 @@ typedef int32_t i32;
 FQ_DEV u32 lds_load_acq(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 FQ_DEV void lds_store_rel(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 FQ_DEV void fq_sleep() { __builtin_amdgcn_s_sleep(4); }
+FQ_DEV u64 fq_clock_raw() { return (u64)wall_clock64(); }
+// Liveness guard of a wait loop (never spin forever on the GPU): `spins` counts the iterations; every 4096th one looks
+// at the 100 MHz wall clock and the wait is given up after FQSX_WAIT_LIMIT_S seconds -- time, not an iteration count,
+// so a wave that is merely slow (GPU shared between processes, counter collection) is not mistaken for a stalled one.
+// spins: low 12 bits = iterations since the last look, upper bits = 1/64 s units waited (0 = clock not sampled yet).
+#define FQSX_WAIT_LIMIT_S 8u
+FQ_DEV bool spin_expired(u32 &spins) {
+  const u32 c = (spins + 1u) & 0xfffu;
+  spins = (spins & ~0xfffu) | c;   // (the count wraps inside its 12 bits)
+  if (c != 0) return false;
+  const u32 now = (u32)(fq_clock_raw() >> 20) | 1u;        // ~10.5 ms units, never 0
+  const u32 first = spins >> 12;
+  if (first == 0) { spins = now << 12; return false; }       // first look: remember when the wait began
+  spins = first << 12;
+  return (u32)((now - first) & 0xfffffu) > FQSX_WAIT_LIMIT_S * 95u;
+}
 FQ_DEV void atomic_add64(u64 *p, u64 v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
 
 FQ_DEV u32 wave_sum32(u32 v) {
@@ -119,6 +135,7 @@ FQ_DEV double ema_update(double avg, double level) { return __dadd_rn(__dmul_rn(
 FQ_DEV u32 lds_load_acq(const u32 *p) { return *p; }
 FQ_DEV void lds_store_rel(u32 *p, u32 v) { *p = v; }
 FQ_DEV void fq_sleep() {}
+FQ_DEV bool spin_expired(u32 &spins) { return ++spins > (1u << 20); }
 FQ_DEV void atomic_add64(u64 *p, u64 v) { *p += v; }
 static thread_local u32 fq_emu_block = 0, fq_emu_nblocks = 1;
 FQ_DEV u32 wave_sum32(u32 v) { return v; }

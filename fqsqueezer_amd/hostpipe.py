@@ -287,7 +287,10 @@ def _host_lib():
     lib = os.path.join(here, "libfqsx_host.so")
     src = os.path.join(here, "csrc", "fqsx_host.cpp")
     if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", src, "-o", lib])
+        # (several ranks / processes may come here at once: build under a private name, then rename atomically)
+        tmp = "%s.tmp%d" % (lib, os.getpid())
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", src, "-o", tmp])
+        os.replace(tmp, lib)
     h = C.CDLL(lib)
     h.fqsx_sort_bin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     return h
