@@ -1384,7 +1384,7 @@ int fqsx_dna_kernel_times(fqsx_dna *c, double out[6]) {
 // =======================================================================================
 // quality stream
 FQ_KERNEL64 void k_qual_encode(QualCfg cfg, u32 n_reads) {
-  FQ_SHARED u8 lds_q[4096];
+  FQ_SHARED u8 lds_q[4096 + 96];
   qual_encode_body(cfg, lds_q, FQ_BLOCK, n_reads);
 }
 FQ_KERNEL void k_qual_rehash(const u64 *o, u64 ocap_mask, u64 *n, u64 ncap_mask, u32 T, u32 slot_u64) {
@@ -1555,7 +1555,7 @@ static int qual_encode_impl(fqsx_qual *q, const uint8_t *quals, const uint8_t *d
     cfg.cap_mask = ncap - 1;
     q->cap = ncap;
   }
-  const u64 need_out = max_w * 2 + 4096, nq = off[n_reads] + 64, no = ((u64)n_reads + 1) * sizeof(u64);
+  const u64 need_out = (max_w * 2 + 4096 + 7) & ~7ull, nq = off[n_reads] + 64, no = ((u64)n_reads + 1) * sizeof(u64);
   if (need_out > q->out_cap) {
     dfree(c, cfg.out);
     if ((rc = dalloc(c, &p, need_out * T, false))) return rc;
