@@ -118,6 +118,7 @@ struct WgShared {
   u8 fr_lvl[64], fr_bad[64];
   u64 pq_key[2][FQSX_PQ];      // LDS mirror of the most recent b / s list entries (ring indexed by list position)
   u64 ib_pos[64];              // insert_batch: target slot per lane
+  u64 ib_hash[256];            // ... and the lanes per slot bucket
   u32 qm_bits[4][128];         // quiet_miss_mask: 4096-bit sets of the sibling groups of recent list entries (b dir, b rc, s dir, s rc)
   // hand-off words of the local-table inserter wave: list entries published / applied per kind (b, s); quit
   u32 lq_target[2], lq_done[2], lq_quit;
@@ -143,6 +144,7 @@ struct InsShared {
   u32 mt[4][624];
   u32 mt_idx[4];
   u64 ib_pos[64];
+  u64 ib_hash[256];
   u64 bk_key[64];
   u64 pe_bk[3][64];
 };
@@ -575,11 +577,19 @@ FQ_DEV void insert_keys(const DevCfg &cfg, SM *sm, const KTab &t, u32 sub, const
                         u64 &nslots, u32 &err) {
 #if FQ_WAVE > 1
   // the keys of the next batch are fetched while the current one is applied (the list is read-only here)
+  // ... and the home slots of the next batch are touched one batch ahead, so that the ordered walk of a batch finds
+  // its cache lines (and address translations) in L2 instead of paying the HBM round trip inside the serial chain
+  const u64 *s = t.slots + (u64)sub * t.stride;
   u64 nextk = FQ_LANE < n ? keys[FQ_LANE] : 0;
   for (u32 o = 0; o < n && !err; o += FQ_WAVE) {
     const u64 k = nextk;
-    if (o + FQ_WAVE + FQ_LANE < n) nextk = keys[o + FQ_WAVE + FQ_LANE];
+    u64 touch = 0;
+    if (o + FQ_WAVE + FQ_LANE < n) {
+      nextk = keys[o + FQ_WAVE + FQ_LANE];
+      touch = touch_load(&s[tab_home(t, nextk >> (64 - 2 * t.k))]);
+    }
     insert_batch_k(cfg, sm, t, sub, k, n - o < FQ_WAVE ? n - o : FQ_WAVE, rng, ci, nslots, err);
+    keep_live(touch);
   }
 #else
   for (u32 j = 0; j < n && !err; ++j) insert_batch(cfg, sm, t, sub, keys + j, 1, rng, ci, nslots, err);
@@ -3749,6 +3759,13 @@ template <class SM>
 FQ_DEV void insert_batch_k(const DevCfg &cfg, SM *sm, const KTab &t, u32 tid, u64 mykey, u32 n, u32 rng, const Cinc &ci,
                            u64 &nslots, u32 &err) {
   (void)cfg;
+#ifdef FQSX_TIMING
+  u64 ib_t[4] = {0, 0, 0, 0}, ib_rounds = 0;   // global-table batches only: probe walk / clash test / draws + stores / store wait
+#define IB_MARK(i) do { const u64 now_ = fq_clock(); ib_t[i] += now_ - ib_c; ib_c = now_; } while (0)
+  u64 ib_c = fq_clock();
+#else
+#define IB_MARK(i) ((void)0)
+#endif
   u64 *s = t.slots + (u64)tid * t.stride;
   const u64 cm = (1ull << t.cbits) - 1ull;
   const u32 lane = FQ_LANE;
@@ -3759,33 +3776,56 @@ FQ_DEV void insert_batch_k(const DevCfg &cfg, SM *sm, const KTab &t, u32 tid, u6
     u64 pos = 0, item = 0;
     bool act = lane >= done && lane < n, found = false;
     if (act) {
+      // four consecutive slots per round trip (independent loads): a cluster holds up to four siblings, and the lane
+      // with the longest walk sets the pace of the whole batch
       u64 p = home;
-      for (u64 q = 0; q <= t.cap_mask; ++q) {
-        u64 it = s[p];
-        ++nslots;
-        if (!it) break;
-        if ((it >> t.cbits) == v) { found = true; item = it; break; }
-        p = (p + 1) & t.cap_mask;
+      bool end = false;
+      for (u64 q = 0; q <= t.cap_mask && !end; q += 4) {
+        u64 it[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) it[j] = s[(p + j) & t.cap_mask];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (end) continue;
+          ++nslots;
+          if (!it[j]) end = true;
+          else if ((it[j] >> t.cbits) == v) { found = true; item = it[j]; end = true; }
+          else p = (p + 1) & t.cap_mask;
+        }
       }
       pos = p;
     }
+    IB_MARK(0);
     // a new key can also extend a cluster another lane scanned, but that lane then targets a
     // different slot and stays correct
     u32 lim = n;
 #if FQ_WAVE > 1
+    // Does an earlier key of this round target my slot?  All pairs are tested through a 256-bucket LDS filter: every
+    // lane sets its bit in the bucket of its slot, reads the bucket back and compares slots only with the (0-2) earlier
+    // lanes it shares the bucket with -- a handful of LDS round trips instead of a 64-step scan per lane.
     FQ_SYNC();
     sm->ib_pos[lane] = act ? pos : ~0ull;
+    for (u32 i = lane; i < 256; i += FQ_WAVE) sm->ib_hash[i] = 0;
     FQ_SYNC();
-    bool clash = false;   // an earlier key of this round targets my slot
-    if (act)
-      for (u32 j = done; j < n; ++j)
-        if (j < lane && sm->ib_pos[j] == pos) clash = true;
+    const u32 hb = (((u32)pos ^ (u32)(pos >> 32)) * 0x9E3779B1u) >> 24;
+    if (act) lds_or64(&sm->ib_hash[hb], 1ull << lane);
+    FQ_SYNC();
+    bool clash = false;
+    if (act) {
+      u64 cand = sm->ib_hash[hb] & ((1ull << lane) - 1ull);
+      while (cand && !clash) {
+        const u32 j = ctz64(cand);
+        cand &= cand - 1ull;
+        clash = sm->ib_pos[j] == pos;
+      }
+    }
     const u64 cl = wave_ballot(clash);
     if (cl) lim = ctz64(cl);
     act = act && lane < lim;
 #else
     lim = done + 1;
 #endif
+    IB_MARK(1);
     const u32 n_new = popc64(wave_ballot(act && !found));
     if ((u64)(filled + n_new) * 10 >= (t.cap_mask + 1) * 9) { err = FQSX_ERR_GTAB_FULL; return; }
     const u32 cnt = (u32)(item & cm);
@@ -3815,8 +3855,21 @@ FQ_DEV void insert_batch_k(const DevCfg &cfg, SM *sm, const KTab &t, u32 tid, u6
     filled += n_new;
     done = lim;
     if (lane == 0 && done >= n) t.filled[tid] = filled;
+    IB_MARK(2);
     FQ_SYNC_MEM();  // later rounds and batches of this wave read these slots from other lanes
+    IB_MARK(3);
+#ifdef FQSX_TIMING
+    ++ib_rounds;
+#endif
   }
+#ifdef FQSX_TIMING
+  if (rng < 2 && lane == 0) {
+    for (u32 i = 0; i < 4; ++i) atomic_add64(&cfg.ws[tid].stat[16 + 40 + i], ib_t[i]);
+    atomic_add64(&cfg.ws[tid].stat[16 + 44], ib_rounds);
+    atomic_add64(&cfg.ws[tid].stat[16 + 45], 1);
+  }
+#endif
+#undef IB_MARK
 }
 
 // ---- stable partition of the mailbox lists by owner -----------------------------------------

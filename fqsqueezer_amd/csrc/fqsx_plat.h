@@ -92,6 +92,7 @@ FQ_DEV u32 wave_excl_scan32(u32 v) {
   return x - v;
 }
 FQ_DEV void lds_inc32(u32 *p) { atomicAdd(p, 1u); }
+FQ_DEV void lds_or64(u64 *p, u64 v) { atomicOr((unsigned long long *)p, (unsigned long long)v); }
 FQ_DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
 FQ_DEV bool wave_all(bool p) { return __ballot(p) == __ballot(true); }
 FQ_DEV u64 wave_ballot(bool p) { return __ballot(p); }
@@ -102,6 +103,9 @@ FQ_DEV u64 uniform64(u64 v) {
   u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
   return ((u64)hi << 32) | lo;
 }
+// cache touch: the value of a load issued early for its side effect on L2 / the TLB is "used" here
+FQ_DEV u64 touch_load(const u64 *p) { return *(const volatile u64 *)p; }
+FQ_DEV void keep_live(u64 v) { asm volatile("" ::"v"((u32)v), "v"((u32)(v >> 32))); }
 FQ_DEV u32 popc64(u64 v) { return (u32)__popcll(v); }
 FQ_DEV u32 ctz64(u64 v) { return (u32)__ffsll((long long)v) - 1u; }
 FQ_DEV u64 fq_clock() { return (u64)wall_clock64(); }  // 100 MHz constant clock (s_memrealtime)
@@ -142,6 +146,7 @@ FQ_DEV u32 wave_sum32(u32 v) { return v; }
 FQ_DEV u64 wave_sum64(u64 v) { return v; }
 FQ_DEV u32 wave_excl_scan32(u32) { return 0; }
 FQ_DEV void lds_inc32(u32 *p) { ++*p; }
+FQ_DEV void lds_or64(u64 *p, u64 v) { *p |= v; }
 FQ_DEV bool wave_any(bool p) { return p; }
 FQ_DEV bool wave_all(bool p) { return p; }
 FQ_DEV u64 wave_ballot(bool p) { return p ? 1ull : 0ull; }
@@ -149,6 +154,8 @@ FQ_DEV u32 wave_bcast32(u32 v, u32) { return v; }
 FQ_DEV u64 wave_bcast64(u64 v, u32) { return v; }
 FQ_DEV u32 uniform32(u32 v) { return v; }
 FQ_DEV u64 uniform64(u64 v) { return v; }
+FQ_DEV u64 touch_load(const u64 *p) { return *p; }
+FQ_DEV void keep_live(u64) {}
 FQ_DEV u32 popc64(u64 v) { return (u32)__builtin_popcountll(v); }
 FQ_DEV u32 ctz64(u64 v) { return (u32)__builtin_ctzll(v); }
 FQ_DEV u64 fq_clock() { return 0; }

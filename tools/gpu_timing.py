@@ -62,3 +62,8 @@ tot = tm[0] or 1
 print("shares of worker time:", {k: round(v / tot, 3) for k, v in zip(names, tm)})
 print("events:", cn)
 print({k: v for k, v in st.items() if k != "timers"})
+ib = st["timers"][40:46]
+if ib[5]:
+    print("global insert batches:", {"batches": ib[5], "rounds": ib[4], "probe walk s": round(ib[0] * 1e-8, 3), "clash test s": round(ib[1] * 1e-8, 3),
+                                     "draws + stores s": round(ib[2] * 1e-8, 3), "store wait s": round(ib[3] * 1e-8, 3),
+                                     "us per batch": round(sum(ib[:4]) * 1e-2 / ib[5], 2)})
