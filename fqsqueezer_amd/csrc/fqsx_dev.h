@@ -1711,6 +1711,57 @@ FQ_DEV void scout_early(Wk &w, u32 n) {
   }
   FQ_SYNC();
 }
+// scout wave, after scout_early: an early position whose first look-up of find_counts (dna.cpp:457-502: the global b-mer
+// table if the b-mer is almost full, else the global s-mer table) finds something is settled here -- level, counts --
+// when merging the trials' counts (ht_kmer.h:321-323) cannot draw from the RNG: every sum stays within the exact range
+// of the counter code (Increment(a, b) of values <= thr is their sum, utils.h:272-290,327-333).  That is the rule for
+// the s-mer table (exact up to 2047), i.e. for the positions before the b-mer is almost full.  The resolving wave then
+// takes the position through its settled path (keys and rank in code_keys) instead of the per-position one.
+FQ_DEV void scout_settle_early(Wk &w, u32 i0, u32 n) {
+  const DevCfg *cfg = w.cfg;
+  SpecBuf *sb = w.sb;
+  const u32 e = FQ_LANE;
+  const u32 bmargin = cfg->bmer - cfg->smer - 1, smargin = cfg->smer - cfg->pmer + 1;
+  u32 np = 0, nsl = 0;
+  FQ_SYNC();
+  if (e < n && e < 32 && sb->sp_flag[e] == 0 && sb->sp_scur[2][e] != cfg->gb.k && sb->sp_nrun[e] < 2) {
+    const u32 cb = sb->sp_scur[2][e], cs = sb->sp_scur[1][e];
+    const u32 tb = cb + bmargin >= cfg->gb.k ? 0u : 1u;   // the table find_counts asks first
+    const u32 cur = tb ? cs : cb, k = tb ? cfg->gs.k : cfg->gb.k;
+    const u32 off = sb->ep_off[e][tb];
+    if ((tb == 0 || cs + smargin >= k) && off != 0xff) {
+      const u32 thr = tb ? (CINC_S).thr : (CINC_B).thr;
+      const u32 m = k - cur, cnt = 1u << (2 * m);
+      u32 c[4] = {0, 0, 0, 0}, nn = 0;
+      for (u32 t = 0; t < cnt; ++t) {
+        const u64 v = sb->ep_res[off + t];
+        nn += sb->ep_ns[off + t];
+        c[0] += (u32)(v & 0xffff); c[1] += (u32)((v >> 16) & 0xffff); c[2] += (u32)((v >> 32) & 0xffff); c[3] += (u32)(v >> 48);
+      }
+      bool ok = (c[0] | c[1] | c[2] | c[3]) != 0;
+      if (m) ok = ok && c[0] <= thr && c[1] <= thr && c[2] <= thr && c[3] <= thr;
+      if (!tb) ok = ok && (c[0] == 63) + (c[1] == 63) + (c[2] == 63) + (c[3] == 63) <= 1;   // (else the mixed level, dna.cpp:466-474)
+      if (ok) {
+        const u32 i = i0 + e;
+        const int cor_dist = tb ? (int)cfg->smer : (int)cfg->bmer, d = (int)i - (int)w.cor_pos;
+        const u32 cz = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
+        sb->sp_cq[e] = (u64)c[0] | ((u64)c[1] << 16) | ((u64)c[2] << 32) | ((u64)c[3] << 48);
+        sb->sp_lvz[e] = (u8)((tb ? LV_SMER : LV_BMER) | (cz << 4));
+        sb->sp_kind[e] = SK_RANK_PENDING;
+        sb->sp_rep[e] = 0xff;     // (no repair while the b-mer is partial, dna.cpp:856)
+        sb->sp_flag[e] = 1;
+        const u32 pf = sb->pv_flag[e];
+        if (pf & PV_PCAND) sb->pv_flag[e] = (u8)(pf | PV_P);   // (the p-mer entry is only hidden under a full b-mer, dna.cpp:822-830)
+        np = cnt;
+        nsl = nn;
+      }
+    }
+  }
+  np = wave_sum32(np); nsl = wave_sum32(nsl);
+  FQ_SYNC();
+  if (FQ_LANE == 0) { sb->h_np += np; sb->h_ns += nsl; }
+  FQ_SYNC();
+}
 #endif
 
 // find_counts, dna.cpp:457-502.  b_miss_known: the speculation stage already probed the global
@@ -3442,7 +3493,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         TM_COUNT(w, CN_SC_CHUNK);
 #if FQ_WAVE > 1
         TM_BEGIN(t_se);
-        if (i0 == base_pos) scout_early(w, n);   // (the look-ups of positions whose b-mer is still partial, if any)
+        if (i0 == base_pos) { scout_early(w, n); scout_settle_early(w, i0, n); }   // (the look-ups of positions whose b-mer is still partial, if any)
         TM_END(w, TM_SC_EARLY, t_se);
         const u32 front0 = scout_rough_first(w, n);
 #else
@@ -3543,7 +3594,7 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
       if (!whole) { TM_COUNT(w, CN_SC_ABORT); break; }
       TM_COUNT(w, CN_SC_CHUNK);
 #if FQ_WAVE > 1
-      if (i0 == base_pos) scout_early(w, n);   // (the look-ups of positions whose b-mer is still partial, if any)
+      if (i0 == base_pos) { scout_early(w, n); scout_settle_early(w, i0, n); }   // (the look-ups of positions whose b-mer is still partial, if any)
       const u32 front0 = scout_rough_first(w, n);
 #else
       const u32 front0 = FQSX_SPEC;
