@@ -76,7 +76,7 @@ struct WgShared {
   u32 hd_ready, hd_taken;      // read heads finished / consumed (free-running counts within the launch)
   u32 mt[4][624];              // MT19937 states of cinc_b, cinc_s, cinc_lb, cinc_ls
   u32 mt_idx[4];
-  u8 rd[2][FQSX_RD_LDS];       // 2-bit codes (0..4) of the current read (two buffers: the head wave stages the next read)
+  alignas(8) u8 rd[2][FQSX_RD_LDS];       // 2-bit codes (0..4) of the current read (two buffers: the head wave stages the next read)
   u64 bk_key[256];             // probe batch: normalised k-mers
   u32 bk_res[256][4];          // probe batch: counts
   u8 bk_dir[256];              // probe batch: orientation
@@ -397,6 +397,13 @@ FQ_DEV Kmer km_roll(const Kmer &b, const KGeom &g, u32 j, u64 fw, u64 rv, u32 L)
   }
   return r;
 }
+#if FQ_WAVE > 1
+// the 32 two-bit symbols of x in reverse order
+FQ_DEV u64 pairrev64(u64 x) {
+  const u64 r = ((u64)__builtin_bitreverse32((u32)x) << 32) | __builtin_bitreverse32((u32)(x >> 32));
+  return ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+}
+#endif
 FQ_DEV bool km_norm_dir(const Kmer &k, const KGeom &g) { return (k.dir & g.kernel_mask) < (k.rc & g.kernel_mask); }
 FQ_DEV u64 km_norm(const Kmer &k, const KGeom &g) { return km_norm_dir(k, g) ? k.dir : k.rc; }
 FQ_DEV u64 km_aligned_dir(const Kmer &k) { return k.cur ? k.dir >> (64 - 2 * k.cur) : 0; }  // kmer.h:398 (quirk 18)
@@ -1754,7 +1761,8 @@ FQ_DEV void scout_settle_early(Wk &w, u32 i0, u32 n) {
         if (pf & PV_PCAND) sb->pv_flag[e] = (u8)(pf | PV_P);   // (the p-mer entry is only hidden under a full b-mer, dna.cpp:822-830)
         np = cnt;
         nsl = nn;
-      }
+      } else if (!tb && (c[0] | c[1] | c[2] | c[3]) != 0)
+        sb->sp_flag[e] = 4;   // the look-up hits, but its merges draw: they are all that is left to the resolving wave
     }
   }
   np = wave_sum32(np); nsl = wave_sum32(nsl);
@@ -1998,18 +2006,45 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
   const u32 b0 = i0 - joff;   // position the k-mers in w stand before
   bool gave_up = false;
   for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
+    TM_BEGIN(t_roll);
     // roll the six k-mers J symbols forward in closed form: only the last min(J, k) new symbols matter
     u64 fw = 0, rv = 0;   // new symbols packed oldest-first (fw) and complemented newest-first (rv)
     const u32 J = j + joff;
     const u32 L = J < 27 ? J : 27;
-    for (u32 s = 0; s < L; ++s) {
-      u32 c = rd_sym(w, p, i0 + j - L + s, size);
-      u64 ck = c == 4 ? 0 : c;
-      fw = (fw << 2) | ck;
-      rv |= (3 - ck) << (2 * s);
-    }
     u32 nrun = 0;
-    {
+    bool windowed = false;
+#if FQ_WAVE > 1
+    if (size <= FQSX_RD_LDS) {
+      // the read's codes are staged in LDS, one byte per base: the 28 bases before this position come in as eight
+      // aligned words, each squeezed to 4 x 2 bits (and 4 N flags) by one multiplication
+      const u32 i = i0 + j, start = i >= 28 ? i - 28 : 0, a = start & ~3u, sh = a + 32 - i;   // base x sits at pair a + 31 - x
+      const u32 *wp = (const u32 *)(w.rdp + a);
+      u64 P = 0;
+      u32 N32 = 0;
+#pragma unroll
+      for (u32 q = 0; q < 8; ++q) {
+        const u32 x = wp[q];
+        P = (P << 8) | (((x & 0x03030303u) * 0x40100401u) >> 24);
+        N32 = (N32 << 4) | (((((x >> 2) & 0x01010101u) * 0x08040201u) >> 24) & 15u);
+      }
+      if (L) {
+        fw = (P >> (2 * sh)) & ((1ull << (2 * L)) - 1ull);
+        rv = ~pairrev64(fw) >> (64 - 2 * L);
+      }
+      const u32 win = 32 - sh;                                     // bases a .. i-1 are in the window
+      const u32 runN = sh < 32 ? ctz64(~(u64)(N32 >> sh)) : 0;     // N run ending at base i-1, as far as the window shows
+      if (runN >= J) { nrun = J + w.N_run; windowed = true; }
+      else if (runN < win) { nrun = runN; windowed = true; }
+      else fw = rv = 0;                                            // (a run of >= 28 N: counted the long way below)
+    }
+#endif
+    if (!windowed) {
+      for (u32 s = 0; s < L; ++s) {
+        u32 c = rd_sym(w, p, i0 + j - L + s, size);
+        u64 ck = c == 4 ? 0 : c;
+        fw = (fw << 2) | ck;
+        rv |= (3 - ck) << (2 * s);
+      }
       u32 s = J;
       while (s > 0 && rd_sym(w, p, b0 + s - 1, size) == 4) { --s; ++nrun; }
       if (s == 0) nrun += w.N_run;
@@ -2032,6 +2067,8 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
     c4_zero(c);
     const bool b_full = bm.cur == cfg->gb.k;
     if (w.sc_poll && lds_load_acq(&w.sm->sc_req_seq) != w.sc_epoch) { gave_up = true; break; }   // (the same answer in every lane that asks)
+    TM_END(w, TM_SP_ROLL, t_roll);
+    TM_BEGIN(t_probe);
     if (b_full) {
       bool nd = km_norm_dir(bm, cfg->gb);
       u64 key = nd ? bm.dir : bm.rc;
@@ -2050,6 +2087,8 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
       }
       tab_rest(cfg->g_b, fb, key, nd, c, ns);
       ++np;
+      TM_END(w, TM_SP_PROBE, t_probe);
+      TM_BEGIN(t_hit);
       if (c4_any(c)) {
         u32 sat = (c.c[0] == 63) + (c.c[1] == 63) + (c.c[2] == 63) + (c.c[3] == 63);
         if (sat <= 1 && nrun < 2) {
@@ -2064,6 +2103,7 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           // repair_kmers_existing decision (dna.cpp:333-360)
           rep = repair_decide(w, c, sym);
         }
+        TM_END(w, TM_SP_HIT, t_hit);
       } else {
         // global b-mer miss; the local probes see the tables as of the last flush
         flag = 3;
@@ -2095,6 +2135,7 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           }
         }
         w.sb->sx_flag[j] = (u8)xf;
+        TM_END(w, TM_SP_MISS, t_hit);
       }
     }
     w.sb->sp_flag[j] = (u8)flag;
@@ -2801,6 +2842,27 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         bool rough = false, loaded = false, resolved = false;
         TM_COUNT(w, CN_SLOW);
         const u32 xf = flag == 3 ? w.sb->sx_flag[j] : 0;
+        const bool early_b = flag == 4;
+        if (early_b) {
+          // early position, b-mer almost full; the scout wave has probed its paddings in the global table and seen hits
+          // (scout_settle_early): find_counts (dna.cpp:461-476) comes down to the merges, in trial order
+          Kmer bmj;
+          bmj.dir = bmj.rc = 0; bmj.cur = w.sb->sp_scur[2][j];
+          kt_find(w, cfg->g_b, true, cfg->gb, bmj, RNG_B, CINC_B, counts, w.sb->ep_off[j][0]);
+          resolved = true;
+          level = LV_BMER;
+          if ((counts.c[0] == 63) + (counts.c[1] == 63) + (counts.c[2] == 63) + (counts.c[3] == 63) > 1) {   // dna.cpp:466-474
+            flush_pushes(w, q_done, j);
+            q_done = j;
+            load_state(w, j);
+            loaded = true;
+            nrun_here = w.N_run;
+            C4 c2;
+            kt_find(w, cfg->g_s, true, cfg->gs, w.sm_, RNG_S, CINC_S, c2);
+            counts.c[0] += c2.c[0]; counts.c[1] += c2.c[1]; counts.c[2] += c2.c[2]; counts.c[3] += c2.c[3];
+            level = LV_MIXED;
+          }
+        }
         if (xf & SX_VALID) {
           // the cascade was resolved in stage P; it stands unless a pending local insert interferes
           Kmer bmj, smj;
@@ -2919,14 +2981,14 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           // stage P's entries stand (k-mers unmodified); settle the p-mer entry, which depends on the level
           u32 pf = w.sb->pv_flag[j];
           if (pf & PV_PCAND) {
-            pf |= (lvl_sbm && c4_get(counts, sym) >= 3) ? PV_PHID : PV_P;   // the b-mer is full on this path
+            pf |= (!early_b && lvl_sbm && c4_get(counts, sym) >= 3) ? PV_PHID : PV_P;   // (hidden only under a full b-mer)
             FQ_SYNC();
             if (FQ_LANE == 0) w.sb->pv_flag[j] = (u8)pf;
             FQ_SYNC();
           }
         }
         // repairs need the exact k-mers only when they can fire
-        const bool b_full = loaded ? km_full(w.bm, cfg->gb) : true;
+        const bool b_full = loaded ? km_full(w.bm, cfg->gb) : !early_b;
         if (b_full) {
           const bool chk_existing = level == LV_BMER || level == LV_MIXED;
           const bool chk_missing = (level == LV_NONE || level == LV_PMER) && w.repm_gate;

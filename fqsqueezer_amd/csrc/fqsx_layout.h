@@ -132,7 +132,8 @@ enum { TM_TOTAL = 0, TM_SPEC, TM_FAST, TM_SLOW, TM_POST, TM_READ_HEAD, TM_LQ, TM
        TM_CODER_IDLE /* coder wave: queue empty */, TM_SCOUT_WAIT /* scout wave: ring full or no read head yet */, TM_SPRE,
        TM_CR_S, TM_CR_MID, TM_CR_AVG, TM_CR_RC, TM_KEYS,
        TM_SC_SPEC /* scout waves: stage P */, TM_SC_EARLY, TM_SC_ROUGH /* ... their sweeps */, TM_SC_IDLE /* ... nothing left to do */, CN_SC_CHUNK, CN_SC_ABORT,
-       TM_N };
+       TM_SP_ROLL /* stage P: k-mer roll */, TM_SP_PROBE /* ... global b-mer probe */,
+       TM_N, TM_SP_HIT = 46 /* ... keys, rank, repair decision of a hit */, TM_SP_MISS = 47 /* ... miss cascade */ };
 #ifdef FQSX_TIMING
 #define FQSX_TM_SLOTS 48
 #else

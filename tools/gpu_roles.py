@@ -61,6 +61,9 @@ def report(tr, tag):
 
 tr = buf[:n].astype(np.int64)
 report(tr[:min(n, 2100)], "blocks 0..69 (two reads per worker and launch)")
+for a, b in ((0, 10), (10, 30), (30, 70)):
+    if n >= 30 * b:
+        report(tr[30 * a:30 * b], f"blocks {a}..{b - 1}")
 if nblk > 110 and n > 2100:
     k = nblk - 100
     report(tr[n - k:], "blocks >= 100 (one launch per block)")

@@ -67,3 +67,5 @@ if ib[5]:
     print("global insert batches:", {"batches": ib[5], "rounds": ib[4], "probe walk s": round(ib[0] * 1e-8, 3), "clash test s": round(ib[1] * 1e-8, 3),
                                      "draws + stores s": round(ib[2] * 1e-8, 3), "store wait s": round(ib[3] * 1e-8, 3),
                                      "us per batch": round(sum(ib[:4]) * 1e-2 / ib[5], 2)})
+sp = [st["timers"][i] * 1e-8 for i in (38, 39, 46, 47)]
+print("stage P sections (wave clock at each lane's branch; summed over scouts) s:", {"roll": round(sp[0], 2), "global b probe": round(sp[1], 2), "hit: keys/rank/repair": round(sp[2], 2), "miss cascade": round(sp[3], 2)})
