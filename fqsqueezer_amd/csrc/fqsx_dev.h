@@ -119,7 +119,7 @@ struct WgShared {
   u64 pq_key[2][FQSX_PQ];      // LDS mirror of the most recent b / s list entries (ring indexed by list position)
   u64 ib_pos[64];              // insert_batch: target slot per lane
   u64 ib_hash[256];            // ... and the lanes per slot bucket
-  u32 qm_bits[4][128];         // quiet_miss_mask: 4096-bit sets of the sibling groups of recent list entries (b dir, b rc, s dir, s rc)
+  alignas(8) u32 qm_bits[4][128];         // quiet_miss_mask: 4096-bit sets of the sibling groups of recent list entries (b dir, b rc, s dir, s rc)
   // hand-off words of the local-table inserter wave: list entries published / applied per kind (b, s); quit
   u32 lq_target[2], lq_done[2], lq_quit;
   // coding queue: every symbol of the worker's stream in stream order, as the context keys of a rank-/letter-coded
@@ -231,7 +231,7 @@ struct Wk {
 // role time stamps of one launch (timing builds): 0 resolve start, 1 head end, 2 resolve end, 3 coder end, 4 scout end,
 // 5 inserter end, 6 resolve: reads done (before the final flush of the local inserts)
 #define FQSX_TRACE_LAUNCHES 4096u
-#define FQSX_TRACE_W 16u   /* 8 clock stamps + 8 per-launch counters of the resolving wave */
+#define FQSX_TRACE_W 32u   /* 8 clock stamps + 24 per-launch counters / section times of the resolving wave */
 #ifdef FQSX_TIMING
 #define TM_STAMP(cfg, tid, launch, slot) do { if ((cfg).trace && (launch) < FQSX_TRACE_LAUNCHES && FQ_LANE == 0) (cfg).trace[((u64)(launch) * (cfg).T + (tid)) * FQSX_TRACE_W + (slot)] = fq_clock(); } while (0)
 #define TM_TRACE_VAL(cfg, tid, launch, slot, v) do { if ((cfg).trace && (launch) < FQSX_TRACE_LAUNCHES && FQ_LANE == 0) (cfg).trace[((u64)(launch) * (cfg).T + (tid)) * FQSX_TRACE_W + (slot)] = (v); } while (0)
@@ -2604,6 +2604,7 @@ FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reverse
   WgShared *sm = w.sm;
   code_keys(w, p, size, i0, m, reversed, hist_start);
   TM_END(w, TM_KEYS, t_c2);
+  TM_BEGIN(t_cq);
   if (!cq_wait_space(w, m)) return;
   for (u32 j = FQ_LANE; j < m; j += FQ_WAVE) {
     const u32 e = (w.cq_tail + j) & (FQSX_CQ - 1);
@@ -2616,6 +2617,7 @@ FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reverse
   FQ_SYNC();
   first = false;
   cq_publish(w, m);
+  TM_END(w, TX_CHUNKQ, t_cq);
   if (!w.piped) {
     while (w.cq_head != w.cq_tail && !w.err) w.cq_head += cq_process(w, w.cq_head, w.cq_tail - w.cq_head);
     TM_END(w, TM_FAST, t_c2);
@@ -2665,16 +2667,34 @@ FQ_DEV u64 quiet_miss_mask(Wk &w, u32 n) {
   FQ_SYNC();
   const u32 hb = grp_hash(gb), hs = grp_hash(gs);
   bool maybe = ((sm->qm_bits[ndb ? 0 : 1][hb >> 5] >> (hb & 31)) & 1u) != 0 || ((sm->qm_bits[nds ? 2 : 3][hs >> 5] >> (hs & 31)) & 1u) != 0;
-  // the entries of the chunk's earlier positions, exactly
-  for (u32 t = 0; t + 1 < n; ++t) {
-    const u32 f = sb->pv_flag[t];
-    if (f & PV_B) {
-      const u64 pv = sb->pv_b[t] >> (64 - k2b);
-      maybe |= lane > t && (ndb ? (pv >> 2) == gb : (pv & lmb) == gb);
+  // the entries of the chunk's earlier positions, exactly: every position files its lane under the 6-bit hashes of its
+  // entries' groups (both readings; the bit sets above are reused as 4 x 64 lane masks), and a lane compares groups
+  // only with the earlier lanes filed where its own group hashes to
+  FQ_SYNC();
+  u64 *lm = (u64 *)&sm->qm_bits[0][0];   // [4][64]
+  for (u32 i = lane; i < 4 * 64; i += FQ_WAVE) lm[i] = 0;
+  FQ_SYNC();
+  const u32 myf = lane < n ? sb->pv_flag[lane] : 0u;
+  if (myf & PV_B) {
+    const u64 pv = sb->pv_b[lane] >> (64 - k2b);
+    lds_or64(&lm[0 * 64 + (grp_hash(pv >> 2) & 63)], 1ull << lane);
+    lds_or64(&lm[1 * 64 + (grp_hash(pv & lmb) & 63)], 1ull << lane);
+  }
+  if (myf & PV_S) {
+    const u64 pv = sb->pv_s[lane] >> (64 - k2s);
+    lds_or64(&lm[2 * 64 + (grp_hash(pv >> 2) & 63)], 1ull << lane);
+    lds_or64(&lm[3 * 64 + (grp_hash(pv & lms) & 63)], 1ull << lane);
+  }
+  FQ_SYNC();
+  if (cand && !maybe) {
+    const u64 lt = (1ull << lane) - 1ull;
+    for (u64 c = lm[(ndb ? 0 : 64) + (hb & 63)] & lt; c && !maybe; c &= c - 1ull) {
+      const u64 pv = sb->pv_b[ctz64(c)] >> (64 - k2b);
+      maybe = ndb ? (pv >> 2) == gb : (pv & lmb) == gb;
     }
-    if (f & PV_S) {
-      const u64 pv = sb->pv_s[t] >> (64 - k2s);
-      maybe |= lane > t && (nds ? (pv >> 2) == gs : (pv & lms) == gs);
+    for (u64 c = lm[(nds ? 128 : 192) + (hs & 63)] & lt; c && !maybe; c &= c - 1ull) {
+      const u64 pv = sb->pv_s[ctz64(c)] >> (64 - k2s);
+      maybe = nds ? (pv >> 2) == gs : (pv & lms) == gs;
     }
   }
   return wave_ballot(cand && !maybe);
@@ -2758,7 +2778,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
     }
     u64 Qm = 0;       // positions nothing is found for anywhere unless their Hamming-1 sweep finds something (quiet_miss_mask)
 #if FQ_WAVE > 1
-    if (pre && !w.repm_gate) Qm = quiet_miss_mask(w, n);   // (with the gate open repair_kmers_missing may fire: per-position path)
+    { TM_BEGIN(t_qm); if (pre && !w.repm_gate) Qm = quiet_miss_mask(w, n); TM_END(w, TX_QMM, t_qm); }   // (with the gate open repair_kmers_missing may fire: per-position path)
 #endif
     u32 q_done = 0;   // chunk positions whose mailbox entries are already in the lists
     u32 w_pos = 0;    // w's k-mers = state before position w_pos of the chunk
@@ -2771,6 +2791,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       const u32 flag = w.sb->sp_flag[j];
 #if FQ_WAVE > 1
       if ((Qm >> j) & 1) {
+        TM_BEGIN(t_qr);
         // A stretch of positions where every look-up came up empty and the sweep did too: level none, the symbol is
         // letter-coded, stage P's mailbox entries stand (p-mer included), nothing draws from an RNG and no repair
         // can fire (dna.cpp:706-744,776-785,840-874) -- settled for the whole stretch in one lane-parallel step.
@@ -2802,8 +2823,10 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
 #endif
           j += len - 1;
           m = j + 1;
+          TM_END(w, TX_QRUN, t_qr);
           continue;
         }
+        TM_END(w, TX_QRUN, t_qr);
       }
 #endif
       TM_BEGIN(t_code);
@@ -2868,8 +2891,9 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           Kmer bmj, smj;
           bmj.dir = w.sb->sp_sdir[2][j]; bmj.rc = w.sb->sp_src[2][j]; bmj.cur = w.sb->sp_scur[2][j];
           smj.dir = w.sb->sp_sdir[1][j]; smj.rc = w.sb->sp_src[1][j]; smj.cur = w.sb->sp_scur[1][j];
-          bool conflict = pend_conflict(w, 0, cfg->gb, bmj, q_done, j);
-          if (!conflict && !(xf & (SX_LB | SX_S))) conflict = pend_conflict(w, 1, cfg->gs, smj, q_done, j);
+          // (a position of the quiet-miss mask has no such entry in either group: quiet_miss_mask)
+          bool conflict = ((Qm >> j) & 1) ? false : pend_conflict(w, 0, cfg->gb, bmj, q_done, j);
+          if (!conflict && !((Qm >> j) & 1) && !(xf & (SX_LB | SX_S))) conflict = pend_conflict(w, 1, cfg->gs, smj, q_done, j);
           if (!conflict) {
             resolved = true;
             TM_COUNT(w, CN_EXT);
@@ -3021,7 +3045,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       m = j + 1;
     }
     if (dirty) TM_COUNT(w, CN_DIRTY);
-    flush_pushes(w, q_done, m);
+    { TM_BEGIN(t_fl); flush_pushes(w, q_done, m); TM_END(w, TX_FLUSH, t_fl); }
     code_chunk(w, p, size, i, m, reversed, hist_start, first);
     lq_publish(w);   // (after the queue hand-off, whose release has already drained the list stores)
     if (w_pos != m) {  // the last committed position went through the fast path: materialise its state
@@ -3210,7 +3234,7 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
   if (FQ_LANE == 0) {
     for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
 #ifdef FQSX_TIMING
-    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
+    for (u32 i = 0; i < FQSX_TM_SLOTS && i < 48; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
 #endif
   }
   if (w.err) *cfg.err = w.err;
@@ -3277,7 +3301,7 @@ FQ_DEV void rc_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg, u
   if (FQ_LANE == 0) {
     for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
 #ifdef FQSX_TIMING
-    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
+    for (u32 i = 0; i < FQSX_TM_SLOTS && i < 48; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
 #endif
   }
   if (w.err) *cfg.err = w.err;
@@ -3580,7 +3604,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
   if (lds_load_acq(&sm->sc_dead)) lds_store_rel(&sm->sc_hd_taken[me], 0x7fffffffu);   // (the read-head wave does not wait for a scout that has left)
 #ifdef FQSX_TIMING
   if (FQ_LANE == 0)
-    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
+    for (u32 i = 0; i < FQSX_TM_SLOTS && i < 48; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
 #endif
   if (me == 0) TM_STAMP(cfg, tid, launch, 4);
 }
@@ -3673,7 +3697,7 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
   }
 #ifdef FQSX_TIMING
   if (FQ_LANE == 0)
-    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) if (w.tm[i]) atomic_add64(&w.ws->stat[16 + i], w.tm[i]);
+    for (u32 i = 0; i < FQSX_TM_SLOTS && i < 48; ++i) if (w.tm[i]) atomic_add64(&w.ws->stat[16 + i], w.tm[i]);
 #endif
   if (me == 0) TM_STAMP(cfg, tid, launch, 4);
 }
@@ -3764,6 +3788,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
 
   u64 cur = ws->cursor;
   w.pe_n = 0;
+  TM_END(w, TX_PROLOG, t_total);
   if (decode) {
     w.din = cfg.din + cfg.din_off[tid];
     w.din_len = cfg.din_off[tid + 1] - cfg.din_off[tid];
@@ -3837,13 +3862,19 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   TM_TRACE_VAL(cfg, tid, launch, 10, w.tm[CN_DIRTY]); TM_TRACE_VAL(cfg, tid, launch, 11, w.tm[CN_FAST]);
   TM_TRACE_VAL(cfg, tid, launch, 12, w.tm[TM_RRWAIT]); TM_TRACE_VAL(cfg, tid, launch, 13, w.tm[TM_SPEC]);
   TM_TRACE_VAL(cfg, tid, launch, 14, w.tm[CN_GENERIC]); TM_TRACE_VAL(cfg, tid, launch, 15, w.tm[TM_LQ]);
+#ifdef FQSX_TIMING
+  {
+    const u32 xs[16] = {TM_SLOW, TM_SPRE, TM_ROUGH, TM_FINDC, TM_POST, TM_KEYS, TM_READ_HEAD, TM_CQWAIT, TX_QMM, TX_QRUN, TX_PROLOG, TX_CHUNKQ, TX_FLUSH, TM_TOTAL, CN_CHUNK, CN_EXT};
+    for (u32 x = 0; x < 16; ++x) TM_TRACE_VAL(cfg, tid, launch, 16 + x, w.tm[xs[x]]);
+  }
+#endif
   if (!piped) {
     for (u32 i = 0; i < ST_N; ++i) ws->stat[i] += w.st[i];
     for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) ws->stat[16 + i] += w.tm[i];
   } else if (FQ_LANE == 0) {   // the coder wave adds to the same counters
     for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
 #ifdef FQSX_TIMING
-    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
+    for (u32 i = 0; i < FQSX_TM_SLOTS && i < 48; ++i) if (w.tm[i]) atomic_add64(&ws->stat[16 + i], w.tm[i]);
 #endif
   }
   FQ_SYNC();

@@ -133,9 +133,11 @@ enum { TM_TOTAL = 0, TM_SPEC, TM_FAST, TM_SLOW, TM_POST, TM_READ_HEAD, TM_LQ, TM
        TM_CR_S, TM_CR_MID, TM_CR_AVG, TM_CR_RC, TM_KEYS,
        TM_SC_SPEC /* scout waves: stage P */, TM_SC_EARLY, TM_SC_ROUGH /* ... their sweeps */, TM_SC_IDLE /* ... nothing left to do */, CN_SC_CHUNK, CN_SC_ABORT,
        TM_SP_ROLL /* stage P: k-mer roll */, TM_SP_PROBE /* ... global b-mer probe */,
-       TM_N, TM_SP_HIT = 46 /* ... keys, rank, repair decision of a hit */, TM_SP_MISS = 47 /* ... miss cascade */ };
+       TM_N, TM_SP_HIT = 46 /* ... keys, rank, repair decision of a hit */, TM_SP_MISS = 47 /* ... miss cascade */,
+       TX_QMM = 48 /* resolver: quiet_miss_mask */, TX_QRUN /* ... quiet stretches */, TX_PROLOG /* ... launch start to first read */,
+       TX_CHUNKQ /* ... chunk into the coding queue (after the keys) */, TX_FLUSH /* ... end-of-chunk flush_pushes */ };
 #ifdef FQSX_TIMING
-#define FQSX_TM_SLOTS 48
+#define FQSX_TM_SLOTS 56   /* [0..47] are summed into WState.stat[16..63]; [48..55] only go to the per-launch trace */
 #else
 #define FQSX_TM_SLOTS 1   /* (the timers only exist in the diagnostic build) */
 #endif

@@ -26,7 +26,7 @@ for g, idx in enumerate(blocks):
     c.encode_block(bases, off, g)
 c._lib.fqsx_dna_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 c._lib.fqsx_dna_trace.restype = C.c_int
-buf = np.zeros((4096, T, 16), dtype=np.uint64)
+buf = np.zeros((4096, T, 32), dtype=np.uint64)
 n = c._lib.fqsx_dna_trace(c._h, buf.ctypes.data, 4096)
 names = ["head", "resolve", "models", "scout", "inserter", "range coder"]
 slots = [1, 2, 3, 4, 5, 7]   # (slot 6: resolving wave, reads done)
@@ -54,6 +54,13 @@ def report(tr, tag):
     vals[:, :, [4, 5, 7]] *= 0.01
     res["resolver_counters_mean_worker"] = {cn[k]: round(float(vals[:, :, k].mean()), 2) for k in range(8)}
     res["resolver_counters_slowest_worker"] = {cn[k]: round(float(np.mean([vals[i, last_worker[i], k] for i in range(n)])), 2) for k in range(8)}
+    xn = ["slow path", "slow: resolve counts", "slow: sweep merge (+frontier wait)", "find_counts", "flush_pushes (all)", "code_keys", "read head wait", "coding-queue wait",
+          "quiet_miss_mask", "quiet stretches", "prologue", "chunk into queue", "end-of-chunk flush", "total"]
+    xv = tr[:, :, 16:30].astype(np.float64) * 0.01
+    res["resolver_sections_us_mean_worker"] = {xn[k]: round(float(xv[:, :, k].mean()), 1) for k in range(14)}
+    res["resolver_sections_us_slowest_worker"] = {xn[k]: round(float(np.mean([xv[i, last_worker[i], k] for i in range(n)])), 1) for k in range(14)}
+    res["chunks_mean_slowest"] = [round(float(tr[:, :, 30].mean()), 2), round(float(np.mean([tr[i, last_worker[i], 30] for i in range(n)])), 2)]
+    res["ext_positions_mean_slowest"] = [round(float(tr[:, :, 31].mean()), 2), round(float(np.mean([tr[i, last_worker[i], 31] for i in range(n)])), 2)]
     rend = ends[:, :, 1]   # resolving wave's end per worker
     res["corr_resolve_end_with"] = {cn[k]: round(float(np.corrcoef(rend.reshape(-1), vals[:, :, k].reshape(-1))[0, 1]), 3) for k in range(8)}
     print(json.dumps(res))
