@@ -1561,6 +1561,13 @@ FQ_DEV bool rough_kt(Wk &w, const KTab &t, const KGeom &g, const Kmer &can, u32 
 FQ_DEV bool rough_merge_pre(Wk &w, u32 r, u32 j, const KGeom &g, u32 rng, const Cinc &ci, C4 &counts) {
   WgShared *sm = w.sm;
   c4_zero(counts);
+  if (r == 0xfd) {   // the hits' counts added up by the scout wave (no merge of theirs can draw: scout_rough)
+    const u64 v = w.sb->rc_val[j][0];
+    counts.c[0] = (u32)(v & 0xffff); counts.c[1] = (u32)((v >> 16) & 0xffff); counts.c[2] = (u32)((v >> 32) & 0xffff); counts.c[3] = (u32)(v >> 48);
+    w.st[ST_GPROBE] += 4 * (g.k - 1);
+    w.st[ST_GSLOT] += w.sb->rc_ns[j] + g.k - 1;
+    return c4_any(counts);
+  }
   if (r == 0xfe) {   // compact form: the hits' counts are stored in probe order
     u32 x = 0;
     for (u64 mk = w.sb->rc_hit[j]; mk; mk &= mk - 1, ++x) {
@@ -1646,7 +1653,22 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
       const u32 nh = popc64(hm), j = js[q];
       if (nh <= 3) {
         if (res != 0) sb->rc_val[j][popc64(hm & lt)] = res;
-        if (lane == 0) { sb->rc_hit[j] = hm; sb->rc_ns[j] = nsum; sb->rr_idx[j] = 0xfe; }
+        u32 form = 0xfe;
+        if (nh) {
+          // Merging the hits' counts (Increment(a, b), utils.h:327-333) is plain addition, and draws nothing, as long as
+          // every sum stays within the exact range of the counter code: then the sums are stored in place of the hits
+          FQ_SYNC();
+          u64 sum = 0;
+          for (u32 x = 0; x < nh; ++x) sum += sb->rc_val[j][x];   // (<= 3 x 63 per 16-bit field)
+          const u32 thr = (CINC_B).thr;
+          const bool exact = (u32)(sum & 0xffff) <= thr && (u32)((sum >> 16) & 0xffff) <= thr && (u32)((sum >> 32) & 0xffff) <= thr && (u32)(sum >> 48) <= thr;
+          FQ_SYNC();
+          if (exact) {
+            form = 0xfd;
+            if (lane == 0) sb->rc_val[j][0] = sum;
+          }
+        }
+        if (lane == 0) { sb->rc_hit[j] = hm; sb->rc_ns[j] = nsum; sb->rr_idx[j] = (u8)form; }
       } else if (big < FQSX_RR) {
         if (in) sb->rr_res[big][lane] = res;
         if (lane == 0) { sb->rr_hit[big] = hm; sb->rr_ns[big] = nsum; sb->rr_idx[j] = (u8)big; }
@@ -2803,14 +2825,21 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         }
         TM_END(w, TM_RRWAIT, t_rrw);
         const u32 t = FQ_LANE;
-        const bool empty = t < front && t < n && ((Qm >> t) & 1) && w.sb->rr_idx[t] == 0xfe && w.sb->rc_hit[t] == 0;
+        const u32 form = t < n ? w.sb->rr_idx[t] : 0xffu;
+        const bool summed = form == 0xfd;   // ... or the sweep's hits merge without a draw (scout_rough): level pmer, rough
+        const bool empty = t < front && t < n && ((Qm >> t) & 1) && ((form == 0xfe && w.sb->rc_hit[t] == 0) || summed);
         const u64 run = wave_ballot(empty) >> j;
         const u32 len = ~run ? ctz64(~run) : 64u;
         if (len) {
           const bool in = t >= j && t < j + len;
           u32 nsl = 0;
           if (in) {
-            w.sb->sp_kind[t] = SK_LETTER_PENDING;
+            if (summed && w.sb->sp_nrun[t] < 2) {   // dna.cpp:737-775 with cor_zone 3 (rough)
+              w.sb->sp_cq[t] = w.sb->rc_val[t][0];
+              w.sb->sp_lvz[t] = (u8)(LV_PMER | (3u << 4));
+              w.sb->sp_kind[t] = SK_RANK_PENDING;
+            } else
+              w.sb->sp_kind[t] = SK_LETTER_PENDING;
             const u32 pf = w.sb->pv_flag[t];
             if (pf & PV_PCAND) w.sb->pv_flag[t] = (u8)(pf | PV_P);
             nsl = w.sb->rc_ns[t];
