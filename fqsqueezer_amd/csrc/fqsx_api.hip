@@ -35,8 +35,15 @@ extern "C" const char *fqsx_version(void) {
 // ---------------------------------------------------------------------------------------
 // kernels.  The encode / decode kernels live in translation units of their own (fqsx_k_se.hip, fqsx_k_pe.hip,
 // fqsx_k_dec.hip; launchers in fqsx_kernels.h); here: the insert phase, the mailbox partition, growth, the block epilogue.
+// Deferred growth check (single-end encoding): the host queues the kernels of all phases of a block without reading
+// anything back.  The group-offset kernel of a phase sees the exact demand of the coming inserts; if a sub-table would
+// pass the load the host grows it at, it posts the phase (err[1] = segment + 1) instead, and every later kernel of the
+// queue -- the inserts of that phase included -- does nothing.  The host finds the word with the end-of-block transfer,
+// grows the tables and takes the block up again at that phase's inserts (block_recover).  err[0]: device error word.
+FQ_DEV bool phase_skip(const DevCfg &cfg) { return (cfg.err[0] | cfg.err[1]) != 0; }
 FQ_KERNEL64 void k_insert_phase(DevCfg cfg) {  // grid = 3 * T: (owner, mailbox kind)
   FQ_SHARED InsShared sm;
+  if (phase_skip(cfg)) return;
   insert_phase_body(cfg, &sm, FQ_BLOCK / 3, FQ_BLOCK % 3);
 }
 // gathers the T streams of the block into one contiguous buffer (one D2H transfer per block)
@@ -50,18 +57,20 @@ FQ_KERNEL64 void k_compact_streams(DevCfg cfg, const u64 *lens, u8 *dst) {
 }
 // ClearKmersToHT (dna.cpp:2475-2488): the workers' local tables and their fill counters, in one launch
 FQ_KERNEL64 void k_clear_local(DevCfg cfg, u64 nb_slots, u64 ns_slots) {
+  if (phase_skip(cfg)) return;
   const u64 stride = (u64)FQ_NBLOCKS * FQ_WAVE, first = (u64)FQ_BLOCK * FQ_WAVE + FQ_LANE;
   for (u64 i = first; i < nb_slots; i += stride) cfg.l_b.slots[i] = 0;
   for (u64 i = first; i < ns_slots; i += stride) cfg.l_s.slots[i] = 0;
   for (u64 i = first; i < 2ull * cfg.T; i += stride) cfg.l_s.filled[i] = 0;   // l_s.filled and l_b.filled are adjacent
 }
-FQ_KERNEL64 void k_finish_block(DevCfg cfg, u64 *lens /*[T+1]*/, u64 *end /*[2T+1]: lengths, context occupancies, error word*/) {
+FQ_KERNEL64 void k_finish_block(DevCfg cfg, u64 *lens /*[T+1]*/, u64 *end /*[2T+2]: lengths, context occupancies, error word, posted phase*/) {
   if (FQ_LANE == 0) {
+    if (FQ_BLOCK == 0) { end[2 * cfg.T] = cfg.err[0]; end[2 * cfg.T + 1] = cfg.err[1]; }
+    if (cfg.err[1]) return;   // the block is not finished yet (see phase_skip)
     finish_block_body(cfg, FQ_BLOCK);
     lens[FQ_BLOCK] = cfg.ws[FQ_BLOCK].out_len;
     end[FQ_BLOCK] = cfg.ws[FQ_BLOCK].out_len;
     end[cfg.T + FQ_BLOCK] = cfg.ctx_filled[FQ_BLOCK];
-    if (FQ_BLOCK == 0) end[2 * cfg.T] = *cfg.err;
   }
 }
 // gathers the per-worker accounting counters: out[i] = sum over workers of stat[i]
@@ -86,11 +95,17 @@ FQ_DEV void part_split(const DevCfg &cfg, u32 &kind, u32 &blk) {
 FQ_KERNEL64 void k_part_count(DevCfg cfg) {
   FQ_SHARED u32 hist[256];
   u32 kind, blk;
+  if (phase_skip(cfg)) return;
   part_split(cfg, kind, blk);
   part_count_body(cfg, kind, blk, hist);
 }
-FQ_KERNEL64 void k_part_scan(DevCfg cfg) { part_scan_body(cfg, FQ_BLOCK / cfg.T, FQ_BLOCK % cfg.T); }
-FQ_KERNEL64 void k_part_dstoff(DevCfg cfg, u32 *demand /*[2][T]+1*/) {
+FQ_KERNEL64 void k_part_scan(DevCfg cfg) {
+  if (phase_skip(cfg)) return;
+  part_scan_body(cfg, FQ_BLOCK / cfg.T, FQ_BLOCK % cfg.T);
+}
+// seg1: segment + 1 when the growth check is left to this kernel (else 0: the host reads `demand` before the inserts)
+FQ_KERNEL64 void k_part_dstoff(DevCfg cfg, u32 *demand /*[2][T]+1*/, u32 seg1) {
+  if (cfg.err[0] || (cfg.err[1] && cfg.err[1] != seg1)) return;   // (another workgroup of this launch may just have posted the phase)
   part_dstoff_body(cfg, FQ_BLOCK);
   // per-owner demand of the coming insert phase (s- and b-mers) + the device error word
   // per-owner demand of the coming insert phase (s- and b-mers), current occupancy, and the device error word:
@@ -102,11 +117,18 @@ FQ_KERNEL64 void k_part_dstoff(DevCfg cfg, u32 *demand /*[2][T]+1*/) {
       demand[2 * cfg.T + 1 + o] = (FQ_BLOCK == MAIL_S ? cfg.g_s : cfg.g_b).filled[d];
     }
   if (FQ_BLOCK == 0 && FQ_LANE == 0) demand[2 * cfg.T] = *cfg.err;
+  if (seg1 && FQ_BLOCK != MAIL_P) {   // the host's growth rule (block_segment): occupancy after the inserts <= cap / 2
+    const KTab &t = FQ_BLOCK == MAIL_S ? cfg.g_s : cfg.g_b;
+    bool over = false;
+    for (u32 d = FQ_LANE; d < cfg.T; d += FQ_WAVE) over |= ((u64)t.filled[d] + cfg.mail[FQ_BLOCK].dst_tot[d]) * 2 > t.cap_mask + 1;
+    if (wave_any(over) && FQ_LANE == 0) cfg.err[1] = seg1;
+  }
 }
-FQ_KERNEL64 void k_part_scatter(DevCfg cfg) {
+FQ_KERNEL64 void k_part_scatter(DevCfg cfg, u32 seg1) {
   FQ_SHARED u32 cursor[256];
   FQ_SHARED u32 ld[64];
   u32 kind, blk;
+  if (cfg.err[0] || (cfg.err[1] && cfg.err[1] != seg1)) return;   // (the posted phase's own scatter runs: its inserts follow the growth)
   part_split(cfg, kind, blk);
   part_scatter_body(cfg, kind, blk, cursor, ld);
 }
@@ -796,6 +818,33 @@ int clear_local_tables(fqsx_dna *c) {
   return FQSX_OK;
 }
 
+// growth decision from the demand words (k_part_dstoff): a sub-table is at most half full after the coming inserts
+int grow_for_demand(fqsx_dna *c) {
+  const u32 T = c->T;
+  DevCfg &cfg = c->cfg;
+  int rc;
+  for (int which = 0; which < 2; ++which) {
+    KTab &t = which ? cfg.g_b : cfg.g_s;
+    u64 &cap = which ? c->gb_cap : c->gs_cap;
+    u64 need = 0;
+    for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_demand[2 * T + 1 + which * T + o] + c->h_demand[which * T + o]);
+    if (need * 2 > cap && (rc = grow_global(c, t, cap, pow2_at_least(need * 2 + 2)))) return rc;
+  }
+  return FQSX_OK;
+}
+// The device stopped the block's queue before the inserts of segment `seg` (phase_skip): grow, then take up from there
+int block_recover(fqsx_dna *c, u32 seg) {
+  const u32 T = c->T;
+  int rc;
+  if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, (4 * T + 1) * sizeof(u32)))) return rc;
+  const u64 before = c->gs_cap + c->gb_cap;
+  if ((rc = grow_for_demand(c))) return rc;
+  if (c->gs_cap + c->gb_cap == before) { g_err = "phase " + std::to_string(seg) + " posted for growth, but no table needs it"; return FQSX_E_DEVICE; }
+  if ((rc = dzero(c, c->cfg.err + 1, sizeof(u32)))) return rc;
+  LAUNCH(c, 1, k_insert_phase, 3 * T, 64, c->cfg);
+  return clear_local_tables(c);
+}
+
 // One synchronisation segment on one GPU: encode launch, mailbox partition, growth decision, insert phase, clear
 int block_segment(fqsx_dna *c, u32 seg) {
   const u32 T = c->T, n_reads = c->cur_n_reads;
@@ -809,22 +858,23 @@ int block_segment(fqsx_dna *c, u32 seg) {
     const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
     LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
     LAUNCH(c, 2, k_part_scan, 3 * T, 64, cfg);
-    LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand);
+    if (!c->paired && !decode) {
+      // single-end encoding: nothing is read back inside a block -- the growth check is the device's (phase_skip)
+      LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand, seg + 1);
+      LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, seg + 1);
+      LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg);
+      return clear_local_tables(c);
+    }
+    LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand, 0u);
     // the demand travels to the host while the scatter (which does not depend on the growth decision) runs
     if ((rc = d2h_small_begin(c, c->d_demand, (4 * T + 1) * sizeof(u32)))) return rc;
-    LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg);
+    LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, 0u);
     if ((rc = d2h_small_end(c, c->h_demand.data(), (4 * T + 1) * sizeof(u32)))) return rc;
     if (c->h_demand[2 * T]) {
       g_err = "device error " + std::to_string(c->h_demand[2 * T]) + " in encode kernel";
       return FQSX_E_DEVICE;
     }
-    for (int which = 0; which < 2; ++which) {
-      KTab &t = which ? cfg.g_b : cfg.g_s;
-      u64 &cap = which ? c->gb_cap : c->gs_cap;
-      u64 need = 0;
-      for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_demand[2 * T + 1 + which * T + o] + c->h_demand[which * T + o]);
-      if (need * 2 > cap && (rc = grow_global(c, t, cap, pow2_at_least(need * 2 + 2)))) return rc;
-    }
+    if ((rc = grow_for_demand(c))) return rc;
     if (c->paired) {  // pair table: size for the exact per-owner demand, then insert
       LAUNCH(c, 2, k_pe_demand, T, 64, cfg, c->d_demand);
       if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, T * sizeof(u32)))) return rc;
@@ -843,7 +893,9 @@ int block_segment(fqsx_dna *c, u32 seg) {
   return FQSX_OK;
 }
 
-int block_finish(fqsx_dna *c, const u64 *h_off, const u8 **streams, u64 *lens, u8 *bases_out) {
+// *posted (if asked for): segment + 1 of the phase the device stopped the queue at, 0 if the block is complete
+int block_finish(fqsx_dna *c, const u64 *h_off, const u8 **streams, u64 *lens, u8 *bases_out, u32 *posted = nullptr) {
+  if (posted) *posted = 0;
   const u32 T = c->T, n_reads = c->cur_n_reads, generation = c->cur_gen;
   const bool decode = c->cur_decode;
   DevCfg &cfg = c->cfg;
@@ -861,15 +913,20 @@ int block_finish(fqsx_dna *c, const u64 *h_off, const u8 **streams, u64 *lens, u
   LAUNCH(c, 2, k_finish_block, T, 64, cfg, c->d_lens, c->d_end);
   // ---- results: stream lengths, context-table occupancies (for the next block's sizing) and the error word at once
   {
-    std::vector<u64> e(2 * T + 1);
+    std::vector<u64> e(2 * T + 2);
     if ((rc = d2h_small_begin(c, c->d_end, e.size() * sizeof(u64)))) return rc;
     if ((rc = d2h_small_end(c, e.data(), e.size() * sizeof(u64)))) return rc;
-    for (u32 t = 0; t < T; ++t) { c->h_lens[t] = e[t]; c->h_filled[t] = (u32)e[T + t]; }
-    c->filled_valid = true;
     if (e[2 * T]) {
       g_err = "device error " + std::to_string(e[2 * T]) + " while encoding block " + std::to_string(generation);
       return FQSX_E_DEVICE;
     }
+    if (e[2 * T + 1]) {
+      if (posted) { *posted = (u32)e[2 * T + 1]; return FQSX_OK; }
+      g_err = "growth posted by the device outside the deferred path";
+      return FQSX_E_DEVICE;
+    }
+    for (u32 t = 0; t < T; ++t) { c->h_lens[t] = e[t]; c->h_filled[t] = (u32)e[T + t]; }
+    c->filled_valid = true;
   }
   u64 total = 0;
   for (u32 t = 0; t < T; ++t) {
@@ -900,8 +957,14 @@ int encode_block_impl(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u6
                       u8 *bases_out = nullptr) {
   if (c->shard_world > 1) { g_err = "a sharded codec is driven through fqsx_shard_* (fqsqueezer_amd/sharded.py)"; return FQSX_E_ARG; }
   int rc = block_prepare(c, d_bases, d_off, h_off, n_reads, generation, dec_streams, dec_lens);
-  for (u32 seg = 0; !rc && seg <= c->cur_S; ++seg) rc = block_segment(c, seg);
-  if (!rc) rc = block_finish(c, h_off, streams, lens, bases_out);
+  for (u32 seg = 0; !rc;) {
+    for (; !rc && seg <= c->cur_S; ++seg) rc = block_segment(c, seg);
+    u32 posted = 0;
+    if (!rc) rc = block_finish(c, h_off, streams, lens, bases_out, &posted);
+    if (rc || !posted) break;
+    rc = block_recover(c, posted - 1);   // (the queue stopped before that phase's inserts)
+    seg = posted;
+  }
   return rc;
 }
 
@@ -926,6 +989,7 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   cfg.siv_stats = (u64 *)p;
   // owner-sharded global tables (application.cpp:87-88; counters defs.h:26-27)
   c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(1024, (1ull << 22) / T));
+  if (const char *e = getenv("FQSX_GTAB_INIT")) c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(64, strtoull(e, nullptr, 10)));   // (tests: growth from tiny tables)
   if ((rc = ktab_alloc(c, cfg.g_s, T, c->gs_cap, cfg.smer, 12, true))) return rc;
   if ((rc = ktab_alloc(c, cfg.g_b, T, c->gb_cap, cfg.bmer, 6, true))) return rc;
   // local tables: geometry chosen per block; counters allocated here
@@ -1027,7 +1091,7 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   c->d_demand = (u32 *)p;
   if ((rc = dalloc(c, &p, ((u64)T + 64) * sizeof(u64), true))) return rc;
   c->d_lens = (u64 *)p;
-  if ((rc = dalloc(c, &p, (2 * (u64)T + 1) * sizeof(u64), true))) return rc;
+  if ((rc = dalloc(c, &p, (2 * (u64)T + 2) * sizeof(u64), true))) return rc;
   c->d_end = (u64 *)p;
 #ifndef FQSX_EMU
   HIPCHK(hipHostMalloc((void **)&c->h_pin, FQSX_PIN_BYTES));
@@ -1254,8 +1318,8 @@ int fqsx_shard_pack(fqsx_dna *c, const uint32_t *counts_sum /*[codec] summed ove
   if ((rc = d2d(c, c->d_cglob, counts_sum, 3ull * T * T * sizeof(u32)))) return rc;
   const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
   LAUNCH(c, 2, k_part_scan, 3 * T, 64, cfg);
-  LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand);
-  LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg);
+  LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand, 0u);
+  LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, 0u);
   std::vector<u32> tot(3 * (T + 1));
   for (u32 k = 0; k < 3; ++k)
     if ((rc = d2h_sync(c, tot.data() + k * (T + 1), cfg.mail[k].dst_off, (T + 1) * sizeof(u32)))) return rc;

@@ -11,6 +11,7 @@
 
 #ifndef FQSX_EMU
 FQ_KERNEL512 void k_encode_se_sorted(EncArgs a) {
+  if (a.cfg.err[0] | a.cfg.err[1]) return;   // the block's queue has been stopped (fqsx_api.hip: phase_skip)
   if (worker_elsewhere(a)) return;
   wg_handoff_init();
   switch (FQ_WAVE_ID) {
@@ -25,6 +26,7 @@ FQ_KERNEL512 void k_encode_se_sorted(EncArgs a) {
   }
 }
 FQ_KERNEL512 void k_encode_se_orig(EncArgs a) {
+  if (a.cfg.err[0] | a.cfg.err[1]) return;
   if (worker_elsewhere(a)) return;
   wg_handoff_init();
   switch (FQ_WAVE_ID) {
@@ -46,6 +48,7 @@ int fqsx_launch_encode_se(hipStream_t s, const EncArgs &a) {
 #else
 // host emulation: one 1-lane "wave" per worker runs the resolving body with everything inline
 static void fqsx_emu_encode_se(const EncArgs &a) {
+  if (a.cfg.err[0] | a.cfg.err[1]) return;
   for (u32 b = 0; b < a.cfg.T; ++b) {
     fq_emu_block = b;
     if (!shard_mine(a.cfg, b)) { for (u32 k = 0; k < 3; ++k) a.cfg.mail[k].n[b] = 0; continue; }

@@ -26,6 +26,16 @@ def test_emu_matches_reference_10k(name):
     assert st["bases"] > 0 and st["coded"] > 0 and st["gprobe"] > 0
 
 
+@pytest.mark.parametrize("name", ["c1_10k_s_t4.fqs", "c1_10k_o_t4.fqs"])
+def test_growth_posted_by_the_device_is_recovered(name, monkeypatch):
+    """Single-end encoding reads nothing back inside a block: when a phase's inserts would overfill a global sub-table,
+    the device stops the block's queue, and the host grows the tables and takes the block up at that phase's inserts
+    (fqsx_api.hip: phase_skip / block_recover).  Tables that start at 256 slots per owner make that happen in most
+    blocks; the streams stay the reference's."""
+    monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    check_against_fqs(emu, c1_records(), name)
+
+
 @pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
 def test_emu_matches_reference_ragged(name):
     check_against_fqs(emu, c4_records(), name)
