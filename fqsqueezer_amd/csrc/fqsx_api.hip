@@ -127,10 +127,11 @@ FQ_KERNEL64 void k_part_dstoff(DevCfg cfg, u32 *demand /*[2][T]+1*/, u32 seg1) {
 FQ_KERNEL64 void k_part_scatter(DevCfg cfg, u32 seg1) {
   FQ_SHARED u32 cursor[256];
   FQ_SHARED u32 ld[64];
+  FQ_SHARED u64 gm[256];
   u32 kind, blk;
   if (cfg.err[0] || (cfg.err[1] && cfg.err[1] != seg1)) return;   // (the posted phase's own scatter runs: its inserts follow the growth)
   part_split(cfg, kind, blk);
-  part_scatter_body(cfg, kind, blk, cursor, ld);
+  part_scatter_body(cfg, kind, blk, cursor, ld, gm);
 }
 // paired-end insert phase: per-owner demand, then the inserts
 FQ_KERNEL64 void k_pe_demand(DevCfg cfg, u32 *demand) {

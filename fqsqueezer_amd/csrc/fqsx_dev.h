@@ -2723,6 +2723,13 @@ FQ_DEV u64 quiet_miss_mask(Wk &w, u32 n) {
 }
 #endif
 
+// Length of the next chunk when `rem` suffix positions are left: as few chunks as the lanes allow, of equal length (a
+// 150 bp read: 45 + 45 + 45 rather than 64 + 64 + 7), so that the scout waves share a read's probes and sweeps evenly.
+// The resolving wave and the scout waves enumerate the chunks with this one rule.
+FQ_DEV u32 chunk_len(u32 rem) {
+  const u32 nch = (rem + FQSX_SPEC - 1) / FQSX_SPEC;
+  return (rem + nch - 1) / nch;
+}
 // hand-over of the scout waves' stage-P chunks (see scout_segment_body)
 FQ_DEV void scout_release(Wk &w) {
   w.sc_taken += 1;
@@ -2778,7 +2785,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
     scout_restart(w, w.sc_read, i, w.s_let);
   }
   while (i < size && !w.err) {
-    const u32 n = size - i < FQSX_SPEC ? size - i : FQSX_SPEC;
+    const u32 n = chunk_len(size - i);
     TM_BEGIN(t_sp);
     bool pre = false;
     if (w.scout && !w.sc_abandoned) pre = scout_take(w, i, n);   // stage P done ahead of time by the scout wave
@@ -3586,7 +3593,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         w.N_run = h_nrun;
       }
       w.sc_read = idx;
-      for (u32 i0 = base_pos; i0 < size && !quit && !restart; i0 += FQSX_SPEC, ++seq) {
+      for (u32 i0 = base_pos, n = 0; i0 < size && !quit && !restart && (n = chunk_len(size - i0)) != 0; i0 += n, ++seq) {
         if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
         if (seq % FQSX_NSC != me) continue;   // another wave's chunk
         spins = 0;
@@ -3598,7 +3605,6 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         }
         TM_END(w, TM_SCOUT_WAIT, t_w2);
         if (quit || restart) break;
-        const u32 n = size - i0 < FQSX_SPEC ? size - i0 : FQSX_SPEC;
         w.sb = &sm->sb[1 + seq % FQSX_SCR];
         lds_store_rel(&w.sb->h_pub, 0u);   // (the slot may hold a chunk of the same number from an earlier epoch)
         TM_BEGIN(t_sp);
@@ -3687,7 +3693,7 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
     w.sc_read = call;
     if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) continue;   // (overwritten while it was read: take the newer one)
     u32 seq = 0;
-    for (u32 i0 = base_pos; i0 < size; i0 += FQSX_SPEC, ++seq) {
+    for (u32 i0 = base_pos, n = 0; i0 < size && (n = chunk_len(size - i0)) != 0; i0 += n, ++seq) {
       if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch || lds_load_acq(&sm->cq_done)) break;
       if (seq % nsc != me) continue;   // another wave's chunk
       spins = 0;
@@ -3700,7 +3706,6 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
       }
       TM_END(w, TM_SCOUT_WAIT, t_w2);
       if (stop) break;
-      const u32 n = size - i0 < FQSX_SPEC ? size - i0 : FQSX_SPEC;
       w.sb = &sm->sb[1 + seq % nsc];
       lds_store_rel(&w.sb->h_pub, 0u);   // (the slot may hold a chunk of the same number from an earlier epoch)
       TM_BEGIN(t_sp);
@@ -4089,11 +4094,12 @@ FQ_DEV void part_dstoff_body(const DevCfg &cfg, u32 kind) {
   if (FQ_LANE == 0) m.dst_off[cfg.T] = run;
 }
 // tile `blk`: stable scatter into the owners' groups
-FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor /*LDS[256]*/, u32 *ld /*LDS[64]*/) {
+FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor /*LDS[256]*/, u32 *ld /*LDS[64]*/, u64 *gm /*LDS[256]*/) {
   const Mail &m = cfg.mail[kind];
   const u32 T = cfg.T, s = blk / m.n_tiles, t = blk % m.n_tiles;
   const u32 n = m.n[s], lo = t * FQSX_TILE, hi = n < lo + FQSX_TILE ? n : lo + FQSX_TILE;
   if (lo >= hi) return;
+  for (u32 d = FQ_LANE; d < 256; d += FQ_WAVE) gm[d] = 0;
   for (u32 d = FQ_LANE; d < T; d += FQ_WAVE) cursor[d] = m.dst_off[d] + m.tile_hist[(u64)blk * T + d];
   FQ_SYNC();
   for (u32 base = lo; base < hi; base += FQ_WAVE) {
@@ -4104,6 +4110,22 @@ FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor 
       x = m.list[(u64)s * m.cap + e];
       d = mail_group(cfg, kind, x);
     }
+#if FQ_WAVE > 1
+    // rank among the round's entries of the same group: the group's lanes as a bit mask in LDS (the groups are < 256)
+    (void)cnt; (void)ld;
+    if (e < hi) lds_or64(&gm[d], 1ull << FQ_LANE);
+    FQ_SYNC();
+    const u64 mine = e < hi ? gm[d] : 0;
+    const u32 rank = popc64(mine & ((1ull << FQ_LANE) - 1ull));
+    const u32 later = (mine >> FQ_LANE) >> 1 ? 1u : 0u;
+    u32 cur = e < hi ? cursor[d] : 0;
+    FQ_SYNC();
+    if (e < hi) {
+      m.sorted[cur + rank] = x;
+      if (later == 0) { cursor[d] = cur + rank + 1; gm[d] = 0; }  // last entry of this owner in the round: advances the cursor, clears the mask
+    }
+    FQ_SYNC();
+#else
     ld[FQ_LANE] = d;
     FQ_SYNC();
     u32 rank = 0, later = 0;
@@ -4119,6 +4141,7 @@ FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor 
       if (later == 0) cursor[d] = cur + rank + 1;  // last entry of this owner in the round advances the cursor
     }
     FQ_SYNC();
+#endif
   }
 }
 
