@@ -2965,6 +2965,9 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         if (flag == 0) TM_COUNT(w, CN_EARLY);
         if (!resolved) {
           TM_COUNT(w, CN_GENERIC);
+#ifdef FQSX_TIMING
+          if (w.sb->sp_scur[2][j] != cfg->gb.k) w.tm[TX_G_EARLY] += 1; else if (flag == 3) w.tm[TX_G_F3] += 1;
+#endif
           // complete reference logic on the exact k-mers of this position
           flush_pushes(w, q_done, j);
           q_done = j;
@@ -3898,7 +3901,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   TM_TRACE_VAL(cfg, tid, launch, 14, w.tm[CN_GENERIC]); TM_TRACE_VAL(cfg, tid, launch, 15, w.tm[TM_LQ]);
 #ifdef FQSX_TIMING
   {
-    const u32 xs[16] = {TM_SLOW, TM_SPRE, TM_ROUGH, TM_FINDC, TM_POST, TM_KEYS, TM_READ_HEAD, TM_CQWAIT, TX_QMM, TX_QRUN, TX_PROLOG, TX_CHUNKQ, TX_FLUSH, TM_TOTAL, CN_CHUNK, CN_EXT};
+    const u32 xs[16] = {TM_SLOW, TM_SPRE, TM_ROUGH, TM_FINDC, TM_POST, TM_KEYS, TM_READ_HEAD, TM_CQWAIT, TX_QMM, TX_QRUN, TX_PROLOG, TX_CHUNKQ, TX_FLUSH, TM_TOTAL, TX_G_EARLY, TX_G_F3};
     for (u32 x = 0; x < 16; ++x) TM_TRACE_VAL(cfg, tid, launch, 16 + x, w.tm[xs[x]]);
   }
 #endif

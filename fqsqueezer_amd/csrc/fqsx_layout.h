@@ -135,7 +135,8 @@ enum { TM_TOTAL = 0, TM_SPEC, TM_FAST, TM_SLOW, TM_POST, TM_READ_HEAD, TM_LQ, TM
        TM_SP_ROLL /* stage P: k-mer roll */, TM_SP_PROBE /* ... global b-mer probe */,
        TM_N, TM_SP_HIT = 46 /* ... keys, rank, repair decision of a hit */, TM_SP_MISS = 47 /* ... miss cascade */,
        TX_QMM = 48 /* resolver: quiet_miss_mask */, TX_QRUN /* ... quiet stretches */, TX_PROLOG /* ... launch start to first read */,
-       TX_CHUNKQ /* ... chunk into the coding queue (after the keys) */, TX_FLUSH /* ... end-of-chunk flush_pushes */ };
+       TX_CHUNKQ /* ... chunk into the coding queue (after the keys) */, TX_FLUSH /* ... end-of-chunk flush_pushes */,
+       TX_G_EARLY /* generic positions: b-mer still partial */, TX_G_F3 /* ... global b-mer miss without a stage-P cascade */ };
 #ifdef FQSX_TIMING
 #define FQSX_TM_SLOTS 56   /* [0..47] are summed into WState.stat[16..63]; [48..55] only go to the per-launch trace */
 #else

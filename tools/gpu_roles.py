@@ -59,8 +59,8 @@ def report(tr, tag):
     xv = tr[:, :, 16:30].astype(np.float64) * 0.01
     res["resolver_sections_us_mean_worker"] = {xn[k]: round(float(xv[:, :, k].mean()), 1) for k in range(14)}
     res["resolver_sections_us_slowest_worker"] = {xn[k]: round(float(np.mean([xv[i, last_worker[i], k] for i in range(n)])), 1) for k in range(14)}
-    res["chunks_mean_slowest"] = [round(float(tr[:, :, 30].mean()), 2), round(float(np.mean([tr[i, last_worker[i], 30] for i in range(n)])), 2)]
-    res["ext_positions_mean_slowest"] = [round(float(tr[:, :, 31].mean()), 2), round(float(np.mean([tr[i, last_worker[i], 31] for i in range(n)])), 2)]
+    res["generic_early_mean_slowest"] = [round(float(tr[:, :, 30].mean()), 2), round(float(np.mean([tr[i, last_worker[i], 30] for i in range(n)])), 2)]
+    res["generic_flag3_nocascade_mean_slowest"] = [round(float(tr[:, :, 31].mean()), 2), round(float(np.mean([tr[i, last_worker[i], 31] for i in range(n)])), 2)]
     rend = ends[:, :, 1]   # resolving wave's end per worker
     res["corr_resolve_end_with"] = {cn[k]: round(float(np.corrcoef(rend.reshape(-1), vals[:, :, k].reshape(-1))[0, 1]), 3) for k in range(8)}
     print(json.dumps(res))
