@@ -2930,7 +2930,20 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           // (a position of the quiet-miss mask has no such entry in either group: quiet_miss_mask)
           bool conflict = ((Qm >> j) & 1) ? false : pend_conflict(w, 0, cfg->gb, bmj, q_done, j);
           if (!conflict && !((Qm >> j) & 1) && !(xf & (SX_LB | SX_S))) conflict = pend_conflict(w, 1, cfg->gs, smj, q_done, j);
-          if (!conflict) {
+          if (conflict) {
+            // An entry still on its way into the local tables lies in the position's sibling group -- typically the
+            // second of two overlapping reads of this worker.  The look-up that entry can change comes first in the
+            // cascade (dna.cpp:478-483): bring the local b-mer table up to date, ask it again; a hit settles the level
+            // without the rest of the per-position path (on a miss that path takes over as before).
+            flush_pushes(w, q_done, j);
+            q_done = j;
+            lq_sync_for(w, MAIL_B, cfg->gb, bmj);
+            if (kt_find(w, cfg->l_b, false, cfg->gb, bmj, RNG_LB, CINC_B, counts)) {
+              level = LV_BMER;
+              resolved = true;
+            } else
+              c4_zero(counts);
+          } else {
             resolved = true;
             TM_COUNT(w, CN_EXT);
             if (xf & SX_LB) {
