@@ -8,7 +8,7 @@ path is fed* (block boundaries, read order) or *where its output goes*
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Iterable, List, Sequence, Tuple
+from typing import Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -58,6 +58,7 @@ class Records:
     seq: "np.ndarray | List[bytes]"
     qual: "np.ndarray | List[bytes]"
     plus: bytes = b"+"
+    plus_len: Optional[np.ndarray] = None   # per-record length of the separator line when the file has `+id` lines (read_fastq)
 
     def __len__(self) -> int:
         return len(self.ids)
@@ -78,7 +79,8 @@ class Records:
             sl = np.full(n, self.seq.shape[1], dtype=np.int64)
         else:
             sl = np.fromiter((len(x) for x in self.seq), dtype=np.int64, count=n)
-        return idl + 1 + sl + 1 + len(self.plus) + 1 + sl + 1
+        pl = len(self.plus) if self.plus_len is None else np.asarray(self.plus_len, dtype=np.int64)
+        return idl + 1 + sl + 1 + pl + 1 + sl + 1
 
 
 def read_fastq(path: str) -> Records:
@@ -90,12 +92,17 @@ def read_fastq(path: str) -> Records:
     ids = lines[0:4 * n:4]
     seq = lines[1:4 * n:4]
     qual = lines[3:4 * n:4]
+    # The separator line's text is not stored in a .fqs, but its length is part of read_size() (defs.h:79-81), which
+    # places the block boundaries (reads_block.h:119-139).  Lines are split at 0x0A only, as the reference does
+    # (io.h:447-478): in a CRLF file the 0x0D stays part of every field, the DNA included.
+    pl = np.fromiter((len(x) for x in lines[2:4 * n:4]), dtype=np.int64, count=n)
+    plus_len = None if n == 0 or bool((pl == 1).all()) else pl
     L = len(seq[0]) if n else 0
     if n and all(len(s) == L for s in seq):
         seq_a = np.frombuffer(b"".join(seq), dtype=np.uint8).reshape(n, L)
         qual_a = np.frombuffer(b"".join(qual), dtype=np.uint8).reshape(n, L)
-        return Records(ids, seq_a, qual_a)
-    return Records(ids, seq, qual)
+        return Records(ids, seq_a, qual_a, plus_len=plus_len)
+    return Records(ids, seq, qual, plus_len=plus_len)
 
 
 _NT = bytes(i if i in b"ACG" else ord("T") for i in range(256))      # io.h:563-571 (N and everything else -> T)

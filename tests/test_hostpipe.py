@@ -62,3 +62,16 @@ def test_sorted_order_is_sorted():
     nt = bytes(i if i in b"ACG" else ord("T") for i in range(256))
     keys = [(rec.seq[i].translate(nt), len(rec.seq[i]), rec.seq[i]) for i in order]
     assert keys == sorted(keys)
+
+
+def test_record_sizes_count_the_separator_line(tmp_path):
+    """read_size() (defs.h:79-81) spans all four lines, so a `+id` separator line moves the block boundaries
+    (reads_block.h:119-139) although its text is not stored: read_fastq keeps the per-record lengths."""
+    p = tmp_path / "a.fq"
+    recs = [b"@r1\nACGT\n+r1\nIIII\n", b"@r2 x\nACGTA\n+\nIIIII\n", b"@r3\nAC\n+r3 again\nII\n"]
+    p.write_bytes(b"".join(recs))
+    rec = hp.read_fastq(str(p))
+    assert rec.record_sizes().tolist() == [len(r) for r in recs]
+    q = tmp_path / "b.fq"
+    q.write_bytes(b"@r1\nACGT\n+\nIIII\n")
+    assert hp.read_fastq(str(q)).plus_len is None
