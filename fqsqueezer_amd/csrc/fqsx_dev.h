@@ -102,6 +102,7 @@ struct WgShared {
   struct ScoutReq {
     u32 read, i0, cor_pos, n_run;
     u32 flags, size;                // SCQ_*; request mode: length of the sequence being coded
+    u32 slot_base, pad_;            // chunk c of the new epoch lives in ring slot (slot_base + c) % nsc
     u64 p;                          // request mode: its bases in HBM (reads longer than the LDS staging buffer)
     u64 kdir[6], krc[6];
     u32 kcur[6];
@@ -218,6 +219,7 @@ struct Wk {
   u32 rq_size;
   bool rq_rev;
   u32 sc_taken;                         // scout chunks of the current epoch released so far
+  u32 sc_base;                          // ring slot of the epoch's first chunk
   HeadRec *rec;                         // read-head wave: where the head's output goes (null: code / push directly)
   bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
   u32 cq_tail, cq_head;                 // this wave's copy of its own queue index
@@ -2738,12 +2740,19 @@ FQ_DEV void scout_release(Wk &w) {
 }
 // The scout waves start again: from the exact state before position i0 of read `read` (a k-mer correction), or, with
 // i0 == pmer, from the head of that read (the resolving wave has finished the read before on its own)
-FQ_DEV void scout_restart(Wk &w, u32 read, u32 i0, const u64 s_let[4], u32 flags = 0) {
+// The chunks of the new epoch take the ring slots in turn starting after the slot of the chunk the resolving wave holds
+// (w.sb), so with `hold` the request can go out while that chunk is still being read: the slot counts as an unreleased
+// chunk (sc_taken = -1) until scout_unhold.
+FQ_DEV void scout_restart(Wk &w, u32 read, u32 i0, const u64 s_let[4], u32 flags = 0, bool hold = false) {
   WgShared *sm = w.sm;
   if (lds_load_acq(&sm->sc_dead)) return;
+  const bool in_ring = w.sb != &sm->sb[0];
+  const u32 base = in_ring ? ((u32)(w.sb - &sm->sb[1]) + 1u) % w.nsc : 0u;
+  hold = hold && in_ring;
   FQ_SYNC();
   if (FQ_LANE == 0) {
     WgShared::ScoutReq &q = sm->sc_req;
+    q.slot_base = base;
     q.read = read; q.i0 = i0; q.cor_pos = w.cor_pos; q.n_run = w.N_run;
     q.flags = flags | (w.rq_rev ? (u32)SCQ_REVERSED : 0u); q.size = w.rq_size; q.p = (u64)w.rq_p;
     const Kmer *k[6] = {&w.pm, &w.sm_, &w.bm, &w.pm_u, &w.sm_u, &w.bm_u};
@@ -2751,14 +2760,19 @@ FQ_DEV void scout_restart(Wk &w, u32 read, u32 i0, const u64 s_let[4], u32 flags
     for (u32 x = 0; x < 4; ++x) q.s_let[x] = s_let[x];
   }
   w.sc_taken = 0;
+  w.sc_base = base;
   FQ_SYNC();
-  lds_store_rel(&sm->sc_taken, 0u);
+  lds_store_rel(&sm->sc_taken, hold ? 0xffffffffu : 0u);
   w.sc_epoch += 1;
   lds_store_rel(&sm->sc_req_seq, w.sc_epoch);
 }
+FQ_DEV void scout_unhold(Wk &w) {   // the chunk held across an early restart is done with
+  FQ_SYNC();
+  lds_store_rel(&w.sm->sc_taken, w.sc_taken);
+}
 FQ_DEV bool scout_take(Wk &w, u32 i, u32 n) {
   WgShared *sm = w.sm;
-  SpecBuf *b = &sm->sb[1 + w.sc_taken % w.nsc];
+  SpecBuf *b = &sm->sb[1 + (w.sc_base + w.sc_taken) % w.nsc];
   u32 spins = 0;
   // the chunk with this number of this epoch (a slot may still hold the one of an earlier epoch with the same number)
   while (lds_load_acq(&b->h_pub) != w.sc_taken + 1 || b->h_epoch != w.sc_epoch) {
@@ -3097,6 +3111,14 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       m = j + 1;
     }
     if (dirty) TM_COUNT(w, CN_DIRTY);
+    // The scout's chunks of this read were rolled from k-mers that have just been corrected: it starts again from here.
+    // The state it needs is final (every path that sets `dirty` leaves w's k-mers after position m - 1), so the request
+    // goes out before the rest of this chunk's work -- flush, keys, queue -- which still reads the chunk (hold).
+    bool reposted = false;
+    if (dirty && w.scout && !w.sc_abandoned && i + m < size) {
+      scout_restart(w, w.sc_read, i + m, w.s_let, 0, pre);
+      reposted = true;
+    }
     { TM_BEGIN(t_fl); flush_pushes(w, q_done, m); TM_END(w, TX_FLUSH, t_fl); }
     code_chunk(w, p, size, i, m, reversed, hist_start, first);
     lq_publish(w);   // (after the queue hand-off, whose release has already drained the list stores)
@@ -3106,9 +3128,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       replace_last_all(w, sym == 4 ? 0 : sym);
       w.N_run = sym == 4 ? w.N_run + 1 : 0;
     }
-    // the scout's chunks of this read were rolled from k-mers that have just been corrected: it starts again from here
-    // (posted before the release below: a scout woken by that must see the request)
-    if (dirty && w.scout && !w.sc_abandoned && i + m < size) scout_restart(w, w.sc_read, i + m, w.s_let);   // (a new epoch: nothing to release)
+    if (reposted) { if (pre) scout_unhold(w); }   // (a new epoch: nothing else to release)
     else if (pre) scout_release(w);
     i += m;
   }
@@ -3524,6 +3544,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
   const u32 n_seg = (u32)(stop > cur ? stop - cur : 0);
   u32 idx = 0;          // read the wave is at (index within the launch)
   u32 seq = 0;          // number, within the epoch, of the next chunk of the enumeration
+  u32 sbase = 0;        // ring slot of the epoch's chunk 0 (a restart names it; chunk c: slot and wave (sbase + c) % nsc)
   bool restart = false; // a request of the resolving wave is to be taken up (sc_req)
   while (!quit) {
     u32 spins = 0;
@@ -3556,6 +3577,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       const WgShared::ScoutReq &q = sm->sc_req;
       idx = uniform32(q.read);
       base_pos = uniform32(q.i0);
+      sbase = uniform32(q.slot_base);
       seq = 0;
       from_head = (uniform32(q.flags) & SCQ_FROM_HEAD) != 0;
       if (!from_head) {
@@ -3611,7 +3633,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       w.sc_read = idx;
       for (u32 i0 = base_pos, n = 0; i0 < size && !quit && !restart && (n = chunk_len(size - i0)) != 0; i0 += n, ++seq) {
         if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
-        if (seq % FQSX_NSC != me) continue;   // another wave's chunk
+        if ((sbase + seq) % FQSX_NSC != me) continue;   // another wave's chunk
         spins = 0;
         TM_BEGIN(t_w2);
         while ((i32)(seq - lds_load_acq(&sm->sc_taken)) >= (i32)FQSX_SCR) {   // the chunk's ring slot still holds an unreleased one
@@ -3621,7 +3643,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         }
         TM_END(w, TM_SCOUT_WAIT, t_w2);
         if (quit || restart) break;
-        w.sb = &sm->sb[1 + seq % FQSX_SCR];
+        w.sb = &sm->sb[1 + me];
         lds_store_rel(&w.sb->h_pub, 0u);   // (the slot may hold a chunk of the same number from an earlier epoch)
         TM_BEGIN(t_sp);
         const bool whole = speculate(w, p, size, i0, n, false, i0 - base_pos);
@@ -3698,7 +3720,7 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
     if (quit) break;
     w.sc_epoch = lds_load_acq(&sm->sc_req_seq);
     const WgShared::ScoutReq &q = sm->sc_req;
-    const u32 call = uniform32(q.read), base_pos = uniform32(q.i0), size = uniform32(q.size);
+    const u32 call = uniform32(q.read), base_pos = uniform32(q.i0), size = uniform32(q.size), sbase = uniform32(q.slot_base);
     const bool reversed = (uniform32(q.flags) & SCQ_REVERSED) != 0;
     const u8 *p = (const u8 *)uniform64(q.p);
     Kmer *k[6] = {&w.pm, &w.sm_, &w.bm, &w.pm_u, &w.sm_u, &w.bm_u};
@@ -3711,7 +3733,7 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
     u32 seq = 0;
     for (u32 i0 = base_pos, n = 0; i0 < size && (n = chunk_len(size - i0)) != 0; i0 += n, ++seq) {
       if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch || lds_load_acq(&sm->cq_done)) break;
-      if (seq % nsc != me) continue;   // another wave's chunk
+      if ((sbase + seq) % nsc != me) continue;   // another wave's chunk
       spins = 0;
       bool stop = false;
       TM_BEGIN(t_w2);
@@ -3722,7 +3744,7 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
       }
       TM_END(w, TM_SCOUT_WAIT, t_w2);
       if (stop) break;
-      w.sb = &sm->sb[1 + seq % nsc];
+      w.sb = &sm->sb[1 + me];
       lds_store_rel(&w.sb->h_pub, 0u);   // (the slot may hold a chunk of the same number from an earlier epoch)
       TM_BEGIN(t_sp);
       const bool whole = speculate(w, p, size, i0, n, reversed, i0 - base_pos);
@@ -3781,6 +3803,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.sc_read = 0;
   w.sc_epoch = 0;
   w.sc_taken = 0;
+  w.sc_base = 0;
   w.cq_head = w.cq_tail = 0;
   w.c_r_sym = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;
