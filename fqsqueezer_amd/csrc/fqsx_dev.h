@@ -245,10 +245,19 @@ struct Wk {
 #define TM_BEGIN(v) u64 v = fq_clock()
 #define TM_END(w, slot, v) (w).tm[slot] += fq_clock() - (v)
 #define TM_COUNT(w, slot) (w).tm[slot] += 1
+#ifdef FQSX_TIMING_MODELS   /* slots 38, 39, 46, 47 time the tail of code_run instead of the sections of stage P */
+#define TM_END_SP(w, slot, v) ((void)0)
+#define TM_END_MD(w, slot, v) TM_END(w, slot, v)
+#else
+#define TM_END_SP(w, slot, v) TM_END(w, slot, v)
+#define TM_END_MD(w, slot, v) ((void)0)
+#endif
 #else
 #define TM_BEGIN(v) ((void)0)
 #define TM_END(w, slot, v) ((void)0)
 #define TM_COUNT(w, slot) ((void)0)
+#define TM_END_SP(w, slot, v) ((void)0)
+#define TM_END_MD(w, slot, v) ((void)0)
 #endif
 
 #define CINC_B (Cinc{7u, 2u, 63u})            /* dna.cpp:162,164 */
@@ -2091,7 +2100,7 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
     c4_zero(c);
     const bool b_full = bm.cur == cfg->gb.k;
     if (w.sc_poll && lds_load_acq(&w.sm->sc_req_seq) != w.sc_epoch) { gave_up = true; break; }   // (the same answer in every lane that asks)
-    TM_END(w, TM_SP_ROLL, t_roll);
+    TM_END_SP(w, TM_SP_ROLL, t_roll);
     TM_BEGIN(t_probe);
     if (b_full) {
       bool nd = km_norm_dir(bm, cfg->gb);
@@ -2111,7 +2120,7 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
       }
       tab_rest(cfg->g_b, fb, key, nd, c, ns);
       ++np;
-      TM_END(w, TM_SP_PROBE, t_probe);
+      TM_END_SP(w, TM_SP_PROBE, t_probe);
       TM_BEGIN(t_hit);
       if (c4_any(c)) {
         u32 sat = (c.c[0] == 63) + (c.c[1] == 63) + (c.c[2] == 63) + (c.c[3] == 63);
@@ -2127,7 +2136,7 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           // repair_kmers_existing decision (dna.cpp:333-360)
           rep = repair_decide(w, c, sym);
         }
-        TM_END(w, TM_SP_HIT, t_hit);
+        TM_END_SP(w, TM_SP_HIT, t_hit);
       } else {
         // global b-mer miss; the local probes see the tables as of the last flush
         flag = 3;
@@ -2159,7 +2168,7 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           }
         }
         w.sb->sx_flag[j] = (u8)xf;
-        TM_END(w, TM_SP_MISS, t_hit);
+        TM_END_SP(w, TM_SP_MISS, t_hit);
       }
     }
     w.sb->sp_flag[j] = (u8)flag;
@@ -2576,10 +2585,14 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len) {
   }
   FQ_SYNC_MEM();
   w.st[ST_CTX] += wave_sum32(vis_sum);
+  TM_END_MD(w, TM_SP_ROLL, t_rc);
+  TM_BEGIN(t_rq);
   // ---- the range coder, in position order
 #if FQ_WAVE > 1
   if (w.rcq) {   // the run's steps go to the range-coder wave, one lane per position
-    if (rq_wait_space(w, L)) {
+    const bool space_ = rq_wait_space(w, L);
+    TM_END_MD(w, TM_SP_PROBE, t_rq);
+    if (space_) {
       const u32 t = FQ_LANE;
       if (t < L) {
         const u32 e = (w.rq_tail + t) & (FQSX_RQ - 1);
@@ -2598,16 +2611,34 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len) {
 #else
   for (u32 t = 0; t < L; ++t) rc_encode(w, sm->fr_f[t], sm->fr_c[t], sm->fr_t[t]);
 #endif
+  TM_BEGIN(t_rs);
   // r_sym history after the run (a letter position shifts in a zero)
   {
+#if FQ_WAVE > 1
+    // closed form of the loop below: the history is the run's Z bits since the last reset (or since the old history),
+    // newest in bit 0, cut to 8 bits
+    const u64 within_l = L >= 64 ? ~0ull : (1ull << L) - 1ull;
+    const u64 rs = RS & within_l;
+    const u32 from = rs ? 63u - (u32)__builtin_clzll(rs) : 0u;        // position of the last reset (the run starts there)
+    const u32 n = L - from;                                           // positions shifted in since
+    const u64 zrev = (((u64)__builtin_bitreverse32((u32)Z) << 32) | __builtin_bitreverse32((u32)(Z >> 32))) >> (64 - L);   // position L-1 in bit 0
+    const u64 znew = n >= 64 ? zrev : zrev & ((1ull << n) - 1ull);
+    const u64 hold = rs ? 0ull : (n >= 8 ? 0ull : ctx_r_sym << n);
+    w.c_r_sym = (hold | znew) & 0xff;
+#else
     u64 h = ctx_r_sym;
     for (u32 t = 0; t < L; ++t) {
       if ((RS >> t) & 1ull) h = 0;
       h = ((h << 1) + ((Z >> t) & 1ull)) & 0xff;
     }
     w.c_r_sym = h;
+#endif
   }
 #undef CQE
+  TM_END_MD(w, TM_SP_HIT, t_rs);
+#ifdef FQSX_TIMING_MODELS
+  TM_COUNT(w, TM_SP_MISS);   // (runs)
+#endif
   TM_END(w, TM_CR_RC, t_rc);
   return L;
 }

@@ -68,4 +68,6 @@ if ib[5]:
                                      "draws + stores s": round(ib[2] * 1e-8, 3), "store wait s": round(ib[3] * 1e-8, 3),
                                      "us per batch": round(sum(ib[:4]) * 1e-2 / ib[5], 2)})
 sp = [st["timers"][i] * 1e-8 for i in (38, 39, 46, 47)]
+if os.environ.get("FQSX_TIMING_MODELS"):
+    print("code_run tail (models wave; build_timing.py models):", {"commit stores + wait s": round(sp[0], 2), "range-coder queue wait s": round(sp[1], 2), "r_sym loop s": round(sp[2], 2), "runs": st["timers"][47], "symbols per run": round(st["coded"] / max(st["timers"][47], 1), 1)})
 print("stage P sections (wave clock at each lane's branch; summed over scouts) s:", {"roll": round(sp[0], 2), "global b probe": round(sp[1], 2), "hit: keys/rank/repair": round(sp[2], 2), "miss cascade": round(sp[3], 2)})
