@@ -84,7 +84,7 @@ struct WgShared {
     SpecBuf sb[1 + FQSX_SCR];  // [0] filled by the resolving wave itself, [1..] ring filled by the scout waves
     struct {
       SpecBuf sb_used_[FQSX_SCR];   // (= sb[0 .. 2])
-      u8 r2c[FQSX_RD_LDS];     // paired-end: codes of the second mate
+      alignas(8) u8 r2c[FQSX_RD_LDS];     // paired-end: codes of the second mate
       u64 pe_cand[512];        // paired-end: candidate partner b-mers (value | count << 2k)
       u64 pe_top[64];
       u64 pe_bk[3][64];        // paired-end insert batch (key, value, weight)

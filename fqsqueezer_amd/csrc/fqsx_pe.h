@@ -29,6 +29,39 @@ FQ_DEV u64 pe_find_minimizer(const DevCfg *cfg, const u8 *codes, int off, int si
   }
   return best;
 }
+// The same for a read staged in LDS (4-byte aligned, encoder): one window position per lane
+FQ_DEV u64 pe_find_minimizer_w(const DevCfg *cfg, const u8 *codes, int off, int size) {
+  const u32 k = cfg->bmer;
+  const u64 vm = pe_value_mask(cfg);
+#if FQ_WAVE > 1
+  if (k <= 28) {
+    // one window position per lane: the b-mer ending there comes out of the 28 bases before it, read as eight aligned
+    // words squeezed to 2 bits per base (as in speculate); the minimum over the lanes is the minimizer
+    u64 best = vm;
+    for (int base = (int)k - 1; base < size; base += (int)FQ_WAVE) {
+      const int i = base + (int)FQ_LANE;
+      if (i < size) {
+        const u32 e1 = (u32)(off + i + 1);                       // position after the b-mer's last base
+        const u32 start = e1 >= 28 ? e1 - 28 : 0, a = start & ~3u, sh = a + 32 - e1;
+        const u32 *wp = (const u32 *)(codes + a);
+        u64 P = 0;
+        u32 N32 = 0;
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+          const u32 x = wp[q];
+          P = (P << 8) | (((x & 0x03030303u) * 0x40100401u) >> 24);
+          N32 = (N32 << 4) | (((((x >> 2) & 0x01010101u) * 0x08040201u) >> 24) & 15u);
+        }
+        const u64 v = (P >> (2 * sh)) & vm;
+        const bool clean = ((N32 >> sh) & ((1u << k) - 1u)) == 0;   // no N among the k bases (the serial scan restarts at an N)
+        if (clean && v < best && pe_valid_minimizer(cfg, v)) best = v;
+      }
+    }
+    return wave_min64(best);
+  }
+#endif
+  return pe_find_minimizer(cfg, codes, off, size);
+}
 // find_maximizer (walks the window backwards), dna.cpp:1026-1050
 FQ_DEV u64 pe_find_maximizer(const DevCfg *cfg, const u8 *codes, int off, int size) {
   const u32 k = cfg->bmer;
@@ -58,6 +91,29 @@ FQ_DEV void ptab_find(Wk &w, const PTab &t, u32 sub, u64 key, u32 &n) {
   const u64 h = murmur64(key);
   const u64 *tk = t.key + (u64)sub * t.stride, *tv = t.val + (u64)sub * t.stride;
   u64 p = h & t.cap_mask;
+#if FQ_WAVE > 1
+  // 64 slots of the cluster per round trip: the matches before the first empty slot are appended in slot order
+  for (u64 base = 0; base <= t.cap_mask; base += FQ_WAVE) {
+    const u64 it = base + FQ_LANE;
+    const bool in = it <= t.cap_mask;
+    const u64 q = (p + it) & t.cap_mask;
+    const u64 k = in ? tk[q] : 0, v = in ? tv[q] : 0;
+    const u64 em = wave_ballot(in && k == 0 && v == 0);
+    const u32 lim = em ? ctz64(em) : FQ_WAVE;
+    const bool hit = in && FQ_LANE < lim && k == key;
+    const u64 hm = wave_ballot(hit);
+    const u32 cnt = popc64(hm);
+    if (cnt) {
+      if (n + cnt > 512) pe_reduce48(w, n);   // (exact whenever it happens: see above)
+      FQ_SYNC();
+      if (hit) w.sm->pe_cand[n + popc64(hm & ((1ull << FQ_LANE) - 1ull))] = v;
+      FQ_SYNC();
+      n += cnt;
+    }
+    if (em) break;
+  }
+  return;
+#endif
   for (u64 it = 0; it <= t.cap_mask; ++it) {
     u64 k = tk[p], v = tv[p];
     if (k == 0 && v == 0) break;
@@ -79,6 +135,34 @@ FQ_DEV void ptab_insert_uniform(Wk &w, const PTab &t, u32 sub, u64 key, u64 valu
   if (key == vm || value == vm) return;
   u64 *tk = t.key + (u64)sub * t.stride, *tv = t.val + (u64)sub * t.stride;
   u64 p = murmur64(key) & t.cap_mask;
+#if FQ_WAVE > 1
+  // 64 slots per round trip: the first slot that is empty or holds (key, value) is the one the serial walk stops at
+  for (u64 base = 0; base <= t.cap_mask; base += FQ_WAVE) {
+    const u64 it = base + FQ_LANE;
+    const bool in = it <= t.cap_mask;
+    const u64 q = (p + it) & t.cap_mask;
+    const u64 k = in ? tk[q] : 0, v = in ? tv[q] : 0;
+    const bool empty = in && k == 0 && v == 0, match = in && k == key && (v & vm) == value;
+    const u64 stop_m = wave_ballot(empty || match);
+    if (!stop_m) continue;
+    const u32 at = ctz64(stop_m);
+    const bool is_empty = (wave_ballot(empty) >> at) & 1ull;
+    if (is_empty) {
+      const u32 f = t.filled[sub];
+      if ((u64)f * 10 >= (t.cap_mask + 1) * 9) { w.err = FQSX_ERR_PE_FULL; return; }
+      if (count > maxc) count = maxc;
+      if (FQ_LANE == at) { tk[q] = key; tv[q] = value + (count << cs); }
+      if (FQ_LANE == 0) t.filled[sub] = f + 1;
+    } else if (FQ_LANE == at) {
+      const u64 cur = v >> cs;
+      tv[q] = cur + count < maxc ? v + (count << cs) : v + ((maxc - cur) << cs);
+    }
+    FQ_SYNC_MEM();
+    return;
+  }
+  w.err = FQSX_ERR_PE_FULL;
+  return;
+#endif
   for (u64 it = 0; it <= t.cap_mask; ++it) {
     u64 k = tk[p], v = tv[p];
     if (k == 0 && v == 0) {
@@ -213,14 +297,14 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
       // minimizers of the first mate: 4 windows for the look-up (dna.cpp:1761-1769), 3 + 1 for the inserts (:1055-1083)
       {
         int mss = (int)size1 - k + 1, s1 = mss / 4, s2 = 2 * mss / 4, s3 = 3 * mss / 4;
-        m1[0] = pe_find_minimizer(cfg, w.rdp, 0, s1 + k - 1);
-        m1[1] = pe_find_minimizer(cfg, w.rdp, s1, s2 - s1 + k - 1);
-        m1[2] = pe_find_minimizer(cfg, w.rdp, s2, s3 - s2 + k - 1);
-        m1[3] = pe_find_minimizer(cfg, w.rdp, s3, (int)size1 - s3);
+        m1[0] = pe_find_minimizer_w(cfg, w.rdp, 0, s1 + k - 1);
+        m1[1] = pe_find_minimizer_w(cfg, w.rdp, s1, s2 - s1 + k - 1);
+        m1[2] = pe_find_minimizer_w(cfg, w.rdp, s2, s3 - s2 + k - 1);
+        m1[3] = pe_find_minimizer_w(cfg, w.rdp, s3, (int)size1 - s3);
         int a = mss / 3, b = 2 * mss / 3;
-        a1[0] = pe_find_minimizer(cfg, w.rdp, 0, a + k - 1);
-        a1[1] = pe_find_minimizer(cfg, w.rdp, a, b - a + k - 1);
-        a1[2] = pe_find_minimizer(cfg, w.rdp, b, (int)size1 - b);
+        a1[0] = pe_find_minimizer_w(cfg, w.rdp, 0, a + k - 1);
+        a1[1] = pe_find_minimizer_w(cfg, w.rdp, a, b - a + k - 1);
+        a1[2] = pe_find_minimizer_w(cfg, w.rdp, b, (int)size1 - b);
         int mid1 = ((int)size1 + k) / 2;
         x1 = (~pe_find_maximizer(cfg, w.rdp, mid1 - k + 1, (int)size1 - (mid1 - k + 1))) & vm;
       }
@@ -230,11 +314,11 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
       FQ_SYNC();
       {
         int mss = (int)size2 - k + 1, a = mss / 3, b = 2 * mss / 3;
-        a2[0] = pe_find_minimizer(cfg, sm->r2c, 0, a + k - 1);
-        a2[1] = pe_find_minimizer(cfg, sm->r2c, a, b - a + k - 1);
-        a2[2] = pe_find_minimizer(cfg, sm->r2c, b, (int)size2 - b);
+        a2[0] = pe_find_minimizer_w(cfg, sm->r2c, 0, a + k - 1);
+        a2[1] = pe_find_minimizer_w(cfg, sm->r2c, a, b - a + k - 1);
+        a2[2] = pe_find_minimizer_w(cfg, sm->r2c, b, (int)size2 - b);
         int mid2 = ((int)size2 + k) / 2;
-        x2 = (~pe_find_minimizer(cfg, sm->r2c, mid2 - k + 1, (int)size2 - (mid2 - k + 1))) & vm;  // sic: minimizer (dna.cpp:1087)
+        x2 = (~pe_find_minimizer_w(cfg, sm->r2c, mid2 - k + 1, (int)size2 - (mid2 - k + 1))) & vm;  // sic: minimizer (dna.cpp:1087)
       }
       // find_minim_cand: global then local table, 4 minimizers each (dna.cpp:1771-1779)
       u32 nc = 0;

@@ -106,6 +106,14 @@ FQ_DEV u64 uniform64(u64 v) {
 // cache touch: the value of a load issued early for its side effect on L2 / the TLB is "used" here
 FQ_DEV u64 touch_load(const u64 *p) { return *(const volatile u64 *)p; }
 FQ_DEV void keep_live(u64 v) { asm volatile("" ::"v"((u32)v), "v"((u32)(v >> 32))); }
+FQ_DEV u64 wave_min64(u64 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 y = __shfl_xor(v, o, 64);
+    v = y < v ? y : v;
+  }
+  return v;
+}
 FQ_DEV u32 popc64(u64 v) { return (u32)__popcll(v); }
 FQ_DEV u32 ctz64(u64 v) { return (u32)__ffsll((long long)v) - 1u; }
 FQ_DEV u64 fq_clock() { return (u64)wall_clock64(); }  // 100 MHz constant clock (s_memrealtime)
