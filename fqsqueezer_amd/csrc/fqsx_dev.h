@@ -220,6 +220,7 @@ struct Wk {
   bool rq_rev;
   u32 sc_taken;                         // scout chunks of the current epoch released so far
   u32 sc_base;                          // ring slot of the epoch's first chunk
+  bool rq_early;                        // request mode: the coming suffix() call's request is posted already
   HeadRec *rec;                         // read-head wave: where the head's output goes (null: code / push directly)
   bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
   u32 cq_tail, cq_head;                 // this wave's copy of its own queue index
@@ -245,12 +246,19 @@ struct Wk {
 #define TM_BEGIN(v) u64 v = fq_clock()
 #define TM_END(w, slot, v) (w).tm[slot] += fq_clock() - (v)
 #define TM_COUNT(w, slot) (w).tm[slot] += 1
-#ifdef FQSX_TIMING_MODELS   /* slots 38, 39, 46, 47 time the tail of code_run instead of the sections of stage P */
+#if defined(FQSX_TIMING_PE)   /* ... or the paired-end steps of the resolving wave (compress_pair) */
+#define TM_END_SP(w, slot, v) ((void)0)
+#define TM_END_MD(w, slot, v) ((void)0)
+#define TM_END_PE(w, slot, v) TM_END(w, slot, v)
+#elif defined(FQSX_TIMING_MODELS)   /* slots 38, 39, 46, 47 time the tail of code_run instead of the sections of stage P */
 #define TM_END_SP(w, slot, v) ((void)0)
 #define TM_END_MD(w, slot, v) TM_END(w, slot, v)
 #else
 #define TM_END_SP(w, slot, v) TM_END(w, slot, v)
 #define TM_END_MD(w, slot, v) ((void)0)
+#endif
+#ifndef TM_END_PE
+#define TM_END_PE(w, slot, v) ((void)0)
 #endif
 #else
 #define TM_BEGIN(v) ((void)0)
@@ -258,6 +266,7 @@ struct Wk {
 #define TM_COUNT(w, slot) ((void)0)
 #define TM_END_SP(w, slot, v) ((void)0)
 #define TM_END_MD(w, slot, v) ((void)0)
+#define TM_END_PE(w, slot, v) ((void)0)
 #endif
 
 #define CINC_B (Cinc{7u, 2u, 63u})            /* dna.cpp:162,164 */
@@ -1939,6 +1948,7 @@ FQ_DEV void prefix_direct(Wk &w, const u8 *p, u32 size) {  // compress_prefix_di
   }
 }
 
+FQ_DEV void scout_restart(Wk &w, u32 read, u32 i0, const u64 s_let[4], u32 flags, bool hold);
 FQ_DEV void prefix_sorted(Wk &w, const u8 *p, u32 size) {  // compress_prefix_sorted, dna.cpp:549-661
   const DevCfg *cfg = w.cfg;
   WState *ws = w.ws;
@@ -1950,6 +1960,16 @@ FQ_DEV void prefix_sorted(Wk &w, const u8 *p, u32 size) {  // compress_prefix_so
     w.ctx_letters = (w.ctx_letters << 4) + sym;
     if (sym == 4) { sym = 3; was_N = true; w.N_run++; } else w.N_run = 0;
     insert_all(w, sym);
+  }
+  // Request mode (no read-head wave: paired-end kernels): the k-mers after the prefix are final here, so the scout waves
+  // can be sent off to the suffix's first chunks now, while this wave still ranks and codes the prefix (suffix() then
+  // finds the request posted).
+  if (w.scout && w.sc_reqmode && cfg->pmer < size) {
+    w.rq_p = p; w.rq_size = size; w.rq_rev = false;
+    w.sc_read += 1;
+    w.sc_abandoned = false;
+    scout_restart(w, w.sc_read, cfg->pmer, w.s_let, 0, false);
+    w.rq_early = true;
   }
   sm_encode(w, sb + SM_OFF_NS, SM_NS_N, 1u << 12, was_N ? 1u : 0u);
   u64 psf = ((ws->ctx_ps_flags << 1) + (was_N ? 1u : 0u)) & 0xffff;
@@ -2774,7 +2794,7 @@ FQ_DEV void scout_release(Wk &w) {
 // The chunks of the new epoch take the ring slots in turn starting after the slot of the chunk the resolving wave holds
 // (w.sb), so with `hold` the request can go out while that chunk is still being read: the slot counts as an unreleased
 // chunk (sc_taken = -1) until scout_unhold.
-FQ_DEV void scout_restart(Wk &w, u32 read, u32 i0, const u64 s_let[4], u32 flags = 0, bool hold = false) {
+FQ_DEV void scout_restart(Wk &w, u32 read, u32 i0, const u64 s_let[4], u32 flags, bool hold) {
   WgShared *sm = w.sm;
   if (lds_load_acq(&sm->sc_dead)) return;
   const bool in_ring = w.sb != &sm->sb[0];
@@ -2824,10 +2844,11 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
   bool first = true;   // the r_sym history starts empty (dna.cpp:676)
   u32 i = start_pos ? start_pos : original_order ? cfg->prefix : cfg->pmer;
   w.rq_p = p; w.rq_size = size; w.rq_rev = reversed;
-  if (w.scout && w.sc_reqmode && i < size) {   // no read-head wave: this call is one request to the scout waves
+  if (w.rq_early) w.rq_early = false;   // (prefix_sorted has posted this call's request already)
+  else if (w.scout && w.sc_reqmode && i < size) {   // no read-head wave: this call is one request to the scout waves
     w.sc_read += 1;
     w.sc_abandoned = false;
-    scout_restart(w, w.sc_read, i, w.s_let);
+    scout_restart(w, w.sc_read, i, w.s_let, 0, false);
   }
   while (i < size && !w.err) {
     const u32 n = chunk_len(size - i);
@@ -3259,7 +3280,7 @@ FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx, bool has_ne
     w.st[ST_BASES] += size;
     // the read was (partly) resolved without the scout waves: they take up again at the head of the next one
     // (posted while this read's record still counts as in use, so that the records they need are in place)
-    if (w.sc_abandoned && has_next) scout_restart(w, idx + 1, w.cfg->pmer, w.s_let, SCQ_FROM_HEAD);
+    if (w.sc_abandoned && has_next) scout_restart(w, idx + 1, w.cfg->pmer, w.s_let, SCQ_FROM_HEAD, false);
   }
   FQ_SYNC();
   lds_store_rel(&sm->hd_taken, idx + 1);   // the record and its staging buffer are free again
@@ -3835,6 +3856,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.sc_epoch = 0;
   w.sc_taken = 0;
   w.sc_base = 0;
+  w.rq_early = false;
   w.cq_head = w.cq_tail = 0;
   w.c_r_sym = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;

@@ -290,11 +290,14 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
     u32 j_size = size2, j_start = 0, j_hist0 = 0, hist[4] = {0, 0, 0, 0};
     if (step == 0) {
       // first mate (CompressDirect / CompressSorted with the duplicate flag, dna.cpp:1795-1799)
+      TM_BEGIN(t_h1);
       const bool same = read_head(w, p1, size1, prev, prev_size, true, hist);
+      TM_END_PE(w, TM_READ_HEAD, t_h1);
       if (!same) { run = true; j_p = p1; j_size = size1; j_orig = w.mode == 2; add_hist = true; }
     } else if (step == 1) {
       // (a duplicate first mate returns early from the coder but sm->rd was staged before that)
       // minimizers of the first mate: 4 windows for the look-up (dna.cpp:1761-1769), 3 + 1 for the inserts (:1055-1083)
+      TM_BEGIN(t_mz);
       {
         int mss = (int)size1 - k + 1, s1 = mss / 4, s2 = 2 * mss / 4, s3 = 3 * mss / 4;
         m1[0] = pe_find_minimizer_w(cfg, w.rdp, 0, s1 + k - 1);
@@ -320,10 +323,14 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
         int mid2 = ((int)size2 + k) / 2;
         x2 = (~pe_find_minimizer_w(cfg, sm->r2c, mid2 - k + 1, (int)size2 - (mid2 - k + 1))) & vm;  // sic: minimizer (dna.cpp:1087)
       }
+      TM_END_PE(w, TM_LQ, t_mz);
+      TM_BEGIN(t_pf);
       // find_minim_cand: global then local table, 4 minimizers each (dna.cpp:1771-1779)
       u32 nc = 0;
       for (u32 i = 0; i < 4; ++i) ptab_find(w, cfg->g_pe, pe_owner(cfg, murmur64(m1[i])), m1[i], nc);
       for (u32 i = 0; i < 4; ++i) ptab_find(w, cfg->l_pe, w.tid, m1[i], nc);
+      TM_END_PE(w, TM_SP_ROLL, t_pf);
+      TM_BEGIN(t_mg);
       int mid = -1;
       if (nc) {
         const u32 ntop = pe_merge_candidates(w, nc);
@@ -355,12 +362,15 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
         mid = best_c == 0xffffffffu || best_c > 14 ? 15 : (int)best_c;
         mpos = best_pos;
       }
+      TM_END_PE(w, TM_SP_PROBE, t_mg);
+      TM_BEGIN(t_rest);
       u16 *sb = small_base(w);
       if (mid >= 0) sm_encode(w, sb + SM_OFF_MID, SM_NIB_N, 1u << 15, (u32)mid);  // ctx_rc_pe_minimizer_id, dna.cpp:1835
       if (mid < 0 || mid == 15) {
         // second mate coded directly: CompressDirect(..., false) -- direct prefix, no duplicate flag (dna.cpp:1836)
         (void)read_head(w, p2, size2, nullptr, 0, false, hist);
         run = true; add_hist = true;
+        TM_END_PE(w, TM_SP_MISS, t_rest);
       } else {
         anchored = true;
         // position of the anchor (dna.cpp:1840-1868); models keyed by id (+0x100..0x500 for the escape bytes)
@@ -377,6 +387,7 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
         FQ_SYNC();
         pe_seed_kmers(w, w.rdp, mpos, mpos + (u32)k);
         run = true; j_start = (u32)k + mpos; j_hist0 = mpos;
+        TM_END_PE(w, TM_SP_HIT, t_rest);
       }
     } else if (anchored) {
       // ... then the left part on the reverse complement, anchored at the same b-mer

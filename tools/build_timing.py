@@ -5,4 +5,4 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
-print(g.build_hip(True, extra_flags=["-DFQSX_TIMING"] + (["-DFQSX_TIMING_MODELS"] if "models" in sys.argv[1:] else []), out=os.path.join(ROOT, "tools", "libfqsx_timing.so")))
+print(g.build_hip(True, extra_flags=["-DFQSX_TIMING"] + (["-DFQSX_TIMING_MODELS"] if "models" in sys.argv[1:] else []) + (["-DFQSX_TIMING_PE"] if "pe" in sys.argv[1:] else []), out=os.path.join(ROOT, "tools", "libfqsx_timing.so")))

@@ -35,3 +35,5 @@ print("counts:", dict(zip(["n_fast", "n_slow", "n_chunk", "n_dirty", "n_rough", 
 print("more s:", {"rrwait": tm[19] * 1e-8, "cqwait": tm[20] * 1e-8, "coder total": tm[23] * 1e-8, "coder idle": tm[24] * 1e-8, "scout wait": tm[25] * 1e-8, "resolve counts": tm[26] * 1e-8,
                   "code_keys": tm[31] * 1e-8, "scouts stage P": tm[32] * 1e-8, "scouts early": tm[33] * 1e-8, "scouts sweeps": tm[34] * 1e-8, "scouts idle": tm[35] * 1e-8, "chunks made": tm[36], "given up": tm[37]})
 print({k: v for k, v in st.items() if k != "timers"})
+print("compress_pair steps (build_timing.py pe) s:", {"first mate's head": tm[5] * 1e-8, "minimizers + staging": tm[6] * 1e-8, "pair-table look-ups": tm[38] * 1e-8, "merge + search in mate 2": tm[39] * 1e-8,
+                                                     "anchored: ids, copy, seed": tm[46] * 1e-8, "direct: second mate's head": tm[47] * 1e-8})
