@@ -74,6 +74,7 @@ struct HeadRec {
 struct WgShared {
   HeadRec hd[2];
   u32 hd_ready, hd_taken;      // read heads finished / consumed (free-running counts within the launch)
+  u32 hd_early;                // read heads whose part for the scout waves (codes, k-mers after the prefix) is in place
   u32 mt[4][624];              // MT19937 states of cinc_b, cinc_s, cinc_lb, cinc_ls
   u32 mt_idx[4];
   alignas(8) u8 rd[2][FQSX_RD_LDS];       // 2-bit codes (0..4) of the current read (two buffers: the head wave stages the next read)
@@ -222,6 +223,7 @@ struct Wk {
   u32 sc_base;                          // ring slot of the epoch's first chunk
   bool rq_early;                        // request mode: the coming suffix() call's request is posted already
   HeadRec *rec;                         // read-head wave: where the head's output goes (null: code / push directly)
+  u32 rec_idx;                          // ... and the read's index within the launch
   bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
   u32 cq_tail, cq_head;                 // this wave's copy of its own queue index
   bool rcq;                             // coding steps go to the range-coder queue (another wave runs the coder proper)
@@ -1961,6 +1963,22 @@ FQ_DEV void prefix_sorted(Wk &w, const u8 *p, u32 size) {  // compress_prefix_so
     if (sym == 4) { sym = 3; was_N = true; w.N_run++; } else w.N_run = 0;
     insert_all(w, sym);
   }
+  // Read-head wave: what the scout waves need of this read -- its codes (staged by read_head), the k-mers after the
+  // prefix -- is complete here; they start on the read's chunks while this wave ranks and codes the prefix.
+  if (w.rec) {
+    HeadRec *rec = w.rec;
+    FQ_SYNC();
+    if (FQ_LANE == 0) {
+      rec->same = 0;
+      rec->n_run = w.N_run;
+      rec->kdir[0] = w.pm.dir; rec->krc[0] = w.pm.rc; rec->kcur[0] = w.pm.cur;
+      rec->kdir[1] = w.sm_.dir; rec->krc[1] = w.sm_.rc; rec->kcur[1] = w.sm_.cur;
+      rec->kdir[2] = w.bm.dir; rec->krc[2] = w.bm.rc; rec->kcur[2] = w.bm.cur;
+      rec->idx = w.rec_idx;
+    }
+    FQ_SYNC();
+    lds_store_rel(&w.sm->hd_early, w.rec_idx + 1);
+  }
   // Request mode (no read-head wave: paired-end kernels): the k-mers after the prefix are final here, so the scout waves
   // can be sent off to the suffix's first chunks now, while this wave still ranks and codes the prefix (suffix() then
   // finds the request posted).
@@ -3216,6 +3234,10 @@ FQ_DEV bool read_head(Wk &w, const u8 *p, u32 size, const u8 *prev, u32 prev_siz
   km_reset(w.pm_u); km_reset(w.sm_u); km_reset(w.bm_u);
   w.cor_pos = 0;
   w.N_run = 0;
+  if (w.rec) {   // (read-head wave: part of what prefix_sorted hands to the scout waves early)
+    FQ_SYNC();
+    if (FQ_LANE == 0) for (u32 x = 0; x < 4; ++x) w.rec->hist[x] = hist[x];
+  }
   if (orig) prefix_direct(w, p, size); else prefix_sorted(w, p, size);
   return false;
 }
@@ -3521,6 +3543,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
     if (w.err) break;
     HeadRec *rec = &sm->hd[idx & 1];
     w.rec = rec;
+    w.rec_idx = idx;
     w.rdp = sm->rd[idx & 1];
     FQ_SYNC();
     if (FQ_LANE == 0) { rec->idx = ~0u; rec->n_raw = 0; rec->n_p = 0; }
@@ -3546,6 +3569,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
       rec->idx = idx;
     }
     FQ_SYNC();
+    lds_store_rel(&sm->hd_early, idx + 1);   // (a duplicate read has no prefix: its record is complete only here)
     lds_store_rel(&sm->hd_ready, idx + 1);
   }
   if (FQ_LANE == 0) {
@@ -3612,7 +3636,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
     }
     if (!restart) {
       TM_BEGIN(t_w1);
-      while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
+      while ((i32)(lds_load_acq(&sm->hd_early) - idx) <= 0) {
         if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
         fq_sleep();
         if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || spin_expired(spins)) { quit = true; break; }
@@ -3647,7 +3671,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       lds_store_rel(&sm->sc_ack[me], w.sc_epoch);   // (the read-head wave keeps the records until every scout is here)
       if (from_head) {   // the record may not be there yet
         spins = 0;
-        while ((i32)(lds_load_acq(&sm->hd_ready) - idx) <= 0) {
+        while ((i32)(lds_load_acq(&sm->hd_early) - idx) <= 0) {
           if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
           fq_sleep();
           if (lds_load_acq(&sm->cq_done) || lds_load_acq(&sm->sc_dead) || spin_expired(spins)) { quit = true; break; }

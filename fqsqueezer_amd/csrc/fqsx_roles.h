@@ -49,7 +49,7 @@ FQ_DEV void wg_handoff_init() {   // the one workgroup barrier of the kernel: th
   if (threadIdx.x == 0) {
     sm->cq_tail = 0; sm->cq_head = 0; sm->cq_done = 0;
     sm->lq_target[0] = sm->lq_target[1] = 0; sm->lq_done[0] = sm->lq_done[1] = 0; sm->lq_quit = 0;
-    sm->hd_ready = 0; sm->hd_taken = 0;
+    sm->hd_ready = 0; sm->hd_taken = 0; sm->hd_early = 0;
     sm->sc_taken = 0; sm->sc_req_seq = 0; sm->sc_dead = 0;
     for (u32 x = 0; x < FQSX_NSC; ++x) { sm->sc_hd_taken[x] = 0; sm->sc_ack[x] = 0; }
     for (u32 x = 1; x <= FQSX_SCR; ++x) sm->sb[x].h_pub = 0;
