@@ -121,7 +121,7 @@ struct WgShared {
   u64 pq_key[2][FQSX_PQ];      // LDS mirror of the most recent b / s list entries (ring indexed by list position)
   u64 ib_pos[64];              // insert_batch: target slot per lane
   u64 ib_hash[256];            // ... and the lanes per slot bucket
-  alignas(8) u32 qm_bits[4][128];         // quiet_miss_mask: 4096-bit sets of the sibling groups of recent list entries (b dir, b rc, s dir, s rc)
+  alignas(8) u32 qm_bits[4][256];         // quiet_miss_mask: 8192-bit sets (two hash bits per entry) of the sibling groups of recent list entries (b dir, b rc, s dir, s rc)
   // hand-off words of the local-table inserter wave: list entries published / applied per kind (b, s); quit
   u32 lq_target[2], lq_done[2], lq_quit;
   // coding queue: every symbol of the worker's stream in stream order, as the context keys of a rank-/letter-coded
@@ -2724,6 +2724,19 @@ FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reverse
 // would say no twice.  The mirror is tested through hashed bit sets (a set bit only sends the position down the
 // exact per-position path), the chunk's own entries exactly.  One position per lane.
 FQ_DEV u32 grp_hash(u64 g) { return (u32)((g * 0x9E3779B97F4A7C15ull) >> 52); }   // 12 bits
+// two 13-bit positions in an 8192-bit set per group: with a few hundred entries pending, one bit per entry left a quarter
+// of the positions "maybe" by chance, which cut the quiet stretches short
+FQ_DEV void qm_set(u32 *bits, u64 g) {
+  const u64 h = g * 0x9E3779B97F4A7C15ull;
+  const u32 a = (u32)(h >> 51), b = (u32)(h >> 38) & 8191u;
+  atomicOr(&bits[a >> 5], 1u << (a & 31));
+  atomicOr(&bits[b >> 5], 1u << (b & 31));
+}
+FQ_DEV bool qm_test(const u32 *bits, u64 g) {
+  const u64 h = g * 0x9E3779B97F4A7C15ull;
+  const u32 a = (u32)(h >> 51), b = (u32)(h >> 38) & 8191u;
+  return ((bits[a >> 5] >> (a & 31)) & (bits[b >> 5] >> (b & 31)) & 1u) != 0;
+}
 FQ_DEV u64 quiet_miss_mask(Wk &w, u32 n) {
   SpecBuf *sb = w.sb;
   WgShared *sm = w.sm;
@@ -2743,23 +2756,21 @@ FQ_DEV u64 quiet_miss_mask(Wk &w, u32 n) {
   const u64 vb = (ndb ? bd : br) >> (64 - k2b), vs = (nds ? sd : sr) >> (64 - k2s);
   const u64 gb = ndb ? (vb >> 2) : (vb & lmb), gs = nds ? (vs >> 2) : (vs & lms);
   // bit sets of the mirror entries' groups, both readings of every entry
-  for (u32 i = lane; i < 4 * 128; i += FQ_WAVE) (&sm->qm_bits[0][0])[i] = 0;
+  for (u32 i = lane; i < 4 * 256; i += FQ_WAVE) (&sm->qm_bits[0][0])[i] = 0;
   FQ_SYNC();
   for (u32 e = lo_b + lane; e < hi_b; e += FQ_WAVE) {
     const u64 pv = sm->pq_key[0][e & (FQSX_PQ - 1)] >> (64 - k2b);
-    const u32 h0 = grp_hash(pv >> 2), h1 = grp_hash(pv & lmb);
-    atomicOr(&sm->qm_bits[0][h0 >> 5], 1u << (h0 & 31));
-    atomicOr(&sm->qm_bits[1][h1 >> 5], 1u << (h1 & 31));
+    qm_set(sm->qm_bits[0], pv >> 2);
+    qm_set(sm->qm_bits[1], pv & lmb);
   }
   for (u32 e = lo_s + lane; e < hi_s; e += FQ_WAVE) {
     const u64 pv = sm->pq_key[1][e & (FQSX_PQ - 1)] >> (64 - k2s);
-    const u32 h0 = grp_hash(pv >> 2), h1 = grp_hash(pv & lms);
-    atomicOr(&sm->qm_bits[2][h0 >> 5], 1u << (h0 & 31));
-    atomicOr(&sm->qm_bits[3][h1 >> 5], 1u << (h1 & 31));
+    qm_set(sm->qm_bits[2], pv >> 2);
+    qm_set(sm->qm_bits[3], pv & lms);
   }
   FQ_SYNC();
   const u32 hb = grp_hash(gb), hs = grp_hash(gs);
-  bool maybe = ((sm->qm_bits[ndb ? 0 : 1][hb >> 5] >> (hb & 31)) & 1u) != 0 || ((sm->qm_bits[nds ? 2 : 3][hs >> 5] >> (hs & 31)) & 1u) != 0;
+  bool maybe = qm_test(sm->qm_bits[ndb ? 0 : 1], gb) || qm_test(sm->qm_bits[nds ? 2 : 3], gs);
   // the entries of the chunk's earlier positions, exactly: every position files its lane under the 6-bit hashes of its
   // entries' groups (both readings; the bit sets above are reused as 4 x 64 lane masks), and a lane compares groups
   // only with the earlier lanes filed where its own group hashes to

@@ -23,6 +23,16 @@ def test_hip_matches_reference_10k(name):
     check_against_fqs(gpu, c1_records(), name)
 
 
+@pytest.mark.parametrize("name", ["c1_10k_s_t4.fqs", "c1_10k_o_t1.fqs"])
+def test_hip_growth_posted_by_the_device_is_recovered(name, monkeypatch):
+    """Nothing is read back inside a block: the device checks the growth rule, stops the block's queue of kernels, and
+    the host grows the tables and resumes at that phase's inserts (fqsx_api.hip: phase_skip / block_recover).  From
+    256 slots per owner that happens in most blocks -- with the queue of real kernels in flight, which the emulation
+    build's test of the same name cannot show."""
+    monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    check_against_fqs(gpu, c1_records(), name)
+
+
 @pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
 def test_hip_matches_reference_ragged(name):
     check_against_fqs(gpu, c4_records(), name)
