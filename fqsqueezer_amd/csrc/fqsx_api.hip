@@ -41,9 +41,18 @@ extern "C" const char *fqsx_version(void) {
 // queue -- the inserts of that phase included -- does nothing.  The host finds the word with the end-of-block transfer,
 // grows the tables and takes the block up again at that phase's inserts (block_recover).  err[0]: device error word.
 FQ_DEV bool phase_skip(const DevCfg &cfg) { return (cfg.err[0] | cfg.err[1]) != 0; }
-FQ_KERNEL64 void k_insert_phase(DevCfg cfg) {  // grid = 3 * T: (owner, mailbox kind)
+// grid = 3 * T: (owner, mailbox kind), plus -- single-end encoding -- workgroups that clear the workers' local tables
+// (ClearKmersToHT, dna.cpp:2475-2488: the insert phase does not touch them), which saves that launch
+FQ_KERNEL64 void k_insert_phase(DevCfg cfg, u64 nb_slots, u64 ns_slots) {
   FQ_SHARED InsShared sm;
   if (phase_skip(cfg)) return;
+  if (FQ_BLOCK >= 3 * cfg.T) {
+    const u64 stride = (u64)(FQ_NBLOCKS - 3 * cfg.T) * FQ_WAVE, first = (u64)(FQ_BLOCK - 3 * cfg.T) * FQ_WAVE + FQ_LANE;
+    for (u64 i = first; i < nb_slots; i += stride) cfg.l_b.slots[i] = 0;
+    for (u64 i = first; i < ns_slots; i += stride) cfg.l_s.slots[i] = 0;
+    for (u64 i = first; i < 2ull * cfg.T; i += stride) cfg.l_s.filled[i] = 0;   // l_s.filled and l_b.filled are adjacent
+    return;
+  }
   insert_phase_body(cfg, &sm, FQ_BLOCK / 3, FQ_BLOCK % 3);
 }
 // gathers the T streams of the block into one contiguous buffer (one D2H transfer per block)
@@ -103,35 +112,57 @@ FQ_KERNEL64 void k_part_scan(DevCfg cfg) {
   if (phase_skip(cfg)) return;
   part_scan_body(cfg, FQ_BLOCK / cfg.T, FQ_BLOCK % cfg.T);
 }
+// group offsets of mailbox `kind`, the demand words, and -- seg1 != 0 -- the growth check (one wave per kind)
+FQ_DEV void part_dstoff_leader(const DevCfg &cfg, u32 kind, u32 *demand /*[2][T]+1*/, u32 seg1);
 // seg1: segment + 1 when the growth check is left to this kernel (else 0: the host reads `demand` before the inserts)
 FQ_KERNEL64 void k_part_dstoff(DevCfg cfg, u32 *demand /*[2][T]+1*/, u32 seg1) {
   if (cfg.err[0] || (cfg.err[1] && cfg.err[1] != seg1)) return;   // (another workgroup of this launch may just have posted the phase)
-  part_dstoff_body(cfg, FQ_BLOCK);
+  part_dstoff_leader(cfg, FQ_BLOCK, demand, seg1);
+}
+FQ_DEV void part_dstoff_leader(const DevCfg &cfg, u32 kind, u32 *demand, u32 seg1) {
+  part_dstoff_body(cfg, kind);
   // per-owner demand of the coming insert phase (s- and b-mers) + the device error word
   // per-owner demand of the coming insert phase (s- and b-mers), current occupancy, and the device error word:
   // everything the host needs for its growth decision in one transfer
-  if (FQ_BLOCK != MAIL_P)
+  if (kind != MAIL_P)
     for (u32 d = FQ_LANE; d < cfg.T; d += FQ_WAVE) {
-      const u32 o = (FQ_BLOCK == MAIL_S ? 0 : cfg.T) + d;
-      demand[o] = cfg.mail[FQ_BLOCK].dst_tot[d];
-      demand[2 * cfg.T + 1 + o] = (FQ_BLOCK == MAIL_S ? cfg.g_s : cfg.g_b).filled[d];
+      const u32 o = (kind == MAIL_S ? 0 : cfg.T) + d;
+      demand[o] = cfg.mail[kind].dst_tot[d];
+      demand[2 * cfg.T + 1 + o] = (kind == MAIL_S ? cfg.g_s : cfg.g_b).filled[d];
     }
-  if (FQ_BLOCK == 0 && FQ_LANE == 0) demand[2 * cfg.T] = *cfg.err;
-  if (seg1 && FQ_BLOCK != MAIL_P) {   // the host's growth rule (block_segment): occupancy after the inserts <= cap / 2
-    const KTab &t = FQ_BLOCK == MAIL_S ? cfg.g_s : cfg.g_b;
+  if (kind == 0 && FQ_LANE == 0) demand[2 * cfg.T] = *cfg.err;
+  if (seg1 && kind != MAIL_P) {   // the host's growth rule (block_segment): occupancy after the inserts <= cap / 2
+    const KTab &t = kind == MAIL_S ? cfg.g_s : cfg.g_b;
     bool over = false;
-    for (u32 d = FQ_LANE; d < cfg.T; d += FQ_WAVE) over |= ((u64)t.filled[d] + cfg.mail[FQ_BLOCK].dst_tot[d]) * 2 > t.cap_mask + 1;
+    for (u32 d = FQ_LANE; d < cfg.T; d += FQ_WAVE) over |= ((u64)t.filled[d] + cfg.mail[kind].dst_tot[d]) * 2 > t.cap_mask + 1;
     if (wave_any(over) && FQ_LANE == 0) cfg.err[1] = seg1;
   }
 }
-FQ_KERNEL64 void k_part_scatter(DevCfg cfg, u32 seg1) {
+// demand != null (single-end encoding): no k_part_dstoff launch before this one -- every workgroup scans the T group
+// totals itself (LDS), and the first workgroup of a kind does that kernel's work for the kind
+FQ_KERNEL64 void k_part_scatter(DevCfg cfg, u32 seg1, u32 *demand) {
   FQ_SHARED u32 cursor[256];
   FQ_SHARED u32 ld[64];
   FQ_SHARED u64 gm[256];
+  FQ_SHARED u32 doff[257];
   u32 kind, blk;
   if (cfg.err[0] || (cfg.err[1] && cfg.err[1] != seg1)) return;   // (the posted phase's own scatter runs: its inserts follow the growth)
   part_split(cfg, kind, blk);
-  part_scatter_body(cfg, kind, blk, cursor, ld, gm);
+  if (demand) {
+    const Mail &m = cfg.mail[kind];
+    u32 run = 0;
+    for (u32 base = 0; base < cfg.T; base += FQ_WAVE) {
+      const u32 d = base + FQ_LANE;
+      const u32 v = d < cfg.T ? m.dst_tot[d] : 0;
+      const u32 ex = wave_excl_scan32(v) + run;
+      if (d < cfg.T) doff[d] = ex;
+      run += wave_sum32(v);
+    }
+    if (FQ_LANE == 0) doff[cfg.T] = run;
+    FQ_SYNC();
+    if (blk == 0) part_dstoff_leader(cfg, kind, demand, seg1);
+  }
+  part_scatter_body(cfg, kind, blk, cursor, ld, gm, demand ? doff : nullptr);
 }
 // paired-end insert phase: per-owner demand, then the inserts
 FQ_KERNEL64 void k_pe_demand(DevCfg cfg, u32 *demand) {
@@ -819,6 +850,13 @@ int clear_local_tables(fqsx_dna *c) {
   return FQSX_OK;
 }
 
+// insert phase and ClearKmersToHT in one launch (single-end encoding)
+int insert_and_clear(fqsx_dna *c) {
+  const u64 words = (c->cur_need_lb + c->cur_need_ls) * c->T;
+  const u32 cgrid = (u32)std::min<u64>(2048, (words + 4095) / 4096 + 1);
+  LAUNCH(c, 1, k_insert_phase, 3 * c->T + cgrid, 64, c->cfg, c->cur_need_lb * c->T, c->cur_need_ls * c->T);
+  return FQSX_OK;
+}
 // growth decision from the demand words (k_part_dstoff): a sub-table is at most half full after the coming inserts
 int grow_for_demand(fqsx_dna *c) {
   const u32 T = c->T;
@@ -842,8 +880,7 @@ int block_recover(fqsx_dna *c, u32 seg) {
   if ((rc = grow_for_demand(c))) return rc;
   if (c->gs_cap + c->gb_cap == before) { g_err = "phase " + std::to_string(seg) + " posted for growth, but no table needs it"; return FQSX_E_DEVICE; }
   if ((rc = dzero(c, c->cfg.err + 1, sizeof(u32)))) return rc;
-  LAUNCH(c, 1, k_insert_phase, 3 * T, 64, c->cfg);
-  return clear_local_tables(c);
+  return insert_and_clear(c);
 }
 
 // One synchronisation segment on one GPU: encode launch, mailbox partition, growth decision, insert phase, clear
@@ -861,15 +898,13 @@ int block_segment(fqsx_dna *c, u32 seg) {
     LAUNCH(c, 2, k_part_scan, 3 * T, 64, cfg);
     if (!c->paired && !decode) {
       // single-end encoding: nothing is read back inside a block -- the growth check is the device's (phase_skip)
-      LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand, seg + 1);
-      LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, seg + 1);
-      LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg);
-      return clear_local_tables(c);
+      LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, seg + 1, c->d_demand);   // (group offsets, demand words and growth check included)
+      return insert_and_clear(c);
     }
     LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand, 0u);
     // the demand travels to the host while the scatter (which does not depend on the growth decision) runs
     if ((rc = d2h_small_begin(c, c->d_demand, (4 * T + 1) * sizeof(u32)))) return rc;
-    LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, 0u);
+    LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, 0u, (u32 *)nullptr);
     if ((rc = d2h_small_end(c, c->h_demand.data(), (4 * T + 1) * sizeof(u32)))) return rc;
     if (c->h_demand[2 * T]) {
       g_err = "device error " + std::to_string(c->h_demand[2 * T]) + " in encode kernel";
@@ -888,7 +923,7 @@ int block_segment(fqsx_dna *c, u32 seg) {
       if ((rc = dzero(c, cfg.l_pe.val, need_lpe * T * sizeof(u64)))) return rc;
       if ((rc = dzero(c, cfg.l_pe.filled, T * sizeof(u32)))) return rc;
     }
-    LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg);
+    LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
     if ((rc = clear_local_tables(c))) return rc;
   }
   return FQSX_OK;
@@ -1320,7 +1355,7 @@ int fqsx_shard_pack(fqsx_dna *c, const uint32_t *counts_sum /*[codec] summed ove
   const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
   LAUNCH(c, 2, k_part_scan, 3 * T, 64, cfg);
   LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand, 0u);
-  LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, 0u);
+  LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, 0u, (u32 *)nullptr);
   std::vector<u32> tot(3 * (T + 1));
   for (u32 k = 0; k < 3; ++k)
     if ((rc = d2h_sync(c, tot.data() + k * (T + 1), cfg.mail[k].dst_off, (T + 1) * sizeof(u32)))) return rc;
@@ -1369,7 +1404,7 @@ int fqsx_shard_insert(fqsx_dna *c, uint64_t need_s, uint64_t need_b, uint64_t *c
   if (need_s * 2 > c->gs_cap && (rc = grow_global(c, cfg.g_s, c->gs_cap, pow2_at_least(need_s * 2 + 2)))) return rc;
   if (need_b * 2 > c->gb_cap && (rc = grow_global(c, cfg.g_b, c->gb_cap, pow2_at_least(need_b * 2 + 2)))) return rc;
   if ((rc = d2h_sync(c, c->siv_before, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
-  LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg);
+  LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
   u64 after[2];
   if ((rc = d2h_sync(c, after, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
   siv_delta[0] = after[0] - c->siv_before[0];

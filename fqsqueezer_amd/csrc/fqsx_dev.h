@@ -4221,13 +4221,14 @@ FQ_DEV void part_dstoff_body(const DevCfg &cfg, u32 kind) {
   if (FQ_LANE == 0) m.dst_off[cfg.T] = run;
 }
 // tile `blk`: stable scatter into the owners' groups
-FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor /*LDS[256]*/, u32 *ld /*LDS[64]*/, u64 *gm /*LDS[256]*/) {
+FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor /*LDS[256]*/, u32 *ld /*LDS[64]*/, u64 *gm /*LDS[256]*/,
+                              const u32 *doff = nullptr /*LDS[T+1]: the group offsets, if the caller has scanned them itself*/) {
   const Mail &m = cfg.mail[kind];
   const u32 T = cfg.T, s = blk / m.n_tiles, t = blk % m.n_tiles;
   const u32 n = m.n[s], lo = t * FQSX_TILE, hi = n < lo + FQSX_TILE ? n : lo + FQSX_TILE;
   if (lo >= hi) return;
   for (u32 d = FQ_LANE; d < 256; d += FQ_WAVE) gm[d] = 0;
-  for (u32 d = FQ_LANE; d < T; d += FQ_WAVE) cursor[d] = m.dst_off[d] + m.tile_hist[(u64)blk * T + d];
+  for (u32 d = FQ_LANE; d < T; d += FQ_WAVE) cursor[d] = (doff ? doff[d] : m.dst_off[d]) + m.tile_hist[(u64)blk * T + d];
   FQ_SYNC();
   for (u32 base = lo; base < hi; base += FQ_WAVE) {
     const u32 e = base + FQ_LANE, cnt = hi - base < FQ_WAVE ? hi - base : FQ_WAVE;
