@@ -46,6 +46,8 @@ def _load(path: str):
     lib.fqsx_dna_decode_block.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     lib.fqsx_dna_stats.restype = C.c_int
     lib.fqsx_dna_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.fqsx_dna_capacity.restype = C.c_int
+    lib.fqsx_dna_capacity.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.fqsx_dna_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.fqsx_dna_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.fqsx_qual_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
@@ -133,6 +135,18 @@ class DnaCodec:
             raise FqsxError(f"fqsx_dna_stats: {rc}: {self._lib.fqsx_last_error().decode()}")
         d = dict(zip(STAT_NAMES, list(a)))
         d["timers"] = list(a)[16:64]
+        return d
+
+    def capacity(self) -> dict:
+        """Table occupancy and device memory (fqsx_dna_capacity)."""
+        a = (C.c_uint64 * 16)()
+        rc = self._lib.fqsx_dna_capacity(self._h, a)
+        if rc:
+            raise FqsxError(f"fqsx_dna_capacity: {rc}: {self._lib.fqsx_last_error().decode()}")
+        d = {"smers": a[0], "bmers": a[1], "smer_slots": a[2], "bmer_slots": a[3], "siv_bytes": a[4], "ctx_slots": a[5],
+             "contexts": a[6], "device_bytes": a[7], "device_bytes_peak": a[8], "growths": a[9], "pairs": a[10], "pair_slots": a[11]}
+        d["bytes_per_bmer"] = round(a[3] * a[12] / a[1], 2) if a[1] else 0.0
+        d["bytes_per_smer"] = round(a[2] * a[12] / a[0], 2) if a[0] else 0.0
         return d
 
     def set_profiling(self, on: bool) -> None:

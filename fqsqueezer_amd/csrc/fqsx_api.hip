@@ -116,7 +116,10 @@ FQ_KERNEL64 void k_part_scan(DevCfg cfg) {
 FQ_DEV void part_dstoff_leader(const DevCfg &cfg, u32 kind, u32 *demand /*[2][T]+1*/, u32 seg1);
 // seg1: segment + 1 when the growth check is left to this kernel (else 0: the host reads `demand` before the inserts)
 FQ_KERNEL64 void k_part_dstoff(DevCfg cfg, u32 *demand /*[2][T]+1*/, u32 seg1) {
-  if (cfg.err[0] || (cfg.err[1] && cfg.err[1] != seg1)) return;   // (another workgroup of this launch may just have posted the phase)
+  if (cfg.err[0] || (cfg.err[1] && cfg.err[1] != seg1)) {   // (another workgroup of this launch may just have posted the phase)
+    if (FQ_BLOCK == 0 && FQ_LANE == 0) demand[2 * cfg.T] = cfg.err[0];   // the host's per-phase check reads the error word here
+    return;
+  }
   part_dstoff_leader(cfg, FQ_BLOCK, demand, seg1);
 }
 FQ_DEV void part_dstoff_leader(const DevCfg &cfg, u32 kind, u32 *demand, u32 seg1) {
@@ -432,6 +435,9 @@ struct fqsx_dna {
   std::vector<u8> h_out;
   std::vector<u64> h_lens;
   std::vector<void *> allocs;
+  std::vector<u64> alloc_bytes;   // size of allocs[i]
+  u64 dev_bytes, dev_bytes_peak;  // device memory held now / at most so far (fqsx_dna_capacity)
+  u32 n_growths;                  // growth events of the global k-mer / pair tables
   u8 *h_pin;          // pinned host scratch for the small device-to-host transfers of the phase loop
   u64 *d_end;         // block epilogue in one transfer: [T] stream lengths, [T] context-table occupancies, error word
   bool filled_valid;  // h_filled holds the context-table occupancies as of the end of the last encoded block
@@ -464,12 +470,20 @@ int dalloc(fqsx_dna *c, void **p, u64 bytes, bool zero) {
   if (!*p) { g_err = "host allocation failed"; return FQSX_E_NOMEM; }
 #endif
   c->allocs.push_back(*p);
+  c->alloc_bytes.push_back(bytes);
+  c->dev_bytes += bytes;
+  c->dev_bytes_peak = std::max(c->dev_bytes_peak, c->dev_bytes);
   return FQSX_OK;
 }
 void dfree(fqsx_dna *c, void *p) {
   if (!p) return;
   auto it = std::find(c->allocs.begin(), c->allocs.end(), p);
-  if (it != c->allocs.end()) c->allocs.erase(it);
+  if (it != c->allocs.end()) {
+    const size_t i = it - c->allocs.begin();
+    c->dev_bytes -= c->alloc_bytes[i];
+    c->alloc_bytes.erase(c->alloc_bytes.begin() + i);
+    c->allocs.erase(it);
+  }
 #ifndef FQSX_EMU
   (void)hipFree(p);
 #else
@@ -613,6 +627,7 @@ int grow_global(fqsx_dna *c, KTab &t, u64 &cap_field, u64 new_cap) {
   dfree(c, t.slots);
   t = n;
   cap_field = new_cap;
+  c->n_growths += 1;
   return FQSX_OK;
 }
 
@@ -643,6 +658,7 @@ int grow_gpe(fqsx_dna *c, u64 new_cap) {
   dfree(c, c->cfg.g_pe.val);
   c->cfg.g_pe = n;
   c->gpe_cap = new_cap;
+  c->n_growths += 1;
   return FQSX_OK;
 }
 
@@ -1015,6 +1031,8 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   cfg.pmer_mod_shift = 2 * cfg.pmer - 12;          // dna.cpp:2381
   cfg.T_magic = ((1ull << 32) + T - 1) / T;
   cfg.T_pow2 = (T & (T - 1)) == 0 ? 1u : 0u;
+  cfg.dbg = 0;
+  if (const char *e = getenv("FQSX_PROTO_DEBUG")) cfg.dbg = (u32)strtoul(e, nullptr, 0);   // (tests: forced fall-back branches, FQSX_DBG_*)
   cfg.ps_nobytes_n = (2 * cfg.pmer + 7) / 8;       // dna.cpp:130
   int rc;
   void *p = nullptr;
@@ -1184,6 +1202,7 @@ int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) {
   c->compact_cap = 0;
   c->din_cap = c->dout_cap = 0;
   c->shard_rank = 0; c->shard_world = 1;
+  c->dev_bytes = c->dev_bytes_peak = 0; c->n_growths = 0;
   c->h_pin = nullptr; c->d_end = nullptr; c->filled_valid = false;
   c->d_vmap = nullptr; c->d_xbuf = nullptr; c->xbuf_cap = 0; c->d_cglob = nullptr;
   c->cur_n_reads = c->cur_S = c->cur_gen = 0;
@@ -1459,8 +1478,40 @@ int fqsx_dna_stats(fqsx_dna *c, uint64_t out[64]) {
   return d2h_sync(c, out, c->d_lens + c->T, 64 * sizeof(u64));
 }
 
-// timing builds: the role time stamps of the first `max_launches` encode launches ([launch][worker][8], 10 ns ticks);
-// returns the number of launches copied (0 in product builds)
+int fqsx_dna_capacity(fqsx_dna *c, uint64_t out[16]) {
+  if (!c || !out) return FQSX_E_ARG;
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  const u32 T = c->T;
+  std::vector<u32> f(T);
+  int rc;
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  if ((rc = d2h_sync(c, f.data(), c->cfg.g_s.filled, T * sizeof(u32)))) return rc;
+  for (u32 t = 0; t < T; ++t) out[0] += f[t];
+  if ((rc = d2h_sync(c, f.data(), c->cfg.g_b.filled, T * sizeof(u32)))) return rc;
+  for (u32 t = 0; t < T; ++t) out[1] += f[t];
+  out[2] = c->gs_cap * T;
+  out[3] = c->gb_cap * T;
+  out[4] = (1ull << (2 * c->cfg.pmer)) / 4;
+  out[5] = c->ctx_cap * T;
+  if ((rc = d2h_sync(c, f.data(), c->cfg.ctx_filled, T * sizeof(u32)))) return rc;
+  for (u32 t = 0; t < T; ++t) out[6] += f[t];
+  out[7] = c->dev_bytes;
+  out[8] = c->dev_bytes_peak;
+  out[9] = c->n_growths;
+  if (c->paired) {
+    if ((rc = d2h_sync(c, f.data(), c->cfg.g_pe.filled, T * sizeof(u32)))) return rc;
+    for (u32 t = 0; t < T; ++t) out[10] += f[t];
+    out[11] = c->gpe_cap * T;
+  }
+  out[12] = sizeof(u64);   // bytes per global-table slot
+  return FQSX_OK;
+}
+
+// timing builds: the role time stamps of the first `max_launches` encode launches ([launch][worker][FQSX_TRACE_WORDS]: 8 stamps
+// in 10 ns ticks + 24 counters); returns the number of launches copied (0 in product builds)
+static_assert(FQSX_TRACE_WORDS == FQSX_TRACE_W, "include/fqsx.h documents the trace record width");
 int fqsx_dna_trace(fqsx_dna *c, uint64_t *out, uint32_t max_launches) {
   if (!c || !out || !c->cfg.trace) return 0;
   u32 n = (u32)std::min<u64>(std::min<u64>(c->k_n[0], FQSX_TRACE_LAUNCHES), max_launches);
@@ -1678,7 +1729,10 @@ static int qual_encode_impl(fqsx_qual *q, const uint8_t *quals, const uint8_t *d
   if ((rc = d2h_sync(c, &err, cfg.err, sizeof(u32)))) return rc;
   if (err) { g_err = "device error " + std::to_string(err) + " in the quality kernel"; return FQSX_E_DEVICE; }
   u64 total = 0;
-  for (u32 t = 0; t < T; ++t) total += q->h_lens[t];
+  for (u32 t = 0; t < T; ++t) {
+    if (q->h_lens[t] > cfg.out_cap) { g_err = "quality stream overflow"; return FQSX_E_DEVICE; }
+    total += q->h_lens[t];
+  }
   q->h_out.resize(total ? total : 1);
   u64 pos = 0;
   for (u32 t = 0; t < T; ++t) {
@@ -1792,7 +1846,7 @@ extern "C" int fqsx_sort_order(const uint8_t *bases, const uint64_t *read_off, u
   if (device < 0 || device >= ndev) { g_err = "bad device ordinal"; return FQSX_E_ARG; }
   HIPCHK(hipSetDevice(device));
 #endif
-  fqsx_dna mem;
+  fqsx_dna mem{};
   fqsx_dna *c = &mem;
   c->T = 1; c->device = device; c->profiling = false;
 #ifndef FQSX_EMU

@@ -137,6 +137,7 @@ struct WgShared {
   u32 rq_f[FQSX_RQ], rq_c[FQSX_RQ], rq_t[FQSX_RQ];
   u64 rq_m[FQSX_RQ];
   u32 rq_tail, rq_head, rq_done;
+  u32 wg_stop;                 // the block's queue has been stopped (device error / posted growth): read once per workgroup, see wg_handoff_init
 };
 #ifndef FQSX_EMU
 static_assert(sizeof(WgShared) <= 160u * 1024u, "WgShared must fit the 160 KB of LDS of a gfx950 CU");
@@ -630,8 +631,9 @@ FQ_DEV void insert_keys(const DevCfg &cfg, SM *sm, const KTab &t, u32 sub, const
 // kernel), or inline on demand (single-wave builds).  A look-up only has to wait for entries that could change its
 // answer, so the tables always give exactly what the sequential algorithm would have seen.
 FQ_DEV u32 lq_done_now(Wk &w, u32 qi) { return w.lqh ? lds_load_acq(&w.sm->lq_done[qi]) : w.la[qi ? MAIL_S : MAIL_B]; }
-FQ_DEV void lq_publish(Wk &w) {   // hand the list entries written so far to the inserter wave
+FQ_DEV void lq_publish(Wk &w, bool force = false) {   // hand the list entries written so far to the inserter wave
   if (!w.lqh) return;
+  if (!force && (w.cfg->dbg & FQSX_DBG_INSERTER_STALL)) return;   // (test switch: only a waiting look-up publishes)
   const u32 nb = w.mn[MAIL_B], ns = w.mn[MAIL_S];
   if (nb != w.lq_pub[0]) { lds_store_rel(&w.sm->lq_target[0], nb); w.lq_pub[0] = nb; }
   if (ns != w.lq_pub[1]) { lds_store_rel(&w.sm->lq_target[1], ns); w.lq_pub[1] = ns; }
@@ -644,7 +646,7 @@ FQ_DEV void lq_flush(Wk &w, u32 kind) {
     if (lds_load_acq(&w.sm->lq_done[qi]) >= n) return;
     TM_BEGIN(t_lq);
     TM_COUNT(w, CN_LQFLUSH);
-    lq_publish(w);
+    lq_publish(w, true);
     u32 spins = 0;
     while (lds_load_acq(&w.sm->lq_done[qi]) < n) {
       fq_sleep();
@@ -869,6 +871,7 @@ FQ_DEV void enc_open(Wk &w, u64 low, u64 range, u64 len, const DevCfg &cfg) {
   if (part && w.enc.len < w.enc.cap) w.enc.acc = uniform64(((const u64 *)w.enc.out)[w.enc.len >> 3]) & ((1ull << (8 * part)) - 1ull);
 }
 FQ_DEV void enc_close(Wk &w) {   // the partly filled word (its tail is rewritten when the stream goes on)
+  if (w.enc.len > w.enc.cap) { w.err = FQSX_ERR_OUT_OVERFLOW; return; }   // (ended inside the word beyond the buffer: rc_put has not seen it)
   if ((w.enc.len & 7) && w.enc.len < w.enc.cap) ((u64 *)w.enc.out)[w.enc.len >> 3] = w.enc.acc;
 }
 FQ_DEV void rc_put(Wk &w, u8 b) {
@@ -2879,9 +2882,13 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
     w.sc_abandoned = false;
     scout_restart(w, w.sc_read, i, w.s_let, 0, false);
   }
+  const u32 dbg = cfg->dbg;
+  if ((dbg & FQSX_DBG_ABANDON) && w.scout && w.sc_read % 3 == 1) w.sc_abandoned = true;   // (test switch) this read without the scouts
+  const u32 i_first = i;
   while (i < size && !w.err) {
     const u32 n = chunk_len(size - i);
     TM_BEGIN(t_sp);
+    if ((dbg & FQSX_DBG_ABANDON) && w.scout && w.sc_read % 3 == 2 && i != i_first) w.sc_abandoned = true;   // ... this one after its first chunk
     bool pre = false;
     if (w.scout && !w.sc_abandoned) pre = scout_take(w, i, n);   // stage P done ahead of time by the scout wave
     if (!pre) {
@@ -3209,8 +3216,13 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       replace_last_all(w, sym == 4 ? 0 : sym);
       w.N_run = sym == 4 ? w.N_run + 1 : 0;
     }
+    bool forced = false;
+    if (!reposted && (dbg & FQSX_DBG_RESTART) && w.scout && !w.sc_abandoned && i + m < size) {   // (test switch) a restart from the exact state after every chunk
+      scout_restart(w, w.sc_read, i + m, w.s_let, 0, false);
+      forced = true;
+    }
     if (reposted) { if (pre) scout_unhold(w); }   // (a new epoch: nothing else to release)
-    else if (pre) scout_release(w);
+    else if (pre && !forced) scout_release(w);
     i += m;
   }
 }
@@ -3636,6 +3648,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
   while (!quit) {
     u32 spins = 0;
     u32 base_pos = cfg.pmer;   // the k-mers in w stand before this position of the read
+    if (lds_load_acq(&sm->sc_dead)) break;
     if (idx >= n_seg && !restart) {
       // every read has its chunks; stay until the resolving wave has finished the last read (it may still ask for a restart)
       if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; continue; }
@@ -3881,7 +3894,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.rdp = sm->rd[0];
   constexpr bool heads = PIPED && MODE == 1;   // single-end sorted: the read heads come from the read-head wave
   w.sb = &sm->sb[0];
-  w.scout = PIPED;                        // stage P comes from the scout waves
+  w.scout = PIPED && !(cfg.dbg & FQSX_DBG_SCOUTS_OFF);   // stage P comes from the scout waves
   w.sc_reqmode = PIPED && MODE != 1;      // ... which, without a read-head wave, serve one request per compress_suffix call
   w.nsc = MODE >= 2 ? 2u : FQSX_NSC;
   w.rq_p = nullptr; w.rq_size = 0; w.rq_rev = false;
@@ -4031,7 +4044,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
 #endif
   if (!piped) {
     for (u32 i = 0; i < ST_N; ++i) ws->stat[i] += w.st[i];
-    for (u32 i = 0; i < FQSX_TM_SLOTS; ++i) ws->stat[16 + i] += w.tm[i];
+    for (u32 i = 0; i < FQSX_TM_SLOTS && i < 48; ++i) ws->stat[16 + i] += w.tm[i];   // (stat[] has 64 words: [48..] only go to the trace)
   } else if (FQ_LANE == 0) {   // the coder wave adds to the same counters
     for (u32 i = 0; i < ST_N; ++i) if (w.st[i]) atomic_add64(&ws->stat[i], w.st[i]);
 #ifdef FQSX_TIMING

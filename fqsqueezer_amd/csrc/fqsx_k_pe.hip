@@ -7,7 +7,7 @@
 #ifndef FQSX_EMU
 template <int MODE> FQ_DEV void encode_pe_kernel_body(const EncArgs &a) {
   if (worker_elsewhere(a)) return;
-  wg_handoff_init();
+  if (wg_handoff_init(a, false)) return;   // a device error stops the block's remaining launches (the host reads the word per phase)
   switch (FQ_WAVE_ID) {
     case 1: role_scout_req<0, 2>(fq_kernarg()); break;
     case 2: role_resolve<MODE>(fq_kernarg()); break;

@@ -11,9 +11,8 @@
 
 #ifndef FQSX_EMU
 FQ_KERNEL512 void k_encode_se_sorted(EncArgs a) {
-  if (a.cfg.err[0] | a.cfg.err[1]) return;   // the block's queue has been stopped (fqsx_api.hip: phase_skip)
   if (worker_elsewhere(a)) return;
-  wg_handoff_init();
+  if (wg_handoff_init(a, true)) return;   // the block's queue has been stopped (fqsx_api.hip: phase_skip)
   switch (FQ_WAVE_ID) {
     case 0: role_head(fq_kernarg()); break;
     case 1: role_scout<0>(fq_kernarg()); break;
@@ -26,9 +25,8 @@ FQ_KERNEL512 void k_encode_se_sorted(EncArgs a) {
   }
 }
 FQ_KERNEL512 void k_encode_se_orig(EncArgs a) {
-  if (a.cfg.err[0] | a.cfg.err[1]) return;
   if (worker_elsewhere(a)) return;
-  wg_handoff_init();
+  if (wg_handoff_init(a, true)) return;
   switch (FQ_WAVE_ID) {
     case 0: break;
     case 1: role_scout_req<0, 3>(fq_kernarg()); break;

@@ -151,7 +151,7 @@ struct DevCfg {
   u32 ps_nobytes_n;            // alphabet of prefix_sorted_no_bytes, dna.cpp:130
   u64 T_magic;                 // ceil(2^32 / T): x % T for x < 2^14 without a division
   u32 T_pow2;                  // T is a power of two (then x % T is a mask)
-  u32 pad0_;
+  u32 dbg;                     // FQSX_DBG_*: forces the fall-back branches of the eight-wave protocol (tests only; env FQSX_PROTO_DEBUG)
   u64 *siv;                    // 4^pmer 2-bit counters
   u64 *siv_stats;              // [0] no_updates [1] no_filled (bit_vec.h:25-26)
   KTab g_s, g_b;               // owner-sharded global tables (T sub-tables)
@@ -187,6 +187,14 @@ struct DevCfg {
   u32 *shard_cnt;              // [3][T][T] entries source s pushed for owner o in this phase (own sources; else 0)
 };
 
+// Protocol test switches (DevCfg.dbg).  Which wave settles what depends on wave timing in the product run, so the
+// branches taken when a partner is late or absent are otherwise exercised only by chance; results must not change.
+enum {
+  FQSX_DBG_SCOUTS_OFF = 1,      // no scout waves: the resolving wave runs stage P, the sweeps and the partial look-ups itself
+  FQSX_DBG_ABANDON = 2,         // the resolving wave abandons the scouts on every third read from its start, on every third after its first chunk
+  FQSX_DBG_RESTART = 4,         // a scout restart (new epoch from the exact state) after every chunk, corrected or not
+  FQSX_DBG_INSERTER_STALL = 8,  // the inserter wave gets list entries only when a look-up has to wait for them (and at the end of a segment)
+};
 enum {
   FQSX_ERR_OUT_OVERFLOW = 1,
   FQSX_ERR_GTAB_FULL = 2,

@@ -31,6 +31,7 @@ FQ_DEV void q_put(QEnc &e, u8 b) {   // output bytes leave as aligned 8-byte wor
   }
 }
 FQ_DEV void q_flush(QEnc &e) {
+  if (e.len > e.cap) { e.err = 1; return; }   // (a stream that ends inside the word beyond the buffer: q_put has not seen it)
   if ((e.len & 7) && e.len < e.cap) ((u64 *)e.out)[e.len >> 3] = e.acc;
 }
 FQ_DEV u64 q_div(u64 x, u32 d) {  // exact x / d for d < 2^16 (see div_u64_small in fqsx_dev.h)

@@ -44,17 +44,23 @@ FQ_DEV bool worker_elsewhere(const EncArgs &a) {
   }
   return true;
 }
-FQ_DEV void wg_handoff_init() {   // the one workgroup barrier of the kernel: the LDS hand-off words start at zero
+// The one workgroup barrier of the kernel: the LDS hand-off words start at zero.  Returns true if the block's queue has
+// been stopped (fqsx_api.hip: phase_skip) -- decided ONCE per workgroup (thread 0 reads the words, every wave branches on
+// the LDS copy after the barrier), so that a word another workgroup of the same launch writes meanwhile cannot send
+// some waves of a worker home and the rest into the hand-off protocol without their partners.
+FQ_DEV bool wg_handoff_init(const EncArgs &a, bool honour_posted) {
   WgShared *sm = fq_wg();
   if (threadIdx.x == 0) {
+    sm->wg_stop = (a.cfg.err[0] | (honour_posted ? a.cfg.err[1] : 0u)) != 0 ? 1u : 0u;
     sm->cq_tail = 0; sm->cq_head = 0; sm->cq_done = 0;
     sm->lq_target[0] = sm->lq_target[1] = 0; sm->lq_done[0] = sm->lq_done[1] = 0; sm->lq_quit = 0;
     sm->hd_ready = 0; sm->hd_taken = 0; sm->hd_early = 0;
-    sm->sc_taken = 0; sm->sc_req_seq = 0; sm->sc_dead = 0;
+    sm->sc_taken = 0; sm->sc_req_seq = 0; sm->sc_dead = (a.cfg.dbg & FQSX_DBG_SCOUTS_OFF) ? 1u : 0u;
     for (u32 x = 0; x < FQSX_NSC; ++x) { sm->sc_hd_taken[x] = 0; sm->sc_ack[x] = 0; }
     for (u32 x = 1; x <= FQSX_SCR; ++x) sm->sb[x].h_pub = 0;
     sm->rq_tail = 0; sm->rq_head = 0; sm->rq_done = 0;
   }
   FQ_WG_BARRIER();
+  return sm->wg_stop != 0;
 }
 #endif

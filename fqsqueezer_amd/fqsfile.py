@@ -18,44 +18,58 @@ def _gpu_groups(rec: hp.Records, device: int, lib_path: Optional[str]):
     return sort_order(bases, off, device=device, lib_path=lib_path)
 
 
-def _encode(header: bytes, blocks, arrays, sizes_of, paired: bool, device: int, lib_path: Optional[str]) -> bytes:
+def encode_blocks(header: bytes, blocks, arrays, sizes_of, paired: bool, device: int, lib_path: Optional[str], stats: Optional[dict] = None):
+    """Generator of the file's container blocks.  Per block the four coders run side by side, as the reference's worker
+    codes meta, id, DNA and quality of a read in one loop (application.cpp:633-641): the DNA kernels and the quality kernel
+    on their own HIP streams (two host threads inside the C ABI, which releases the GIL), the meta and id coders on host
+    threads meanwhile."""
+    from concurrent.futures import ThreadPoolExecutor
     threads = header[4]
     stored = hp.stored_streams(header)
     dna = DnaCodec(header, device=device, lib_path=lib_path)
     meta = MetaCodec(threads, lib_path=lib_path)
     idc = IdCodec(header, lib_path=lib_path) if hp.STREAM_ID in stored else None
     qual = QualCodec(header, device=device, lib_path=lib_path) if hp.STREAM_QUALITY in stored else None
-    out = []
+    pool = ThreadPoolExecutor(max_workers=3)
     try:
         for g, idx in enumerate(blocks):
             bases, off, ids, id_off, quals = arrays(idx)
             n = len(off) - 1
-            st = {hp.STREAM_DNA: dna.encode_block(bases, off, g),
-                  hp.STREAM_META: meta.encode_block(np.diff(off.astype(np.int64)).astype(np.uint32), paired)}
-            if idc is not None:
-                st[hp.STREAM_ID] = idc.encode_block(ids, id_off, paired)
+            jobs = {hp.STREAM_DNA: pool.submit(dna.encode_block, bases, off, g)}
             if qual is not None:
-                st[hp.STREAM_QUALITY] = qual.encode_block(quals, off)
+                jobs[hp.STREAM_QUALITY] = pool.submit(qual.encode_block, quals, off)
+            if idc is not None:
+                jobs[hp.STREAM_ID] = pool.submit(idc.encode_block, ids, id_off, paired)
+            st = {hp.STREAM_META: meta.encode_block(np.diff(off.astype(np.int64)).astype(np.uint32), paired)}
+            for k, f in jobs.items():
+                st[k] = f.result()
             cs = np.concatenate([[0], np.cumsum(sizes_of(idx))])
             blk = hp.FqsBlock(n)
             for w, (first, _) in enumerate(hp.partition_for_workers(n, threads)):
                 blk.offsets.append(int(cs[first]) if n else 0)   # application.cpp:716
                 blk.streams.append({k: v[w] for k, v in st.items()})
-            out.append(blk)
+            yield blk
+        if stats is not None:
+            stats["dna"] = dna.stats()
     finally:
+        pool.shutdown(wait=True)
         dna.close()
         meta.close()
         if idc is not None:
             idc.close()
         if qual is not None:
             qual.close()
-    return hp.write_fqs(header, out)
+
+
+def _encode(header: bytes, blocks, arrays, sizes_of, paired: bool, device: int, lib_path: Optional[str]) -> bytes:
+    return hp.write_fqs(header, encode_blocks(header, blocks, arrays, sizes_of, paired, device, lib_path))
 
 
 def compress_records(rec: hp.Records, threads: int, order: str = "s", genome_size_mbp: int = 3100, device: int = 0,
                      lib_path: Optional[str] = None, quality_mode: str = "none", id_mode: str = "none",
-                     quality_thr: int = 20) -> bytes:
-    """`fqs e -s -om <order> -t <threads> -gs <g> -qm <..> -im <..>` on single-end records."""
+                     quality_thr: int = 20, as_blocks: bool = False):
+    """`fqs e -s -om <order> -t <threads> -gs <g> -qm <..> -im <..>` on single-end records.  Returns the file's bytes, or
+    -- as_blocks -- (header, generator of container blocks) for files too large to hold (hostpipe.fqs_chunks serialises them)."""
     mode = "se_sorted" if order == "s" else "se_original"
     header = hp.make_header(threads, mode, genome_size_mbp, quality_mode, id_mode, quality_thr)
     sizes = rec.record_sizes()
@@ -67,12 +81,14 @@ def compress_records(rec: hp.Records, threads: int, order: str = "s", genome_siz
         return bases, off, ids, id_off, quals
 
     groups = _gpu_groups(rec, device, lib_path) if mode == "se_sorted" else None
+    if as_blocks:
+        return header, encode_blocks(header, hp.form_blocks(rec, mode, groups=groups), arrays, lambda idx: sizes[idx], False, device, lib_path)
     return _encode(header, hp.form_blocks(rec, mode, groups=groups), arrays, lambda idx: sizes[idx], False, device, lib_path)
 
 
 def compress_records_pe(rec1: hp.Records, rec2: hp.Records, threads: int, order: str = "s", genome_size_mbp: int = 3100,
                         device: int = 0, lib_path: Optional[str] = None, quality_mode: str = "none", id_mode: str = "none",
-                        quality_thr: int = 20) -> bytes:
+                        quality_thr: int = 20, as_blocks: bool = False):
     """`fqs e -p ...` on two mate files (records interleaved mate 1 / mate 2 inside a block)."""
     mode = "pe_sorted" if order == "s" else "pe_original"
     header = hp.make_header(threads, mode, genome_size_mbp, quality_mode, id_mode, quality_thr)
@@ -90,4 +106,6 @@ def compress_records_pe(rec1: hp.Records, rec2: hp.Records, threads: int, order:
         return z
 
     groups = _gpu_groups(rec1, device, lib_path) if mode == "pe_sorted" else None   # mates follow mate 1's order, io.h:541-550
+    if as_blocks:
+        return header, encode_blocks(header, hp.form_blocks_pe(rec1, rec2, mode, groups=groups), arrays, sizes_of, True, device, lib_path)
     return _encode(header, hp.form_blocks_pe(rec1, rec2, mode, groups=groups), arrays, sizes_of, True, device, lib_path)

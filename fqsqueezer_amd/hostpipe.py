@@ -270,17 +270,22 @@ def parse_fqs(data: bytes) -> Tuple[bytes, List[FqsBlock]]:
     return header, blocks
 
 
-def write_fqs(header: bytes, blocks: Iterable[FqsBlock]) -> bytes:
-    out = [bytes([17]), header]
+def fqs_chunks(header: bytes, blocks: Iterable[FqsBlock]):
+    """The file as a sequence of byte chunks: the header, then one chunk per container block."""
+    yield bytes([17]) + header
     sids = stored_streams(header)
     for b in blocks:
-        out.append(put_varint(b.n_reads))
+        out = [put_varint(b.n_reads)]
         for off, st in zip(b.offsets, b.streams):
             out.append(put_varint(off))
             for sid in sids:
                 out.append(put_varint(len(st[sid])))
                 out.append(st[sid])
-    return b"".join(out)
+        yield b"".join(out)
+
+
+def write_fqs(header: bytes, blocks: Iterable[FqsBlock]) -> bytes:
+    return b"".join(fqs_chunks(header, blocks))
 
 
 # ----------------------------------------------------------------------------------------
@@ -351,6 +356,10 @@ def form_blocks_pe(rec1: Records, rec2: Records, dna_mode: str = "pe_sorted", gr
 
 def block_arrays_pe(rec1: Records, rec2: Records, idx: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """Interleaved mates (r1_0, r2_0, r1_1, r2_1, ...) of one block: bases + 2*n_pairs+1 offsets."""
+    if isinstance(rec1.seq, np.ndarray) and isinstance(rec2.seq, np.ndarray) and rec1.seq.shape[1] == rec2.seq.shape[1]:
+        L = rec1.seq.shape[1]
+        both = np.stack([rec1.seq[idx], rec2.seq[idx]], axis=1)      # (n, 2, L)
+        return both.reshape(-1), np.arange(2 * len(idx) + 1, dtype=np.uint64) * np.uint64(L)
     parts = []
     for i in idx:
         parts.append(rec1.seq_bytes(int(i)))
@@ -390,6 +399,10 @@ def id_arrays_pe(rec1: Records, rec2: Records, idx: np.ndarray) -> Tuple[np.ndar
 
 
 def qual_arrays_pe(rec1: Records, rec2: Records, idx: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    if isinstance(rec1.qual, np.ndarray) and isinstance(rec2.qual, np.ndarray) and rec1.qual.shape[1] == rec2.qual.shape[1]:
+        L = rec1.qual.shape[1]
+        both = np.stack([rec1.qual[idx], rec2.qual[idx]], axis=1)
+        return both.reshape(-1), np.arange(2 * len(idx) + 1, dtype=np.uint64) * np.uint64(L)
     parts = []
     for i in idx:
         parts.append(rec1.qual_bytes(int(i)))

@@ -182,26 +182,43 @@ def synth_ragged(n_reads: int, genome_len: int, seed: int, min_len: int = 30, ma
 
 
 def synth_pairs(n_pairs: int, read_len: int, genome_len: int, seed: int, frag_min: int = 300, frag_max: int = 600,
-                sub_rate: float = 0.005, n_rate: float = 0.001):
+                sub_rate: float = 0.005, n_rate: float = 0.001, chunk: int = 1 << 16):
     """Paired-end reads: fragment of random length, mate 1 from its start (forward), mate 2 the reverse
-    complement of its end; fragment strand 50/50.  Returns two (n_pairs, read_len) uint8 arrays."""
+    complement of its end; fragment strand 50/50.  Returns two (n_pairs, read_len) uint8 arrays.
+    The draws are, in this order: genome, fragment lengths, positions, strands, then per mate the (n, L) uniforms
+    followed by the (n, L) substitution letters.  They are made in row chunks (memory: 5 M pairs need a few GB instead
+    of tens) WITHOUT changing the stream: the uniforms of a mate come from a copy of the generator, the generator
+    itself is advanced past them (one 64-bit step per double) and then supplies the letters; `chunk` is a multiple of
+    8 rows so that every chunk of uint8 letters consumes whole 64-bit outputs."""
+    assert chunk % 8 == 0
     rng = np.random.Generator(np.random.PCG64(seed))
     genome = _ACGT[rng.integers(0, 4, size=genome_len, dtype=np.uint8)]
     frag = rng.integers(frag_min, frag_max + 1, size=n_pairs, dtype=np.int64)
     pos = (rng.random(n_pairs) * (genome_len - frag)).astype(np.int64)
     strand = rng.integers(0, 2, size=n_pairs, dtype=np.uint8)
     ar = np.arange(read_len, dtype=np.int64)
-    left = genome[pos[:, None] + ar[None, :]]
-    right = _COMP[genome[(pos + frag - read_len)[:, None] + ar[None, :]][:, ::-1]]
-    r1 = np.where(strand[:, None] == 0, left, right)
-    r2 = np.where(strand[:, None] == 0, right, left)
     out = []
-    for r in (r1, r2):
-        u = rng.random(size=(n_pairs, read_len))
-        alt = _ACGT[rng.integers(0, 4, size=(n_pairs, read_len), dtype=np.uint8)]
-        r = np.where(u < sub_rate, alt, r)
-        r = np.where((u >= sub_rate) & (u < sub_rate + n_rate), np.uint8(ord("N")), r)
-        out.append(np.ascontiguousarray(r))
+    for mate in (0, 1):
+        res = np.empty((n_pairs, read_len), dtype=np.uint8)
+        bg_u = np.random.PCG64()
+        bg_u.state = rng.bit_generator.state          # the uniforms: n * L doubles from here
+        rng_u = np.random.Generator(bg_u)
+        st0 = rng.bit_generator.state
+        rng.bit_generator.advance(n_pairs * read_len)  # ... and the letters follow them
+        st1 = rng.bit_generator.state                  # (advance() drops a cached 32-bit half, which the doubles would have left alone)
+        st1["has_uint32"], st1["uinteger"] = st0["has_uint32"], st0["uinteger"]
+        rng.bit_generator.state = st1
+        for s in range(0, n_pairs, chunk):
+            e = min(n_pairs, s + chunk)
+            left = genome[pos[s:e, None] + ar[None, :]]
+            right = _COMP[genome[(pos[s:e] + frag[s:e] - read_len)[:, None] + ar[None, :]][:, ::-1]]
+            fwd = (strand[s:e, None] == 0) if mate == 0 else (strand[s:e, None] != 0)
+            r = np.where(fwd, left, right)
+            u = rng_u.random(size=(e - s, read_len))
+            alt = _ACGT[rng.integers(0, 4, size=(e - s, read_len), dtype=np.uint8)]
+            r = np.where(u < sub_rate, alt, r)
+            res[s:e] = np.where((u >= sub_rate) & (u < sub_rate + n_rate), np.uint8(ord("N")), r)
+        out.append(res)
     return out[0], out[1]
 
 

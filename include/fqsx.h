@@ -79,6 +79,13 @@ int fqsx_dna_decode_block(fqsx_dna *, const uint8_t *const *streams, const uint6
  * [16..63] in-kernel section timers / event counts (10 ns ticks, only in -DFQSX_TIMING diagnostic builds) */
 int fqsx_dna_stats(fqsx_dna *, uint64_t out[64]);
 
+/* Table occupancy and device memory (no counterpart in the reference, which prints table populations at -v 2,
+ * fqs/application.cpp:733-741): [0] distinct s-mers stored [1] distinct b-mers stored [2] s-mer table slots (all owners)
+ * [3] b-mer table slots [4] p-mer vector bytes [5] context-table slots (all workers) [6] contexts stored
+ * [7] device bytes held now [8] ... at most so far (old + new table during a growth included) [9] table growth events
+ * [10] minimizer pairs stored (paired-end) [11] pair-table slots [12] bytes per k-mer table slot. */
+int fqsx_dna_capacity(fqsx_dna *, uint64_t out[16]);
+
 /* Sharded mode (reference: the T x T mailboxes of fqs/application.h:56-59 and their owner-side
  * application, fqs/dna.cpp:825-847, :2393-2472): logical worker w -- coder state, RNG streams, local tables and the
  * sub-tables it owns -- lives on rank w % world; every rank keeps a replica of all sub-tables for the look-ups.
@@ -104,7 +111,9 @@ int fqsx_shard_finish_block(fqsx_dna *, const uint64_t *h_read_off, const uint8_
 int fqsx_dna_set_profiling(fqsx_dna *, int enable);
 int fqsx_dna_kernel_times(fqsx_dna *, double out[6]);
 /* Diagnostic builds (-DFQSX_TIMING) only: per-launch, per-worker clock stamps of the five roles of the encode kernel,
- * out[launch][worker][16]: 8 stamps in 10 ns ticks + 8 per-launch counters of the resolving wave; returns the number of launches copied (always 0 in the product build). */
+ * out[launch][worker][FQSX_TRACE_WORDS]: 8 stamps in 10 ns ticks + 24 per-launch counters / section times of the resolving wave; returns the
+ * number of launches copied (always 0 in the product build).  `out` must hold max_launches * T * FQSX_TRACE_WORDS words. */
+#define FQSX_TRACE_WORDS 32
 int fqsx_dna_trace(fqsx_dna *, uint64_t *out, uint32_t max_launches);
 
 /* Quality stream on the GPU: replaces CQualityCompressor::Init / Compress for all T

@@ -1,0 +1,128 @@
+"""Full-size runs against digests of the reference's own files (tools/make_golden.py c18 / c19).
+
+c18 = BASELINE configs[2] at its full size: 5 M pairs x 150 bp, fragments 300-600, G = 75 Mbp, `-p -om s -qm 8 -gs 75`
+      (default -im i), T = 8: meta, id, DNA and quality streams of every block, then the whole file's SHA-256.
+c19 = a configs[3]-shaped single-end file: 10 M x 150 bp, G = 300 Mbp, `-om s -gs 300` (k = 12/17/21/26; 4 GiB p-mer
+      vector, global tables of ~10^9 slots -- far beyond the 256 MB Infinity Cache), per-block DNA digests, plus an
+      encode -> decode round trip of the file's first blocks on the GPU and the table-capacity figures.
+The inputs are re-generated from their seeds (fqsqueezer_amd.synth); the sorted order comes from the GPU pre-pass.
+Set FQSX_FULLSIZE_BLOCKS=<n> to stop after n blocks (a quicker, weaker run)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, IM, QM
+from fqsqueezer_amd import hostpipe as hp
+
+pytestmark = pytest.mark.gpu
+LIMIT = int(os.environ.get("FQSX_FULLSIZE_BLOCKS", "0")) or None
+
+
+def _need(name):
+    path = os.path.join(GOLD, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} has not been generated (tools/make_golden.py)")
+    return json.load(open(path))
+
+
+def _se_records(d):
+    from fqsqueezer_amd.synth import read_id, synth_reads
+    n = d["reads"]
+    reads = synth_reads(n, d["len"], d["genome"], d["seed"])
+    return hp.Records([read_id(i) for i in range(n)], reads, reads)   # (qualities are not part of these fixtures)
+
+
+@pytest.fixture(scope="module")
+def c19_input():
+    from fqsqueezer_amd.codec import sort_order
+    d = _need("c19_10M150_gs300_s_t64.json") if os.path.exists(os.path.join(GOLD, "c19_10M150_gs300_s_t64.json")) else _need("c19_10M150_gs300_s_t8.json")
+    rec = _se_records(d)
+    n, L = rec.seq.shape
+    groups = sort_order(rec.seq.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    return rec, hp.form_blocks(rec, "se_sorted", groups=groups)
+
+
+def _run_c19(c19_input, name, roundtrip_blocks):
+    from fqsqueezer_amd.codec import DnaCodec
+    d = _need(name)
+    rec, blks = c19_input
+    header = bytes.fromhex(d["header"])
+    assert len(blks) == d["n_blocks"]
+    enc = DnaCodec(header, device=0)
+    dec = DnaCodec(header, device=0) if roundtrip_blocks else None
+    total = 0
+    for g, (idx, ref) in enumerate(zip(blks, d["blocks"])):
+        if LIMIT is not None and g >= LIMIT:
+            break
+        assert len(idx) == ref["n_reads"]
+        bases, off = hp.block_arrays(rec, idx)
+        streams = enc.encode_block(bases, off, g)
+        h = hashlib.sha256()
+        for s in streams:
+            h.update(s)
+        n_bytes = sum(len(s) for s in streams)
+        assert n_bytes == ref["bytes"] and h.hexdigest() == ref["sha256"], f"{name}: block {g} differs from the reference"
+        total += n_bytes
+        if dec is not None and g < roundtrip_blocks:
+            assert np.array_equal(dec.decode_block(streams, off, g), np.asarray(bases)), f"{name}: block {g} did not round-trip"
+        elif dec is not None:
+            dec.close()
+            dec = None
+    if LIMIT is None:
+        assert total == d["dna_bytes"]
+    cap = enc.capacity()
+    # the tables hold what was inserted: every distinct canonical k-mer once (genome both strands ~ 2 x 3e8 minus repeats, plus error k-mers)
+    assert cap["bmers"] > 2e8 and cap["smers"] > 2e8 and cap["bytes_per_bmer"] <= 48
+    print(f"{name}: {cap}")
+    return enc
+
+
+def test_c19_10M_reads_gs300_t64_matches_reference_and_round_trips(c19_input):
+    _run_c19(c19_input, "c19_10M150_gs300_s_t64.json", roundtrip_blocks=16)
+
+
+@pytest.mark.skipif(os.environ.get("FQSX_SLOW") != "1", reason="T = 8 puts eight workgroups on the chip: minutes; set FQSX_SLOW=1")
+def test_c19_10M_reads_gs300_t8_matches_reference(c19_input):
+    _run_c19(c19_input, "c19_10M150_gs300_s_t8.json", roundtrip_blocks=0)
+
+
+def test_c18_paired_end_5M_pairs_q8_matches_reference_file():
+    from fqsqueezer_amd.fqsfile import compress_records_pe
+    from fqsqueezer_amd.synth import read_id, synth_pairs, synth_quals
+    name = "c18_pe5M_s_q8_t8.json"
+    d = _need(name)
+    n, seed = d["pairs"], d["seed"]
+    r1, r2 = synth_pairs(n, d["len"], d["genome"], seed)
+    # (tools/make_golden.py c18 wrote the mates with write_fastq(seed) / write_fastq(seed + 1): qualities of those seeds)
+    rec1 = hp.Records([read_id(i, 1) for i in range(n)], r1, synth_quals(n, d["len"], seed))
+    rec2 = hp.Records([read_id(i, 2) for i in range(n)], r2, synth_quals(n, d["len"], seed + 1))
+    header, blocks = compress_records_pe(rec1, rec2, d["threads"], d["om"], d["gs"], quality_mode=QM[d["qm"]], id_mode=IM[d["im"]], as_blocks=True)
+    assert header.hex() == d["header"]
+    names = {hp.STREAM_META: "meta", hp.STREAM_ID: "id", hp.STREAM_DNA: "dna", hp.STREAM_QUALITY: "quality"}
+    sids = hp.stored_streams(header)
+    file_h, file_n, g = hashlib.sha256(), 0, 0
+    it = hp.fqs_chunks(header, _tee_blocks(blocks, d, sids, names, name))
+    for chunk in it:
+        file_h.update(chunk)
+        file_n += len(chunk)
+        g += 1
+        if LIMIT is not None and g > LIMIT:
+            return
+    assert g - 1 == d["n_blocks"]
+    assert file_n == d["file_bytes"] and file_h.hexdigest() == d["file_sha256"]
+
+
+def _tee_blocks(blocks, d, sids, names, name):
+    """checks every block's streams against the reference's digests on their way into the container"""
+    for g, b in enumerate(blocks):
+        ref = d["blocks"][g]
+        assert b.n_reads == ref["n_reads"]
+        for sid in sids:
+            h = hashlib.sha256()
+            for st in b.streams:
+                h.update(st[sid])
+            assert h.hexdigest() == ref[str(sid)], f"{name}: block {g}: {names[sid]} stream differs from the reference"
+        yield b

@@ -28,6 +28,10 @@ Fixtures (data only -- inputs are re-generated deterministically by fqsqueezer_a
                             (incl. the order of equal reads, which only the id stream sees) at 1 M reads
   c17_1M150_gs3100_s_t8.json  the c12 input at the DEFAULT geometry -gs 3100 (k = 13/18/21/27; BASELINE configs[3]'s geometry on a 1 M-read
                             prefix-sized file): DNA digests; the reference needs ~45 GiB and ~10 min (only with --only c17)
+  c18_pe5M_s_q8_t8.json     BASELINE configs[2] at FULL size: 5 M pairs x 150bp (fragments 300-600), G=75Mbp, seed 3, -p -om s -qm 8 -gs 75
+                            (default -im i), T=8: every stream of every block (only with --only c18; the reference needs ~30-60 min)
+  c19_10M150_gs300_s_t{8,64}.json  a configs[3]-shaped SE file: 10 M x 150bp, G=300Mbp, seed 19, -om s -gs 300 (k = 12/17/21/26; tables far
+                            beyond the Infinity Cache): DNA digests per block (only with --only c19 / c19t64; ~15 / ~45 GiB, 30-60 min)
 Usage: python tools/make_golden.py [--work /tmp/w] [--only c1|c2|c3]
 """
 import argparse, hashlib, json, os, subprocess, sys
@@ -210,6 +214,10 @@ def main():
         c16(a)
     if a.only == "c17":
         c17(a)
+    if a.only == "c18":
+        c18(a)
+    if a.only in ("c19", "c19t64"):
+        c19(a, 64 if a.only == "c19t64" else 8)
     if a.only in ("", "c3"):
         fq = os.path.join(a.work, "c3.fq")
         if not os.path.exists(fq):
@@ -303,6 +311,33 @@ def c17(a):
     run_ref(fq, out, "s", 8, 3100, a.work)
     meta = {"reads": 1000000, "len": 150, "genome": 7500000, "seed": 2, "gs": 3100, "om": "s", "threads": 8}
     json.dump(digest(out, meta), open(os.path.join(GOLD, "c17_1M150_gs3100_s_t8.json"), "w"))
+
+
+def c18(a):
+    from fqsqueezer_amd.synth import synth_pairs, synth_quals, read_id
+    npairs, G, seed = 5000000, 75000000, 3
+    f1, f2 = os.path.join(a.work, "c18_1.fq"), os.path.join(a.work, "c18_2.fq")
+    if not os.path.exists(f2):
+        r1, r2 = synth_pairs(npairs, 150, G, seed)
+        write_fastq(f1, r1, seed=seed, mate=1)
+        write_fastq(f2, r2, seed=seed + 1, mate=2)
+    out = os.path.join(a.work, "c18.fqs")
+    if not os.path.exists(out):
+        subprocess.check_call([REF, "e", "-p", "-om", "s", "-t", "8", "-gs", "75", "-qm", "8", "-v", "0",
+                               "-tmp", os.path.join(a.work, "tmp18_"), "-out", out, f1, f2], stdout=subprocess.DEVNULL)
+    meta = {"pairs": npairs, "len": 150, "genome": G, "seed": seed, "gs": 75, "om": "s", "qm": "8", "im": "i", "threads": 8,
+            "paired": True, "varied_ids": False}
+    json.dump(fdigest(out, meta), open(os.path.join(GOLD, "c18_pe5M_s_q8_t8.json"), "w"))
+
+
+def c19(a, t):
+    fq = os.path.join(a.work, "c19.fq")
+    if not os.path.exists(fq):
+        write_fastq(fq, synth_reads(10000000, 150, 300000000, 19), seed=19)
+    out = os.path.join(a.work, f"c19_s_t{t}.fqs")
+    run_ref(fq, out, "s", t, 300, a.work)
+    meta = {"reads": 10000000, "len": 150, "genome": 300000000, "seed": 19, "gs": 300, "om": "s", "threads": t}
+    json.dump(digest(out, meta), open(os.path.join(GOLD, f"c19_10M150_gs300_s_t{t}.json"), "w"))
 
 
 def ragged():
