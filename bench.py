@@ -86,9 +86,13 @@ def main() -> None:
     # ---- synthetic input, host preparation (not timed): binning + sort + block formation
     seed = 2 + rank
     reads = synth_reads(a.reads, a.len, a.genome, seed)
-    rec = hp.Records([read_id(i) for i in range(a.reads)], reads, synth_quals(a.reads, a.len, seed))
+    rec = hp.Records([read_id(i) for i in range(a.reads)], reads, reads if a.no_cpu_baseline else synth_quals(a.reads, a.len, seed))   # (qualities: only the reference CPU leg reads them)
     header = hp.make_header(a.threads, "se_sorted", a.gs)
-    blocks = hp.form_blocks(rec, "se_sorted")
+    groups = None
+    if a.reads > 2_000_000:   # large files: the sorted order from the GPU pre-pass (fqsx_sort_order) instead of numpy's lexsort
+        from fqsqueezer_amd.codec import sort_order
+        groups = sort_order(reads.reshape(-1), np.arange(a.reads + 1, dtype=np.uint64) * np.uint64(a.len), device=local_rank)
+    blocks = hp.form_blocks(rec, "se_sorted", groups=groups)
     dev_blocks = []
     for idx in blocks:
         bases, off = hp.block_arrays(rec, idx)
@@ -98,6 +102,7 @@ def main() -> None:
     n_bases = int(a.reads) * int(a.len)
     torch.cuda.synchronize()
 
+    capacity = {}     # table occupancy / device memory at the end of the most recent pass (fqsx_dna_capacity)
     block_done = []   # host clock after every block of the most recent pass (a block call returns when its streams are back)
 
     def one_step(profile: bool = False):
@@ -111,6 +116,8 @@ def main() -> None:
             out_bytes += codec.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g, collect=False)
             block_done.append(time.perf_counter())
         res = (out_bytes, codec.stats() if profile else None, codec.kernel_times() if profile else None)
+        capacity.clear()
+        capacity.update(codec.capacity())
         codec.close()
         return res
 
@@ -149,6 +156,8 @@ def main() -> None:
                   "blocks": f"100..{len(dev_blocks) - 1}", "warmup_blocks_value": round(sum(int(off[-1]) for (_, _, off) in dev_blocks[:70]) / (block_done[70] - block_done[0]) / 1e6, 4),
                   "note": "this rank, same timed pass: blocks >= 100 (one synchronisation segment per block) vs blocks 0..69 (30 segments per block, two reads per worker and segment)"}
 
+    cap_line = dict(capacity, note="k-mer tables at the end of the file: distinct s-/b-mers stored, slots allocated (8-byte slots, all owners), "
+                                   "device bytes held / peak (old + new table alive during a growth), growth events")
     # ---- kernel-level measurement pass (HIP events around every launch on the codec's stream; untimed)
     _, st, kt = one_step(profile=True)
     alg = algorithmic_bytes(st)
@@ -197,29 +206,44 @@ def main() -> None:
     conc = None
     if world == 1 and a.concurrent > 1:
         import threading
-        outs = [0] * a.concurrent
 
-        def run(k):
-            c = DnaCodec(header, device=local_rank)
-            nb = 0
-            for g, (d_b, d_o, off) in enumerate(dev_blocks):
-                nb += c.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g, collect=False)
-            outs[k] = nb
-            c.close()
+        def conc_pass(partitioned):
+            outs = [0] * a.concurrent
+            marks = [None] * a.concurrent
 
-        th = [threading.Thread(target=run, args=(k,)) for k in range(a.concurrent)]
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        conc = {"instances": a.concurrent, "value": round(a.concurrent * n_bases / dt / 1e6, 4), "unit": "Mbases/s",
-                "identical_output": len(set(outs)) == 1 and outs[0] == dna_bytes,
-                "note": "independent compressions of the workload file running concurrently on one GPU as threads of this process "
-                        "(aggregate rate; one file occupies T of the 256 CUs)"}
+            def run(k):
+                c = DnaCodec(header, device=local_rank, partition=(k, a.concurrent) if partitioned else None)
+                nb = 0
+                tm = [time.perf_counter()]
+                for g, (d_b, d_o, off) in enumerate(dev_blocks):
+                    nb += c.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g, collect=False)
+                    tm.append(time.perf_counter())
+                outs[k] = nb
+                marks[k] = tm
+                c.close()
+
+            th = [threading.Thread(target=run, args=(k,)) for k in range(a.concurrent)]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            r = {"value": round(a.concurrent * n_bases / dt / 1e6, 4), "identical_output": len(set(outs)) == 1 and outs[0] == dna_bytes}
+            if len(dev_blocks) > 110:   # aggregate rate while every instance is past its block 100
+                sb = sum(int(off[-1]) for (_, _, off) in dev_blocks[100:])
+                r["steady_state_value"] = round(sum(sb / (m[-1] - m[100]) for m in marks) / 1e6, 4)
+            return r
+
+        part, free = conc_pass(True), conc_pass(False)
+        conc = {"instances": a.concurrent, "value": part["value"], "unit": "Mbases/s", "identical_output": part["identical_output"] and free["identical_output"],
+                "steady_state_value": part.get("steady_state_value"), "speedup_over_one_file": round(part["value"] / value, 3),
+                "unpartitioned": free,
+                "note": "independent compressions of the workload file running concurrently on one GPU as threads of this process, each codec on "
+                        "its own partition of the compute units (fqsx_dna_create_on_partition: CU-masked stream; one file occupies T of the 256 CUs); "
+                        "`unpartitioned` = the same with plain streams (the files' kernels queue behind each other for CUs); aggregate rates"}
 
     # HBM traffic of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/traffic.json), if recorded
     traffic = None
@@ -252,7 +276,7 @@ def main() -> None:
         "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2+rank), -om s -gs {a.gs} -qm n -im n",
                    "workers_T": a.threads, "blocks": len(blocks), "per_gpu": "one independent file per GPU"},
         "bits_per_base": round(8.0 * dna_bytes / n_bases, 5), "steady_state": steady, "pcie_inclusive_mbases_s": pcie, "workers_255": t255, "concurrent_files": conc,
-        "other_rows": rows, "roofline": roofline, "cpu_baseline": cpu,
+        "capacity": cap_line, "other_rows": rows, "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
     if world > 1:

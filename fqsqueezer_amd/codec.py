@@ -35,6 +35,9 @@ def _load(path: str):
     lib = C.CDLL(path)
     lib.fqsx_dna_create.restype = C.c_int
     lib.fqsx_dna_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    if hasattr(lib, "fqsx_dna_create_on_partition"):   # (tools/ab_bench.py also loads builds that predate these entry points)
+        lib.fqsx_dna_create_on_partition.restype = C.c_int
+        lib.fqsx_dna_create_on_partition.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     lib.fqsx_dna_destroy.argtypes = [C.c_void_p]
     lib.fqsx_dna_encode_block.restype = C.c_int
     lib.fqsx_dna_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
@@ -46,8 +49,9 @@ def _load(path: str):
     lib.fqsx_dna_decode_block.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     lib.fqsx_dna_stats.restype = C.c_int
     lib.fqsx_dna_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-    lib.fqsx_dna_capacity.restype = C.c_int
-    lib.fqsx_dna_capacity.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    if hasattr(lib, "fqsx_dna_capacity"):
+        lib.fqsx_dna_capacity.restype = C.c_int
+        lib.fqsx_dna_capacity.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.fqsx_dna_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.fqsx_dna_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.fqsx_qual_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
@@ -79,13 +83,17 @@ def load_library(path: Optional[str] = None):
 class DnaCodec:
     """One .fqs file's DNA-stream encoder state on one GPU (fqsx_dna_*)."""
 
-    def __init__(self, header: bytes, device: int = 0, lib_path: Optional[str] = None):
+    def __init__(self, header: bytes, device: int = 0, lib_path: Optional[str] = None, partition: Optional[tuple] = None):
+        """partition = (k, n): confine the codec's kernels to the k-th of n equal sets of compute units (several files at once on one GPU)."""
         if len(header) != 17:
             raise ValueError("header must be the 17 .fqs parameter bytes")
         self._lib = load_library(lib_path)
         self.T = header[4]
         self._h = C.c_void_p()
-        rc = self._lib.fqsx_dna_create(bytes(header), device, C.byref(self._h))
+        if partition is None:
+            rc = self._lib.fqsx_dna_create(bytes(header), device, C.byref(self._h))
+        else:
+            rc = self._lib.fqsx_dna_create_on_partition(bytes(header), device, partition[0], partition[1], C.byref(self._h))
         if rc:
             raise FqsxError(f"fqsx_dna_create: {rc}: {self._lib.fqsx_last_error().decode()}")
         self._streams = (C.c_void_p * self.T)()

@@ -356,7 +356,7 @@ FQ_KERNEL void k_shard_apply(DevCfg cfg, u32 kind, const u64 *items, u32 n) {
       for (;;) {   // the field only grows
         if (((old >> sh) & 3) >= val) break;
         const u64 seen = atomic_cas64(wp, old, (old & ~(3ull << sh)) | (val << sh));
-        if (seen == old) break;
+        if (seen == old) { siv_idx_move(cfg, idx, (u32)((old >> sh) & 3), (u32)val); break; }
         old = seen;
       }
       continue;
@@ -1041,6 +1041,8 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   cfg.siv = (u64 *)p;
   if ((rc = dalloc(c, &p, 2 * sizeof(u64), true))) return rc;
   cfg.siv_stats = (u64 *)p;
+  if ((rc = dalloc(c, &p, ((1ull << (2 * cfg.pmer)) >> FQSX_SIV_BLK_LOG) * 4 * sizeof(u32), true))) return rc;   // count index: all fields zero
+  cfg.siv_idx = (u32 *)p;
   // owner-sharded global tables (application.cpp:87-88; counters defs.h:26-27)
   c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(1024, (1ull << 22) / T));
   if (const char *e = getenv("FQSX_GTAB_INIT")) c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(64, strtoull(e, nullptr, 10)));   // (tests: growth from tiny tables)
@@ -1167,7 +1169,10 @@ int create_impl(fqsx_dna *c, const u8 *h) {
 // ---------------------------------------------------------------------------------------
 extern "C" {
 
-int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) {
+int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) { return fqsx_dna_create_on_partition(h, device, 0, 1, out); }
+
+int fqsx_dna_create_on_partition(const uint8_t *h, int device, uint32_t part, uint32_t n_parts, fqsx_dna **out) {
+  if (n_parts == 0 || part >= n_parts) { g_err = "bad compute-unit partition"; return FQSX_E_ARG; }
   if (!h || !out || h[0] != 'K' || h[1] != 'C' || h[2] != 'S' || h[3] != 'D') {  // params.h:102-129
     g_err = "malformed .fqs parameter header";
     return FQSX_E_ARG;
@@ -1209,7 +1214,17 @@ int fqsx_dna_create(const uint8_t *h, int device, fqsx_dna **out) {
   c->cur_need_lb = c->cur_need_ls = c->cur_need_lpe = 0;
   c->cur_decode = false;
 #ifndef FQSX_EMU
-  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+  hipError_t se;
+  if (n_parts > 1) {   // a stream whose kernels only run on this partition's compute units
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_err = "hipGetDeviceProperties failed"; delete c; return FQSX_E_HIP; }
+    const u32 ncu = (u32)prop.multiProcessorCount, lo = (u32)((u64)part * ncu / n_parts), hi = (u32)(((u64)part + 1) * ncu / n_parts);
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (u32 i = lo; i < hi; ++i) mask[i / 32] |= 1u << (i % 32);
+    se = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data());
+  } else
+    se = hipStreamCreate(&c->stream);
+  if (se != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     g_err = "hipStreamCreate / hipEventCreate failed";
     delete c;
     return FQSX_E_HIP;

@@ -232,16 +232,17 @@ FQ_DEV void prefix_direct_dec(Wk &w, u8 *codes, u8 *p_out) {  // decompress_pref
   }
 }
 
-// index of the (dif+1)-th field equal to `flag` after position `lo` of the p-mer vector (dna.cpp:1432-1437)
-FQ_DEV u64 siv_select_equal(Wk &w, u64 lo, u64 dif, u64 flag) {
+// index of the (dif+1)-th field equal to `flag` after position `lo` of the p-mer vector (dna.cpp:1432-1437):
+// the words up to the end of lo's block are swept, whole blocks are then skipped through the count index
+// (DevCfg.siv_idx), and the block the answer lies in is swept again.
+// One sweep: words [wa, wb), fields below `start` masked out; `run` = matching fields seen so far.
+FQ_DEV bool siv_select_sweep(Wk &w, u64 wa, u64 wb, u64 start, u64 flag, u64 dif, u64 &run, u64 &ans) {
   const u64 *sv = w.cfg->siv;
   const u64 rep = flag * 0x5555555555555555ULL;
-  const u64 start = lo + 1, n_words = (1ull << (2 * w.cfg->pmer)) / 32;
-  u64 run = 0;
-  for (u64 base = start >> 5; base < n_words; base += FQ_WAVE) {
+  for (u64 base = wa; base < wb; base += FQ_WAVE) {
     const u64 x = base + FQ_LANE;
     u64 eq = 0;
-    if (x < n_words) {
+    if (x < wb) {
       u64 d = sv[x] ^ rep;
       eq = ~(d | (d >> 1)) & 0x5555555555555555ULL;
       if (x == (start >> 5)) eq &= ~0ull << (2 * (start & 31));
@@ -252,18 +253,56 @@ FQ_DEV u64 siv_select_equal(Wk &w, u64 lo, u64 dif, u64 flag) {
     if (run + tot > dif) {
       const u64 want = dif - run;  // rank inside this group of words
       const bool mine = want >= ex && want < (u64)ex + c;
-      u64 ans = 0;
+      u64 a = 0;
       if (mine) {
         u64 e = eq;
         for (u64 r = want - ex; r; --r) e &= e - 1;
-        ans = x * 32 + ctz64(e) / 2;
+        a = x * 32 + ctz64(e) / 2;
       }
 #if FQ_WAVE > 1
       const u64 bm = wave_ballot(mine);
-      return wave_bcast64(ans, ctz64(bm));
+      ans = wave_bcast64(a, ctz64(bm));
 #else
-      return ans;
+      ans = a;
 #endif
+      return true;
+    }
+    run += tot;
+  }
+  return false;
+}
+FQ_DEV u64 siv_select_equal(Wk &w, u64 lo, u64 dif, u64 flag) {
+  const u64 start = lo + 1, n_words = (1ull << (2 * w.cfg->pmer)) / 32, n_blocks = n_words >> (FQSX_SIV_BLK_LOG - 5);
+  const u32 wpb = FQSX_SIV_BLK / 32;   // words per block
+  u64 run = 0, ans = 0;
+  u64 b = start >> FQSX_SIV_BLK_LOG;
+  if (b >= n_blocks) { w.err = FQSX_ERR_DECODE; return 0; }
+  if (siv_select_sweep(w, start >> 5, (b + 1) * wpb, start, flag, dif, run, ans)) return ans;
+  // whole blocks, a wave's worth at a time
+  struct alignas(16) I4 { u32 c[4]; };
+  const I4 *ix = (const I4 *)w.cfg->siv_idx;
+  for (u64 base = b + 1; base < n_blocks; base += FQ_WAVE) {
+    const u64 x = base + FQ_LANE;
+    u32 c = 0;
+    if (x < n_blocks) {
+      const I4 v = ix[x];
+      c = flag ? (flag == 1 ? v.c[1] : flag == 2 ? v.c[2] : v.c[3]) : FQSX_SIV_BLK - v.c[1] - v.c[2] - v.c[3];
+    }
+    const u32 ex = wave_excl_scan32(c), tot = wave_sum32(c);
+    w.st[ST_SIV_WORDS] += 2 * FQ_WAVE;
+    if (run + tot > dif) {
+      const u64 want = dif - run;
+      const bool mine = want >= ex && want < (u64)ex + c;
+#if FQ_WAVE > 1
+      const u32 src = ctz64(wave_ballot(mine));
+      const u64 blk = wave_bcast64(x, src);
+      run += wave_bcast32(ex, src);
+#else
+      const u64 blk = x;
+      run += ex;
+#endif
+      if (siv_select_sweep(w, blk * wpb, (blk + 1) * wpb, 0, flag, dif, run, ans)) return ans;
+      break;   // (index and vector disagree: cannot happen)
     }
     run += tot;
   }

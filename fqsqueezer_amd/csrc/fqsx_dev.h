@@ -75,7 +75,7 @@ struct WgShared {
   HeadRec hd[2];
   u32 hd_ready, hd_taken;      // read heads finished / consumed (free-running counts within the launch)
   u32 hd_early;                // read heads whose part for the scout waves (codes, k-mers after the prefix) is in place
-  u32 mt[4][624];              // MT19937 states of cinc_b, cinc_s, cinc_lb, cinc_ls
+  alignas(8) u32 mt[4][624];   // MT19937 states of cinc_b, cinc_s, cinc_lb, cinc_ls
   u32 mt_idx[4];
   alignas(8) u8 rd[2][FQSX_RD_LDS];       // 2-bit codes (0..4) of the current read (two buffers: the head wave stages the next read)
   u64 bk_key[256];             // probe batch: normalised k-mers
@@ -175,7 +175,8 @@ typedef const EncArgs *FqArgsP;
 FQ_DEV WgShared *fq_wg() { static thread_local WgShared s; return &s; }
 FQ_DEV const EncArgs *fq_args(FqArgsP a) { return a; }
 #endif
-enum { SX_VALID = 1, SX_LB = 2, SX_S = 4, SX_LS = 8 };
+enum { SX_VALID = 1, SX_LB = 2, SX_S = 4, SX_LS = 8, SX_UNC = 16 /* the uncorrected b-mer is in the global table (counts in sx_s) */,
+       SX_HITS = SX_LB | SX_S | SX_LS | SX_UNC };
 enum { SCQ_FROM_HEAD = 1 /* base state = the read's head record */, SCQ_REVERSED = 2 /* positions count from the end (dna.cpp:750-752) */ };
 enum { SK_NONE = 0, SK_RANK = 1, SK_LETTER = 2, SK_RANK_PENDING = 3, SK_LETTER_PENDING = 4, SK_RAW = 5, SK_KIND_MASK = 7,
        SK_RESET = 8 /* the r_sym history restarts at this entry (first symbol of a compress_suffix call, dna.cpp:676) */ };
@@ -311,6 +312,19 @@ FQ_DEV void mt_twist(u32 *s) {
     if (i < 624) s[i] = v;
     FQ_SYNC();
   }
+}
+// the four 624-word states between HBM and LDS (launch prologue / epilogue): 1248 eight-byte words, every lane's loads
+// issued back to back before the first store (a lone wave: what counts is how many requests are in flight)
+FQ_DEV void mt_copy(u64 *dst, const u64 *src) {
+#if FQ_WAVE > 1
+  u64 v[20];
+#pragma unroll
+  for (u32 k = 0; k < 20; ++k) { const u32 i = k * FQ_WAVE + FQ_LANE; v[k] = i < 1248u ? src[i] : 0ull; }
+#pragma unroll
+  for (u32 k = 0; k < 20; ++k) { const u32 i = k * FQ_WAVE + FQ_LANE; if (i < 1248u) dst[i] = v[k]; }
+#else
+  for (u32 i = 0; i < 1248u; ++i) dst[i] = src[i];
+#endif
 }
 FQ_DEV u32 mt_temper(u32 y) {
   y ^= y >> 11;
@@ -816,8 +830,8 @@ FQ_DEV u64 siv_eq_count(u64 d, u64 rep) {
   d ^= rep;
   return popc64(~(d | (d >> 1)) & 0x5555555555555555ULL);
 }
-FQ_DEV u64 siv_count_equal(Wk &w, u64 lo, u64 hi, u64 flag) {
-  u64 start = lo + 1;
+// fields of [start, hi) equal to `flag`, by sweeping the words
+FQ_DEV u64 siv_count_sweep(Wk &w, u64 start, u64 hi, u64 flag) {
   if (start >= hi) return 0;
   const u64 *sv = w.cfg->siv;
   const u64 rep = flag * 0x5555555555555555ULL;
@@ -849,13 +863,41 @@ FQ_DEV u64 siv_count_equal(Wk &w, u64 lo, u64 hi, u64 flag) {
   x += 2 * pairs;
   if (x < end && FQ_LANE == 0) r += siv_eq_count(sv[x], rep);   // odd tail word
   r = wave_sum64(r);
-  // fields of the end words that lie outside (lo,hi)
+  // fields of the end words that lie outside [start, hi)
   u64 d0 = sv[w0] ^ rep, d1 = sv[w1] ^ rep;
   u64 e0 = ~(d0 | (d0 >> 1)) & 0x5555555555555555ULL, e1 = ~(d1 | (d1 >> 1)) & 0x5555555555555555ULL;
   if (w0 == w1) r -= popc64(e0 & ~(m0 & m1));
   else r -= popc64(e0 & ~m0) + popc64(e1 & ~m1);
   w.st[ST_SIV_WORDS] += w1 - w0 + 1;
   return r;
+}
+// fields equal to `flag` in the whole blocks [b0, b1) of the vector, from the count index (16 bytes per 4 KiB block)
+FQ_DEV u64 siv_count_blocks(Wk &w, u64 b0, u64 b1, u64 flag) {
+  if (b0 >= b1) return 0;
+  struct alignas(16) I4 { u32 c[4]; };
+  const I4 *ix = (const I4 *)w.cfg->siv_idx;
+  u64 r = 0;
+  u64 q = b0 + FQ_LANE;
+  for (; q + 3 * FQ_WAVE < b1; q += 4 * FQ_WAVE) {
+    I4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ix[q + k * FQ_WAVE];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r += flag ? (flag == 1 ? v[k].c[1] : flag == 2 ? v[k].c[2] : v[k].c[3]) : FQSX_SIV_BLK - v[k].c[1] - v[k].c[2] - v[k].c[3];
+  }
+  for (; q < b1; q += FQ_WAVE) {
+    const I4 v = ix[q];
+    r += flag ? (flag == 1 ? v.c[1] : flag == 2 ? v.c[2] : v.c[3]) : FQSX_SIV_BLK - v.c[1] - v.c[2] - v.c[3];
+  }
+  w.st[ST_SIV_WORDS] += 2 * (b1 - b0);
+  return wave_sum64(r);
+}
+FQ_DEV u64 siv_count_equal(Wk &w, u64 lo, u64 hi, u64 flag) {
+  const u64 start = lo + 1;
+  if (start >= hi) return 0;
+  const u64 b0 = (start + FQSX_SIV_BLK - 1) >> FQSX_SIV_BLK_LOG, b1 = hi >> FQSX_SIV_BLK_LOG;   // whole blocks inside [start, hi): b0 .. b1-1
+  if (b0 + 2 > b1) return siv_count_sweep(w, start, hi, flag);   // (a short range: the sweep alone)
+  return siv_count_sweep(w, start, b0 << FQSX_SIV_BLK_LOG, flag) + siv_count_blocks(w, b0, b1, flag) + siv_count_sweep(w, b1 << FQSX_SIV_BLK_LOG, hi, flag);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1630,7 +1672,7 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
   const u32 lane = FQ_LANE;
   const u64 lt = (1ull << lane) - 1ull;
   FQ_SYNC();
-  const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_LB | SX_S | SX_LS)) == SX_VALID;
+  const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_HITS)) == SX_VALID;
   u64 cm = wave_ballot(cand);
   u32 big = 0;
   const bool in = lane < n3;
@@ -1713,7 +1755,7 @@ FQ_DEV u32 scout_rough_first(Wk &w, u32 n) {
   const u32 lane = FQ_LANE;
   if (3 * (w.cfg->gb.k - 1) > 64) return FQSX_SPEC;
   FQ_SYNC();
-  const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_LB | SX_S | SX_LS)) == SX_VALID;
+  const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_HITS)) == SX_VALID;
   const u64 cm = wave_ballot(cand);
   return cm ? ctz64(cm) : FQSX_SPEC;
 }
@@ -2149,12 +2191,17 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
       // the rest of find_counts' cascade after a global b-mer miss (dna.cpp:478-499) -- local b, global s, local s
       // -- applies in the common case of a full s-mer and no pending correction; its probes are independent of
       // each other, so their first round trips are issued together with the b-mer's instead of one after another
-      const bool casc = bm.dir == bu.dir && sk.cur == cfg->gs.k;
+      // ... and, within a b-mer's length after a correction (corrected != uncorrected k-mers), with the look-up of the
+      // uncorrected b-mer that find_counts makes between the local b-mer table and the s-mer tables (dna.cpp:484-488)
+      const bool casc = sk.cur == cfg->gs.k;
+      const bool unc = bm.dir != bu.dir;
       const bool nds = km_norm_dir(sk, cfg->gs);
       const u64 ks = nds ? sk.dir : sk.rc;
+      const bool ndu = km_norm_dir(bu, cfg->gb);
+      const u64 ku = ndu ? bu.dir : bu.rc;
       const TabIt fb = tab_first(cfg->g_b, sb_owner(cfg, key), key);
-      TabIt flb = fb, fs = fb, fls = fb;
-      if (casc) {
+      TabIt flb = fb, fs = fb, fls = fb, fu = fb;
+      if (casc && !unc) {   // (after a correction the corrected b-mer mostly hits: those lanes start the cascade only on a miss)
         flb = tab_first(cfg->l_b, w.tid, key);
         fs = tab_first(cfg->g_s, sb_owner(cfg, ks), ks);
         fls = tab_first(cfg->l_s, w.tid, ks);
@@ -2184,6 +2231,12 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
         u32 xf = 0;
         if (casc) {
           xf = SX_VALID;
+          if (unc) {   // the four first round trips together, now that they are needed
+            flb = tab_first(cfg->l_b, w.tid, key);
+            fu = tab_first(cfg->g_b, sb_owner(cfg, ku), ku);
+            fs = tab_first(cfg->g_s, sb_owner(cfg, ks), ks);
+            fls = tab_first(cfg->l_s, w.tid, ks);
+          }
           C4 l;
           c4_zero(l);
           tab_rest(cfg->l_b, flb, key, nd, l, nls);
@@ -2191,6 +2244,9 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           if (c4_any(l)) {
             xf |= SX_LB;
             w.sb->sx_lb[j] = l.c[0] | (l.c[1] << 8) | (l.c[2] << 16) | (l.c[3] << 24);
+          } else if (unc && (tab_rest(cfg->g_b, fu, ku, ndu, l, ns), ++np, c4_any(l))) {
+            xf |= SX_UNC;
+            w.sb->sx_s[j] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
           } else {
             c4_zero(l);
             tab_rest(cfg->g_s, fs, ks, nds, l, ns);
@@ -2561,19 +2617,24 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len) {
     // position; ema_update with the level term precomputed by the position's lane); every lane keeps the average its
     // position started from, the starting-level test is then one lane-parallel comparison, and in the rare case it
     // fails somewhere the recurrence is simply run again up to that position.
+    // (the two averages are chains of their own: each walks the set bits of its positions' mask -- bit scan, two
+    // v_readlane, the two dependent fp64 operations and the capture of the value the position started from)
     for (int pass = 0; pass < 2; ++pass) {
       double before = 0.0;
       ac = w.avg_code; al = w.avg_letters;
-      for (t = 0; t < L; ++t) {
-        if ((KR >> t) & 1) continue;
-        const double pl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lane_pl), t), __builtin_amdgcn_readlane(__double2loint(lane_pl), t));
-        if ((KL >> t) & 1) {
-          before = FQ_LANE == t ? al : before;
-          al = __dadd_rn(__dmul_rn(0.999, al), pl);
-        } else {
-          before = FQ_LANE == t ? ac : before;
-          ac = __dadd_rn(__dmul_rn(0.999, ac), pl);
-        }
+      const u64 inl = L >= 64 ? ~0ull : (1ull << L) - 1ull;
+      const u32 my = FQ_LANE;
+      for (u64 m = ~KR & ~KL & inl; m; m &= m - 1) {
+        const u32 p = ctz64(m);
+        const double pl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lane_pl), p), __builtin_amdgcn_readlane(__double2loint(lane_pl), p));
+        before = my == p ? ac : before;
+        ac = __dadd_rn(__dmul_rn(0.999, ac), pl);
+      }
+      for (u64 m = ~KR & KL & inl; m; m &= m - 1) {
+        const u32 p = ctz64(m);
+        const double pl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lane_pl), p), __builtin_amdgcn_readlane(__double2loint(lane_pl), p));
+        before = my == p ? al : before;
+        al = __dadd_rn(__dmul_rn(0.999, al), pl);
       }
       if (pass) break;
       const u32 ln = FQ_LANE;
@@ -2746,7 +2807,7 @@ FQ_DEV u64 quiet_miss_mask(Wk &w, u32 n) {
   const DevCfg *cfg = w.cfg;
   const u32 lane = FQ_LANE;
   FQ_SYNC();
-  const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_LB | SX_S | SX_LS)) == SX_VALID;
+  const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_HITS)) == SX_VALID;
   const u64 A = wave_ballot(cand);
   if (popc64(A) < 8) return 0;   // not worth the set-up: the per-position path handles them
   const u32 lo_b = w.pq_lo[0], hi_b = w.mn[MAIL_B], lo_s = w.pq_lo[1], hi_s = w.mn[MAIL_S];
@@ -3031,7 +3092,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           smj.dir = w.sb->sp_sdir[1][j]; smj.rc = w.sb->sp_src[1][j]; smj.cur = w.sb->sp_scur[1][j];
           // (a position of the quiet-miss mask has no such entry in either group: quiet_miss_mask)
           bool conflict = ((Qm >> j) & 1) ? false : pend_conflict(w, 0, cfg->gb, bmj, q_done, j);
-          if (!conflict && !((Qm >> j) & 1) && !(xf & (SX_LB | SX_S))) conflict = pend_conflict(w, 1, cfg->gs, smj, q_done, j);
+          if (!conflict && !((Qm >> j) & 1) && !(xf & (SX_LB | SX_UNC | SX_S))) conflict = pend_conflict(w, 1, cfg->gs, smj, q_done, j);
           if (conflict) {
             // An entry still on its way into the local tables lies in the position's sibling group -- typically the
             // second of two overlapping reads of this worker.  The look-up that entry can change comes first in the
@@ -3052,6 +3113,20 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
               u32 pc = w.sb->sx_lb[j];
               counts.c[0] = pc & 0xff; counts.c[1] = (pc >> 8) & 0xff; counts.c[2] = (pc >> 16) & 0xff; counts.c[3] = pc >> 24;
               level = LV_BMER;
+            } else if (xf & SX_UNC) {
+              // the uncorrected b-mer is known where the corrected one is not: the correction is dropped (dna.cpp:697-705)
+              const u64 pc = w.sb->sx_s[j];
+              counts.c[0] = (u32)(pc & 0xffff); counts.c[1] = (u32)((pc >> 16) & 0xffff);
+              counts.c[2] = (u32)((pc >> 32) & 0xffff); counts.c[3] = (u32)(pc >> 48);
+              flush_pushes(w, q_done, j);
+              q_done = j;
+              load_state(w, j);
+              loaded = true;
+              nrun_here = w.N_run;
+              w.bm = w.bm_u; w.sm_ = w.sm_u; w.pm = w.pm_u;
+              w.cor_pos = 0;
+              level = LV_BMER;
+              dirty = true;
             } else if (xf & (SX_S | SX_LS)) {
               u64 pc = (xf & SX_S) ? w.sb->sx_s[j] : w.sb->sx_ls[j];
               counts.c[0] = (u32)(pc & 0xffff); counts.c[1] = (u32)((pc >> 16) & 0xffff);
@@ -3940,10 +4015,8 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   if (stop > last) stop = last;
   // load state
   FQ_SYNC();
-  for (u32 g = 0; g < 4; ++g) {
-    for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) sm->mt[g][i] = ws->mt[g][i];
-    if (FQ_LANE == 0) sm->mt_idx[g] = ws->mt_idx[g];
-  }
+  mt_copy((u64 *)&sm->mt[0][0], (const u64 *)&ws->mt[0][0]);
+  if (FQ_LANE < 4) sm->mt_idx[FQ_LANE] = ws->mt_idx[FQ_LANE];
   w.mn[0] = w.mn[1] = w.mn[2] = 0;
   {  // avg_filling_factor (bit_vec.h:204-210) only changes in insert phases (dna.cpp:2416-2418)
     u64 nu = cfg.siv_stats[0], nf = cfg.siv_stats[1];
@@ -4052,10 +4125,8 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
 #endif
   }
   FQ_SYNC();
-  for (u32 g = 0; g < 4; ++g) {
-    for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) ws->mt[g][i] = sm->mt[g][i];
-    ws->mt_idx[g] = sm->mt_idx[g];
-  }
+  mt_copy((u64 *)&ws->mt[0][0], (const u64 *)&sm->mt[0][0]);
+  if (FQ_LANE < 4) ws->mt_idx[FQ_LANE] = sm->mt_idx[FQ_LANE];
   for (u32 k = 0; k < 3; ++k) cfg.mail[k].n[tid] = w.mn[k];
   if (paired) cfg.pe_n[tid] = w.pe_n;
   if (w.err) *cfg.err = w.err;
@@ -4286,6 +4357,17 @@ FQ_DEV void part_scatter_body(const DevCfg &cfg, u32 kind, u32 blk, u32 *cursor 
   }
 }
 
+// the count index of the p-mer vector follows a field that went from value `from` to value `to` (DevCfg.siv_idx)
+FQ_DEV void siv_idx_move(const DevCfg &cfg, u64 idx, u32 from, u32 to) {
+  u32 *e = cfg.siv_idx + 4 * (idx >> FQSX_SIV_BLK_LOG);
+#ifndef FQSX_EMU
+  if (from) atomicSub(&e[from], 1u);
+  atomicAdd(&e[to], 1u);
+#else
+  if (from) e[from] -= 1;
+  e[to] += 1;
+#endif
+}
 // owner `tid` applies its group of mailbox `kind` (InsertKmersToHT, dna.cpp:2393-2472).  The three
 // mailboxes touch disjoint state (p-mer vector / ht_smer + cinc_s / ht_bmer + cinc_b), so they run as
 // three independent workgroups per owner.
@@ -4306,7 +4388,11 @@ FQ_DEV void insert_phase_body(const DevCfg &cfg, SM *sm, u32 tid, u32 kind) {
         u64 f = (old >> sh) & 3;
         if (f == 3) break;
         u64 seen = atomic_cas64(wp, old, old + (1ull << sh));
-        if (seen == old) { nf += f == 0; break; }
+        if (seen == old) {
+          nf += f == 0;
+          siv_idx_move(cfg, idx, (u32)f, (u32)f + 1);
+          break;
+        }
         old = seen;
       }
       ++nu;

@@ -9,12 +9,12 @@ template <int MODE> FQ_DEV void encode_pe_kernel_body(const EncArgs &a) {
   if (worker_elsewhere(a)) return;
   if (wg_handoff_init(a, false)) return;   // a device error stops the block's remaining launches (the host reads the word per phase)
   switch (FQ_WAVE_ID) {
-    case 1: role_scout_req<0, 2>(fq_kernarg()); break;
+    case 1: role_scout_req<2>(fq_kernarg(), 0u); break;
     case 2: role_resolve<MODE>(fq_kernarg()); break;
     case 3: role_models(fq_kernarg()); break;
     case 4: role_rc(fq_kernarg()); break;
     case 5: role_inserter(fq_kernarg()); break;
-    case 7: role_scout_req<1, 2>(fq_kernarg()); break;
+    case 7: role_scout_req<2>(fq_kernarg(), 1u); break;
     default: break;
   }
 }

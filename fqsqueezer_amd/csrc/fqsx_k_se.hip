@@ -15,13 +15,13 @@ FQ_KERNEL512 void k_encode_se_sorted(EncArgs a) {
   if (wg_handoff_init(a, true)) return;   // the block's queue has been stopped (fqsx_api.hip: phase_skip)
   switch (FQ_WAVE_ID) {
     case 0: role_head(fq_kernarg()); break;
-    case 1: role_scout<0>(fq_kernarg()); break;
+    case 1: role_scout(fq_kernarg(), 0u); break;
     case 2: role_resolve<1>(fq_kernarg()); break;
     case 3: role_models(fq_kernarg()); break;
     case 4: role_rc(fq_kernarg()); break;
     case 5: role_inserter(fq_kernarg()); break;
-    case 6: role_scout<2>(fq_kernarg()); break;
-    default: role_scout<1>(fq_kernarg()); break;
+    case 6: role_scout(fq_kernarg(), 2u); break;
+    default: role_scout(fq_kernarg(), 1u); break;
   }
 }
 FQ_KERNEL512 void k_encode_se_orig(EncArgs a) {
@@ -29,13 +29,13 @@ FQ_KERNEL512 void k_encode_se_orig(EncArgs a) {
   if (wg_handoff_init(a, true)) return;
   switch (FQ_WAVE_ID) {
     case 0: break;
-    case 1: role_scout_req<0, 3>(fq_kernarg()); break;
+    case 1: role_scout_req<3>(fq_kernarg(), 0u); break;
     case 2: role_resolve<0>(fq_kernarg()); break;
     case 3: role_models(fq_kernarg()); break;
     case 4: role_rc(fq_kernarg()); break;
     case 5: role_inserter(fq_kernarg()); break;
-    case 6: role_scout_req<2, 3>(fq_kernarg()); break;
-    default: role_scout_req<1, 3>(fq_kernarg()); break;
+    case 6: role_scout_req<3>(fq_kernarg(), 2u); break;
+    default: role_scout_req<3>(fq_kernarg(), 1u); break;
   }
 }
 int fqsx_launch_encode_se(hipStream_t s, const EncArgs &a) {

@@ -13,6 +13,8 @@
 #include "fqsx_plat.h"
 
 #define FQSX_MAX_T 255
+#define FQSX_SIV_BLK_LOG 14u     // fields per block of the p-mer vector's count index (16384 fields = 512 words = 4 KiB)
+#define FQSX_SIV_BLK (1u << FQSX_SIV_BLK_LOG)
 #define FQSX_NIL 0xffffffffu
 #define FQSX_RD_LDS 4096u        // reads up to this length are staged in LDS
 #define FQSX_SPEC 64u            // positions speculated per chunk (one per lane)
@@ -106,7 +108,7 @@ struct WState {
   u64 out_len;
   u64 dec_buffer, dec_pos;             // CRangeDecoder (sub_rc.h:154-157) when the codec decodes
   u32 mt_idx[4];                       // cinc_b, cinc_s, cinc_lb, cinc_ls (dna.h:113-116)
-  u32 mt[4][624];
+  alignas(8) u32 mt[4][624];
   u64 stat[64];                        // probe/byte accounting, see ST_*; [16..63] in-kernel section times (10 ns ticks; timing builds)
 };
 enum { RNG_B = 0, RNG_S = 1, RNG_LB = 2, RNG_LS = 3 };
@@ -154,6 +156,9 @@ struct DevCfg {
   u32 dbg;                     // FQSX_DBG_*: forces the fall-back branches of the eight-wave protocol (tests only; env FQSX_PROTO_DEBUG)
   u64 *siv;                    // 4^pmer 2-bit counters
   u64 *siv_stats;              // [0] no_updates [1] no_filled (bit_vec.h:25-26)
+  u32 *siv_idx;                // [4^pmer / FQSX_SIV_BLK][4]: per block of the vector, how many fields hold 1, 2, 3 ([0] unused: zeros are the rest).
+                               // The rank of compress_prefix_sorted (dna.cpp:600-605) is a count over a range of the vector; whole blocks of
+                               // the range come from here instead of being swept (kept up to date by the insert phase)
   KTab g_s, g_b;               // owner-sharded global tables (T sub-tables)
   KTab l_s, l_b;               // per-worker local tables (T sub-tables)
   CtxSlot *ctx;                // [T][ctx_cap]

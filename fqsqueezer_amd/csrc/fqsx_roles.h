@@ -25,13 +25,16 @@ FQ_ROLE void role_head(FqArgsP ap) {
   const EncArgs *a = fq_args(ap);
   head_segment_body(a->cfg, fq_wg(), FQ_BLOCK, a->n_reads, a->S, a->seg, a->pad);
 }
-template <int ME> FQ_ROLE void role_scout(FqArgsP ap) {   // single-end sorted: the scouts walk the reads behind the read-head wave
+// The scout waves share ONE copy of their code (`me` is a run-time argument, made wave-uniform again inside): three
+// instantiations were 3 x 38 KB of the kernel's ~390 KB of role code competing for the 64 KB instruction cache a CU
+// pair shares, and three waves running the same lines fetch them once.
+FQ_ROLE void role_scout(FqArgsP ap, u32 me_) {   // single-end sorted: the scouts walk the reads behind the read-head wave
   const EncArgs *a = fq_args(ap);
-  scout_segment_body(a->cfg, fq_wg(), FQ_BLOCK, a->n_reads, a->S, a->seg, (u32)ME, a->pad);
+  scout_segment_body(a->cfg, fq_wg(), FQ_BLOCK, a->n_reads, a->S, a->seg, uniform32(me_), a->pad);
 }
-template <int ME, int NSC> FQ_ROLE void role_scout_req(FqArgsP ap) {   // the other modes: one request per compress_suffix call
+template <int NSC> FQ_ROLE void role_scout_req(FqArgsP ap, u32 me_) {   // the other modes: one request per compress_suffix call
   const EncArgs *a = fq_args(ap);
-  scout_request_body(a->cfg, fq_wg(), FQ_BLOCK, (u32)ME, (u32)NSC, a->pad);
+  scout_request_body(a->cfg, fq_wg(), FQ_BLOCK, uniform32(me_), (u32)NSC, a->pad);
 }
 
 #ifndef FQSX_EMU

@@ -47,6 +47,11 @@ enum {
  * paired modes a block holds the mates interleaved (mate 1, mate 2, mate 1, ...) and n_reads is even.
  * device: HIP device ordinal. */
 int fqsx_dna_create(const uint8_t *header17, int device, fqsx_dna **out);
+/* The same with the codec's kernels confined to compute units [part * CUs / n_parts, (part + 1) * CUs / n_parts) of the
+ * device (a HIP stream with a CU mask).  One file with T <= 64 workers occupies T of the 256 CUs (a worker's workgroup
+ * takes a whole CU's LDS), so a GPU has room for several files; giving every concurrent file a partition of its own keeps
+ * their kernels from queueing behind each other for compute units.  n_parts = 1: the whole device (= fqsx_dna_create). */
+int fqsx_dna_create_on_partition(const uint8_t *header17, int device, uint32_t part, uint32_t n_parts, fqsx_dna **out);
 void fqsx_dna_destroy(fqsx_dna *);
 
 /* Encode one reads block.  bases = concatenated ASCII sequences (ACGTN) of the block's
