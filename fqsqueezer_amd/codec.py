@@ -287,6 +287,16 @@ class QualCodec:
             raise FqsxError(f"fqsx_qual_encode_block_dev: {rc}: {self._lib.fqsx_last_error().decode()}")
         return sum(self._lens[w] for w in range(self.T))
 
+    def set_profiling(self, on: bool) -> None:
+        self._lib.fqsx_qual_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        self._lib.fqsx_qual_set_profiling(self._h, int(on))
+
+    def kernel_times(self) -> dict:
+        a = (C.c_double * 2)()
+        self._lib.fqsx_qual_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._lib.fqsx_qual_kernel_times(self._h, a)
+        return {"encode_ms": a[0], "encode_launches": int(a[1])}
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._lib.fqsx_qual_destroy(self._h)

@@ -1593,6 +1593,19 @@ struct fqsx_qual {
 
 extern "C" {
 
+// Kernel timing of the quality coder: HIP events around every k_qual_encode launch on the codec's stream (as
+// fqsx_dna_set_profiling / fqsx_dna_kernel_times); out[0] = accumulated milliseconds, out[1] = launches
+int fqsx_qual_set_profiling(fqsx_qual *q, int enable) {
+  if (!q) return FQSX_E_ARG;
+  q->mem.profiling = enable != 0;
+  return FQSX_OK;
+}
+int fqsx_qual_kernel_times(fqsx_qual *q, double out[2]) {
+  if (!q || !out) return FQSX_E_ARG;
+  out[0] = q->mem.k_ms[0];
+  out[1] = (double)q->mem.k_n[0];
+  return FQSX_OK;
+}
 void fqsx_qual_destroy(fqsx_qual *q) {
   if (!q) return;
   fqsx_dna *c = &q->mem;

@@ -988,7 +988,9 @@ FQ_DEV void rc_encode_m(Wk &w, u32 freq, u32 cum, u32 tot, u64 m) {
 #else
   u64 range = (u64)(((unsigned __int128)w.enc.range * m) >> 64);
 #endif
-  if (w.enc.range - range * tot >= tot) ++range;
+  // mulhi gives the quotient or one less, so the remainder is below 2 * tot < 2^17: its low 32 bits decide (one
+  // multiply, one subtract, one compare on the scalar unit instead of a 64-bit multiply-subtract-compare)
+  if ((u32)w.enc.range - (u32)range * tot >= tot) ++range;
   low += range * cum;
   range *= freq;
   while (range <= Top) {
@@ -1668,33 +1670,47 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
   SpecBuf *sb = w.sb;
   const KGeom &g = cfg->gb;
   const u32 n3 = 3 * (g.k - 1);
-  if (n3 > 64) return;
+  if (n3 > 2 * FQ_WAVE) return;
+  // b-mers of up to 22 symbols: one probe of a sweep per lane, FQSX_SW sweeps in flight.  Longer b-mers (the large-genome
+  // geometries: k = 24 .. 27, 69 .. 78 probes): two probes per lane -- the sweep takes two of the FQSX_SW probe groups in
+  // flight -- and only the compact forms (at most 3 hits), which is what a sweep in covered sequence looks like; a fuller
+  // sweep is left to the resolving wave.
+  const u32 halves = n3 > FQ_WAVE ? 2u : 1u, per_round = FQSX_SW / halves;
   const u32 lane = FQ_LANE;
   const u64 lt = (1ull << lane) - 1ull;
   FQ_SYNC();
   const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_HITS)) == SX_VALID;
   u64 cm = wave_ballot(cand);
   u32 big = 0;
-  const bool in = lane < n3;
-  const u32 pi = lane / 3, r3 = lane - 3 * pi;
-  const u32 shd = 62 - 2 * pi, shr = 64 - 2 * g.k + 2 * pi;
   while (cm) {
     if (lds_load_acq(&w.sm->sc_req_seq) != w.sc_epoch) break;   // nobody will look at this chunk any more
+    // up to per_round candidate positions; probe group q belongs to sweep q / halves (all indices compile-time constants)
+    u32 cj[FQSX_SW];
+    bool co[FQSX_SW];
+#pragma unroll
+    for (int x = 0; x < (int)FQSX_SW; ++x) {
+      co[x] = (u32)x < per_round && cm != 0;
+      cj[x] = co[x] ? ctz64(cm) : 0u;
+      if (co[x]) cm &= cm - 1;
+    }
     u32 js[FQSX_SW];
     bool ok[FQSX_SW];
 #pragma unroll
     for (int q = 0; q < (int)FQSX_SW; ++q) {
-      ok[q] = cm != 0;
-      js[q] = ok[q] ? ctz64(cm) : 0u;
-      cm &= cm - 1;
+      ok[q] = halves == 2 ? co[q >> 1] : co[q];
+      js[q] = halves == 2 ? cj[q >> 1] : cj[q];
     }
     TabIt f[FQSX_SW];
     u64 key[FQSX_SW];
-    bool nd[FQSX_SW];
+    bool nd[FQSX_SW], in[FQSX_SW];
 #pragma unroll
     for (int q = 0; q < (int)FQSX_SW; ++q) {
       key[q] = 0; nd[q] = false; f[q].s = nullptr; f[q].p = 0; f[q].it0 = 0; f[q].it1 = 0;
-      if (ok[q] && in) {
+      const u32 pr = ((u32)q & (halves - 1u)) * FQ_WAVE + lane;   // this lane's probe of the group
+      in[q] = ok[q] && pr < n3;
+      if (in[q]) {
+        const u32 pi = pr / 3, r3 = pr - 3 * pi;
+        const u32 shd = 62 - 2 * pi, shr = 64 - 2 * g.k + 2 * pi;
         const u64 cdir = sb->sp_sdir[2][js[q]], crc = sb->sp_src[2][js[q]];
         const u32 orig = (u32)((cdir >> shd) & 3ull);
         const u64 sy = r3 + (r3 >= orig ? 1u : 0u);
@@ -1705,21 +1721,36 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
         f[q] = tab_first(cfg->g_b, sb_owner(cfg, key[q]), key[q]);
       }
     }
+    u64 res[FQSX_SW], hmv[FQSX_SW];
+    u32 nsv[FQSX_SW];
 #pragma unroll
     for (int q = 0; q < (int)FQSX_SW; ++q) {
+      res[q] = 0; hmv[q] = 0; nsv[q] = 0;
       if (!ok[q]) continue;   // (uniform)
-      u64 ns = 0, res = 0;
-      if (in) {
+      u64 ns = 0;
+      if (in[q]) {
         C4 c;
         c4_zero(c);
         tab_rest(cfg->g_b, f[q], key[q], nd[q], c, ns);
-        res = (u64)c.c[0] | ((u64)c.c[1] << 16) | ((u64)c.c[2] << 32) | ((u64)c.c[3] << 48);
+        res[q] = (u64)c.c[0] | ((u64)c.c[1] << 16) | ((u64)c.c[2] << 32) | ((u64)c.c[3] << 48);
       }
-      const u64 hm = wave_ballot(res != 0);
-      const u32 nsum = wave_sum32((u32)ns);
-      const u32 nh = popc64(hm), j = js[q];
+      hmv[q] = wave_ballot(res[q] != 0);
+      nsv[q] = wave_sum32((u32)ns);
+    }
+#pragma unroll
+    for (int s = 0; s < (int)FQSX_SW; ++s) {
+      if (!co[s]) continue;   // (uniform)
+      constexpr int kSW = (int)FQSX_SW;
+      const int qa = 2 * s < kSW ? 2 * s : 0, qb = 2 * s + 1 < kSW ? 2 * s + 1 : 0;   // the sweep's groups when it takes two
+      const u32 j = cj[s];
+      const u64 hm0 = halves == 2 ? hmv[qa] : hmv[s], hm1 = halves == 2 ? hmv[qb] : 0ull;
+      const u64 r0 = halves == 2 ? res[qa] : res[s], r1 = halves == 2 ? res[qb] : 0ull;
+      const u32 nh0 = popc64(hm0), nh = nh0 + popc64(hm1);
+      const u32 nsum = halves == 2 ? nsv[qa] + nsv[qb] : nsv[s];
       if (nh <= 3) {
-        if (res != 0) sb->rc_val[j][popc64(hm & lt)] = res;
+        // the hits' counts in probe order (the first half's probes come first)
+        if (r0 != 0) sb->rc_val[j][popc64(hm0 & lt)] = r0;
+        if (r1 != 0) sb->rc_val[j][nh0 + popc64(hm1 & lt)] = r1;
         u32 form = 0xfe;
         if (nh) {
           // Merging the hits' counts (Increment(a, b), utils.h:327-333) is plain addition, and draws nothing, as long as
@@ -1735,10 +1766,11 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
             if (lane == 0) sb->rc_val[j][0] = sum;
           }
         }
-        if (lane == 0) { sb->rc_hit[j] = hm; sb->rc_ns[j] = nsum; sb->rr_idx[j] = (u8)form; }
-      } else if (big < FQSX_RR) {
-        if (in) sb->rr_res[big][lane] = res;
-        if (lane == 0) { sb->rr_hit[big] = hm; sb->rr_ns[big] = nsum; sb->rr_idx[j] = (u8)big; }
+        // (rc_hit is only ever counted: one bit per hit)
+        if (lane == 0) { sb->rc_hit[j] = halves == 2 ? (1ull << nh) - 1ull : hm0; sb->rc_ns[j] = nsum; sb->rr_idx[j] = (u8)form; }
+      } else if (halves == 1 && big < FQSX_RR) {
+        if (lane < n3) sb->rr_res[big][lane] = r0;
+        if (lane == 0) { sb->rr_hit[big] = hm0; sb->rr_ns[big] = nsum; sb->rr_idx[j] = (u8)big; }
         ++big;
       }
     }
@@ -1753,7 +1785,7 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
 FQ_DEV u32 scout_rough_first(Wk &w, u32 n) {
   SpecBuf *sb = w.sb;
   const u32 lane = FQ_LANE;
-  if (3 * (w.cfg->gb.k - 1) > 64) return FQSX_SPEC;
+  if (3 * (w.cfg->gb.k - 1) > 2 * FQ_WAVE) return FQSX_SPEC;
   FQ_SYNC();
   const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_HITS)) == SX_VALID;
   const u64 cm = wave_ballot(cand);
@@ -2401,11 +2433,11 @@ FQ_DEV RoHit ctx_probe_ro(Wk &w, u32 tag, u64 key, u32 &vis) {
   return r;
 }
 // level keys (and the rank) of the positions stage C resolved itself: rank-coded from counts, or plain letters
-FQ_DEV void code_keys(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reversed, u32 hist_start) {
+FQ_DEV void code_keys(Wk &w, const u8 *p, u32 size, u32 i0, u32 j0, u32 m, bool reversed, u32 hist_start) {
   WgShared *sm = w.sm;
   const DevCfg *cfg = w.cfg;
   FQ_SYNC();
-  for (u32 j = FQ_LANE; j < m; j += FQ_WAVE) {
+  for (u32 j = j0 + FQ_LANE; j < m; j += FQ_WAVE) {
     const u32 kind = w.sb->sp_kind[j], pos = i0 + j, sym = rd_sym(w, p, pos, size);
     if (kind == SK_RANK_PENDING) {
       const u64 cq = w.sb->sp_cq[j];
@@ -2754,26 +2786,26 @@ FQ_DEV u32 cq_process(Wk &w, u32 head, u32 avail) {
   }
   return L;
 }
-// all committed positions [0, m) of the chunk go to the coding queue; the single-wave build codes them right away
-FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 m, bool reversed, u32 hist_start, bool &first) {
-  if (m == 0) return;
+// the committed positions [j0, m) of the chunk go to the coding queue; the single-wave build codes them right away
+FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 j0, u32 m, bool reversed, u32 hist_start, bool &first) {
+  if (m <= j0) return;
   TM_BEGIN(t_c2);
   WgShared *sm = w.sm;
-  code_keys(w, p, size, i0, m, reversed, hist_start);
+  code_keys(w, p, size, i0, j0, m, reversed, hist_start);
   TM_END(w, TM_KEYS, t_c2);
   TM_BEGIN(t_cq);
-  if (!cq_wait_space(w, m)) return;
-  for (u32 j = FQ_LANE; j < m; j += FQ_WAVE) {
-    const u32 e = (w.cq_tail + j) & (FQSX_CQ - 1);
+  if (!cq_wait_space(w, m - j0)) return;
+  for (u32 j = j0 + FQ_LANE; j < m; j += FQ_WAVE) {
+    const u32 e = (w.cq_tail + (j - j0)) & (FQSX_CQ - 1);
     const u32 kind = w.sb->sp_kind[j];
     const u32 nk = kind == SK_LETTER ? 10u : 7u;
     for (u32 l = 0; l < nk; ++l) sm->cq_key[e][l] = w.sb->sp_key[j][l];
-    sm->cq_kind[e] = (u8)(kind | (first && j == 0 ? SK_RESET : 0u));
+    sm->cq_kind[e] = (u8)(kind | (first && j == j0 ? SK_RESET : 0u));
     sm->cq_rsym[e] = w.sb->sp_rsym[j];
   }
   FQ_SYNC();
   first = false;
-  cq_publish(w, m);
+  cq_publish(w, m - j0);
   TM_END(w, TX_CHUNKQ, t_cq);
   if (!w.piped) {
     while (w.cq_head != w.cq_tail && !w.err) w.cq_head += cq_process(w, w.cq_head, w.cq_tail - w.cq_head);
@@ -2914,18 +2946,24 @@ FQ_DEV void scout_unhold(Wk &w) {   // the chunk held across an early restart is
   FQ_SYNC();
   lds_store_rel(&w.sm->sc_taken, w.sc_taken);
 }
-FQ_DEV bool scout_take(Wk &w, u32 i, u32 n) {
+// The scouts' chunk that covers position `at` of the current read / request becomes w.sb; chunks that lie wholly before
+// it (inside a window the resolving wave has just covered itself) are released on the way.  False: go on without them.
+FQ_DEV bool scout_seek(Wk &w, u32 at) {
   WgShared *sm = w.sm;
-  SpecBuf *b = &sm->sb[1 + (w.sc_base + w.sc_taken) % w.nsc];
-  u32 spins = 0;
-  // the chunk with this number of this epoch (a slot may still hold the one of an earlier epoch with the same number)
-  while (lds_load_acq(&b->h_pub) != w.sc_taken + 1 || b->h_epoch != w.sc_epoch) {
-    fq_sleep();
-    if (lds_load_acq(&sm->sc_dead) || spin_expired(spins)) { w.sc_abandoned = true; return false; }   // never spin forever on the GPU
+  for (;;) {
+    SpecBuf *b = &sm->sb[1 + (w.sc_base + w.sc_taken) % w.nsc];
+    u32 spins = 0;
+    // the chunk with this number of this epoch (a slot may still hold the one of an earlier epoch with the same number)
+    while (lds_load_acq(&b->h_pub) != w.sc_taken + 1 || b->h_epoch != w.sc_epoch) {
+      fq_sleep();
+      if (lds_load_acq(&sm->sc_dead) || spin_expired(spins)) { w.sc_abandoned = true; return false; }   // never spin forever on the GPU
+    }
+    const i32 older = (i32)(b->h_read - w.sc_read);
+    if (older < 0) { scout_release(w); continue; }   // a chunk of an earlier read that ended inside a window
+    if (older > 0 || at < b->h_i0) { w.sc_abandoned = true; return false; }   // (cannot happen: the waves enumerate the chunks alike)
+    if (at < b->h_i0 + b->h_n) { w.sb = b; return true; }
+    scout_release(w);
   }
-  if (b->h_read == w.sc_read && b->h_i0 == i && b->h_n == n) { w.sb = b; return true; }
-  w.sc_abandoned = true;   // (cannot happen: the waves enumerate the chunks alike)
-  return false;
 }
 
 // compress_suffix, dna.cpp:674-877, as chunks of stage P (parallel) -> stage C (the serial loop below:
@@ -2945,18 +2983,38 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
   }
   const u32 dbg = cfg->dbg;
   if ((dbg & FQSX_DBG_ABANDON) && w.scout && w.sc_read % 3 == 1) w.sc_abandoned = true;   // (test switch) this read without the scouts
-  const u32 i_first = i;
-  while (i < size && !w.err) {
-    const u32 n = chunk_len(size - i);
+  // A k-mer correction at position q (repair_kmers_*, or the adoption of the uncorrected k-mers) changes what stage P
+  // would have found only where a corrected k-mer still holds a corrected symbol or the distance to the correction
+  // enters a context key: positions q + 1 .. q + bmer - 1.  Beyond that window the scouts' chunks -- rolled from the
+  // state the read (or the request) started from -- stand as they are.  So the scouts never hear of a correction: the
+  // resolving wave runs stage P itself for the window (`own_end`: positions below it are its own) and then goes on in
+  // the scouts' chunk that covers the next position, from whatever lane that is.
+  u32 at = i;               // next position to resolve
+  u32 own_end = 0;          // positions below this one are speculated by this wave itself
+  const u32 at_first = at;
+  const SpecBuf *counted = nullptr;   // ring chunk whose probes have been accounted (a chunk can be entered more than once)
+  u32 counted_pub = 0;
+  while (at < size && !w.err) {
     TM_BEGIN(t_sp);
-    if ((dbg & FQSX_DBG_ABANDON) && w.scout && w.sc_read % 3 == 2 && i != i_first) w.sc_abandoned = true;   // ... this one after its first chunk
+    if ((dbg & FQSX_DBG_ABANDON) && w.scout && w.sc_read % 3 == 2 && at != at_first) w.sc_abandoned = true;   // ... this one after its first chunk
     bool pre = false;
-    if (w.scout && !w.sc_abandoned) pre = scout_take(w, i, n);   // stage P done ahead of time by the scout wave
-    if (!pre) {
+    u32 n, j0 = 0;
+    if (at >= own_end && w.scout && !w.sc_abandoned) pre = scout_seek(w, at);   // stage P done ahead of time by a scout wave
+    if (pre) {
+      i = w.sb->h_i0; n = w.sb->h_n; j0 = at - i;
+      w.pq_lo[0] = w.sb->h_pq_lo[0];
+      w.pq_lo[1] = w.sb->h_pq_lo[1];
+      if (counted != w.sb || counted_pub != w.sb->h_pub) { counted = w.sb; counted_pub = w.sb->h_pub; spec_adopt(w); }
+    } else {
+      i = at;
+      n = chunk_len(size - at);
+      if (w.scout && !w.sc_abandoned && at < own_end && own_end - at < n) n = own_end - at;   // (just the window: a scout's chunk takes over behind it)
       w.sb = &sm->sb[0];
+      TM_BEGIN(t_own);
       speculate(w, p, size, i, n, reversed);
+      TM_END(w, TX_OWNSPEC, t_own);
+      spec_adopt(w);
     }
-    spec_adopt(w);
     TM_END(w, TM_SPEC, t_sp);
     TM_COUNT(w, CN_CHUNK);
     u64 Fm = 0, Rm = 0;   // positions settled by stage P; settled positions whose repair fires
@@ -2972,11 +3030,11 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
 #if FQ_WAVE > 1
     { TM_BEGIN(t_qm); if (pre && !w.repm_gate) Qm = quiet_miss_mask(w, n); TM_END(w, TX_QMM, t_qm); }   // (with the gate open repair_kmers_missing may fire: per-position path)
 #endif
-    u32 q_done = 0;   // chunk positions whose mailbox entries are already in the lists
-    u32 w_pos = 0;    // w's k-mers = state before position w_pos of the chunk
-    u32 m = 0;        // committed positions
-    bool dirty = false;  // corrected k-mers were modified: the rest of the chunk's speculation is stale
-    for (u32 j = 0; j < n && !dirty && !w.err; ++j) {
+    u32 q_done = j0;  // chunk positions whose mailbox entries are already in the lists
+    u32 w_pos = j0;   // w's k-mers = state before position w_pos of the chunk
+    u32 m = j0;       // committed positions (lanes [j0, m) of the chunk)
+    bool dirty = false;  // corrected k-mers were modified: the speculation of the next bmer - 1 positions is stale
+    for (u32 j = j0; j < n && !dirty && !w.err; ++j) {
       const u32 pos = i + j;
       const u32 sym = rd_sym(w, p, pos, size);
       const u64 sym_k = sym == 4 ? 0 : sym;
@@ -3156,7 +3214,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         if (!resolved) {
           TM_COUNT(w, CN_GENERIC);
 #ifdef FQSX_TIMING
-          if (w.sb->sp_scur[2][j] != cfg->gb.k) w.tm[TX_G_EARLY] += 1; else if (flag == 3) w.tm[TX_G_F3] += 1;
+          if (w.sb->sp_scur[2][j] != cfg->gb.k) w.tm[TX_G_EARLY] += 1;
 #endif
           // complete reference logic on the exact k-mers of this position
           flush_pushes(w, q_done, j);
@@ -3274,16 +3332,8 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       m = j + 1;
     }
     if (dirty) TM_COUNT(w, CN_DIRTY);
-    // The scout's chunks of this read were rolled from k-mers that have just been corrected: it starts again from here.
-    // The state it needs is final (every path that sets `dirty` leaves w's k-mers after position m - 1), so the request
-    // goes out before the rest of this chunk's work -- flush, keys, queue -- which still reads the chunk (hold).
-    bool reposted = false;
-    if (dirty && w.scout && !w.sc_abandoned && i + m < size) {
-      scout_restart(w, w.sc_read, i + m, w.s_let, 0, pre);
-      reposted = true;
-    }
     { TM_BEGIN(t_fl); flush_pushes(w, q_done, m); TM_END(w, TX_FLUSH, t_fl); }
-    code_chunk(w, p, size, i, m, reversed, hist_start, first);
+    code_chunk(w, p, size, i, j0, m, reversed, hist_start, first);
     lq_publish(w);   // (after the queue hand-off, whose release has already drained the list stores)
     if (w_pos != m) {  // the last committed position went through the fast path: materialise its state
       const u32 sym = rd_sym(w, p, i + m - 1, size);
@@ -3291,14 +3341,9 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       replace_last_all(w, sym == 4 ? 0 : sym);
       w.N_run = sym == 4 ? w.N_run + 1 : 0;
     }
-    bool forced = false;
-    if (!reposted && (dbg & FQSX_DBG_RESTART) && w.scout && !w.sc_abandoned && i + m < size) {   // (test switch) a restart from the exact state after every chunk
-      scout_restart(w, w.sc_read, i + m, w.s_let, 0, false);
-      forced = true;
-    }
-    if (reposted) { if (pre) scout_unhold(w); }   // (a new epoch: nothing else to release)
-    else if (pre && !forced) scout_release(w);
-    i += m;
+    at = i + m;
+    if (dirty || (dbg & FQSX_DBG_RESTART)) own_end = at + cfg->bmer - 1;   // (test switch: the window after every chunk, corrected or not)
+    if (pre && m == n) scout_release(w);   // (a chunk left in its middle stays the head of the ring: the position after the window may lie in it)
   }
 }
 
@@ -4111,7 +4156,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   TM_TRACE_VAL(cfg, tid, launch, 14, w.tm[CN_GENERIC]); TM_TRACE_VAL(cfg, tid, launch, 15, w.tm[TM_LQ]);
 #ifdef FQSX_TIMING
   {
-    const u32 xs[16] = {TM_SLOW, TM_SPRE, TM_ROUGH, TM_FINDC, TM_POST, TM_KEYS, TM_READ_HEAD, TM_CQWAIT, TX_QMM, TX_QRUN, TX_PROLOG, TX_CHUNKQ, TX_FLUSH, TM_TOTAL, TX_G_EARLY, TX_G_F3};
+    const u32 xs[16] = {TM_SLOW, TM_SPRE, TM_ROUGH, TM_FINDC, TM_POST, TM_KEYS, TM_READ_HEAD, TM_CQWAIT, TX_QMM, TX_QRUN, TX_PROLOG, TX_CHUNKQ, TX_FLUSH, TM_TOTAL, TX_G_EARLY, TX_OWNSPEC};
     for (u32 x = 0; x < 16; ++x) TM_TRACE_VAL(cfg, tid, launch, 16 + x, w.tm[xs[x]]);
   }
 #endif

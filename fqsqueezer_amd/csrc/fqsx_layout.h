@@ -138,7 +138,7 @@ enum { TM_TOTAL = 0, TM_SPEC, TM_FAST, TM_SLOW, TM_POST, TM_READ_HEAD, TM_LQ, TM
        TM_N, TM_SP_HIT = 46 /* ... keys, rank, repair decision of a hit */, TM_SP_MISS = 47 /* ... miss cascade */,
        TX_QMM = 48 /* resolver: quiet_miss_mask */, TX_QRUN /* ... quiet stretches */, TX_PROLOG /* ... launch start to first read */,
        TX_CHUNKQ /* ... chunk into the coding queue (after the keys) */, TX_FLUSH /* ... end-of-chunk flush_pushes */,
-       TX_G_EARLY /* generic positions: b-mer still partial */, TX_G_F3 /* ... global b-mer miss without a stage-P cascade */ };
+       TX_G_EARLY /* generic positions: b-mer still partial */, TX_OWNSPEC /* resolver: its own stage P (correction windows, reads without the scouts) */ };
 #ifdef FQSX_TIMING
 #define FQSX_TM_SLOTS 56   /* [0..47] are summed into WState.stat[16..63]; [48..55] only go to the per-launch trace */
 #else
@@ -197,7 +197,8 @@ struct DevCfg {
 enum {
   FQSX_DBG_SCOUTS_OFF = 1,      // no scout waves: the resolving wave runs stage P, the sweeps and the partial look-ups itself
   FQSX_DBG_ABANDON = 2,         // the resolving wave abandons the scouts on every third read from its start, on every third after its first chunk
-  FQSX_DBG_RESTART = 4,         // a scout restart (new epoch from the exact state) after every chunk, corrected or not
+  FQSX_DBG_RESTART = 4,         // a correction window (the resolving wave's own stage P for bmer - 1 positions, then back into the
+                                // scouts' chunk in mid-chunk) after every chunk, corrected or not
   FQSX_DBG_INSERTER_STALL = 8,  // the inserter wave gets list entries only when a look-up has to wait for them (and at the end of a segment)
 };
 enum {

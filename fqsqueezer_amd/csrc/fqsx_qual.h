@@ -54,7 +54,7 @@ FQ_DEV void q_encode_m(QEnc &e, u32 freq, u32 cum, u32 tot, u64 m) {
 #else
   u64 range = (u64)(((unsigned __int128)e.range * m) >> 64);
 #endif
-  if (e.range - range * tot >= tot) ++range;
+  if ((u32)e.range - (u32)range * tot >= tot) ++range;   // (remainder < 2 * tot < 2^17: the low words decide)
   u64 low = e.low + range * cum;
   range *= freq;
   while (range <= Top) {

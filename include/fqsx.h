@@ -132,6 +132,8 @@ int fqsx_qual_encode_block(fqsx_qual *, const uint8_t *quals, const uint64_t *re
 /* Same with the block already resident in device memory (d_quals / d_read_off device pointers, h_read_off the host copy). */
 int fqsx_qual_encode_block_dev(fqsx_qual *, const uint8_t *d_quals, const uint64_t *d_read_off, const uint64_t *h_read_off,
                                uint32_t n_reads, const uint8_t **streams, uint64_t *lens);
+int fqsx_qual_set_profiling(fqsx_qual *, int enable);         /* HIP events around every launch of the quality kernel ... */
+int fqsx_qual_kernel_times(fqsx_qual *, double out[2]);       /* ... out[0] = accumulated milliseconds, out[1] = launches */
 void fqsx_qual_destroy(fqsx_qual *);
 
 /* Host-side (CPU) read-length stream that accompanies every DNA stream in the container

@@ -1,8 +1,9 @@
 """The fall-back branches of the eight-wave worker protocol, taken deterministically.
 
 In the product run, which wave settles what depends on wave timing: whether a scout made a chunk or the resolving
-wave went on without it (sc_abandoned), whether a restart comes after a chunk, whether a local look-up finds its
-entries applied already.  The results must not depend on any of that.  DevCfg.dbg (env FQSX_PROTO_DEBUG, read by
+wave went on without it (sc_abandoned), where a correction window (the resolving wave's own stage P for the bmer - 1
+positions after a k-mer correction) ends inside a scout's chunk, whether a local look-up finds its entries applied
+already.  The results must not depend on any of that.  DevCfg.dbg (env FQSX_PROTO_DEBUG, read by
 fqsx_dna_create) forces each branch for a whole run; every run must reproduce the reference goldens bit for bit.
 Only the real kernels have these waves, so this is a GPU test (the emulation build runs every role inline)."""
 import pytest
@@ -14,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 SCOUTS_OFF, ABANDON, RESTART, INSERTER_STALL = 1, 2, 4, 8
 MODES = [SCOUTS_OFF, ABANDON, RESTART, INSERTER_STALL, ABANDON | RESTART | INSERTER_STALL]
-IDS = ["scouts_off", "abandon_every_3rd_read", "restart_after_every_chunk", "inserter_stalled", "abandon+restart+stall"]
+IDS = ["scouts_off", "abandon_every_3rd_read", "window_after_every_chunk", "inserter_stalled", "abandon+window+stall"]
 
 
 def gpu(header):
