@@ -19,6 +19,7 @@ struct SpecBuf {
   u32 h_read, h_i0, h_n;       // scout chunks: read index within the launch, first position, positions
   u32 h_epoch;                 // ... the restart epoch of the k-mer state they were rolled from (see ScoutReq) ...
   u32 h_pub;                   // ... and, stored last (release), the chunk's sequence number within the epoch + 1
+  u32 h_fix_lane, h_fix_end;   // scout_fix: lanes (h_fix_lane, h_fix_end) already assume the repair that fires at h_fix_lane (0xff: none)
   u32 h_pq_lo[2];              // list entries (b, s) below these were in the local tables when the chunk's probes started
   u32 h_np, h_nlp;             // probes issued (global, local) ...
   u64 h_ns, h_nls;             // ... and slots scanned, accounted when the chunk is used
@@ -2142,18 +2143,23 @@ FQ_DEV u32 repair_decide(const Wk &w, const C4 &c, u32 sym) {
 // The k-mers in w are the state before position i0 - joff (joff = 0: before the chunk itself; the scout wave starts
 // every chunk of a read from the state after the read's prefix).
 // Returns false if the wave gave the chunk up because a restart request came in (scout waves only).
-FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed, u32 joff = 0) {
+// lane0 != 0: a second pass over part of a chunk (scout_fix): the results go to lanes lane0 .. lane0 + n - 1, the chunk's
+// header (snapshot of the local lists, sweep bookkeeping) stands and the probe counts are added to it.
+FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed, u32 joff = 0, u32 lane0 = 0) {
   const DevCfg *cfg = w.cfg;
   u64 ns = 0, nls = 0;
   u32 np = 0, nlp = 0;
   const u32 lo0 = lq_done_now(w, 0), lo1 = lq_done_now(w, 1);   // everything below is in the local tables before the probes start
   FQ_SYNC();
-  if (FQ_LANE == 0) { w.sb->h_pq_lo[0] = lo0; w.sb->h_pq_lo[1] = lo1; }
-  for (u32 j = FQ_LANE; j < FQSX_SPEC; j += FQ_WAVE) { w.sb->rr_idx[j] = 0xff; w.sb->ep_off[j][0] = 0xff; w.sb->ep_off[j][1] = 0xff; }
-  if (FQ_LANE == 0) w.sb->rr_front = FQSX_SPEC;
+  if (lane0 == 0) {
+    if (FQ_LANE == 0) { w.sb->h_pq_lo[0] = lo0; w.sb->h_pq_lo[1] = lo1; }
+    for (u32 j = FQ_LANE; j < FQSX_SPEC; j += FQ_WAVE) { w.sb->rr_idx[j] = 0xff; w.sb->ep_off[j][0] = 0xff; w.sb->ep_off[j][1] = 0xff; }
+    if (FQ_LANE == 0) { w.sb->rr_front = FQSX_SPEC; w.sb->h_fix_lane = 0xff; w.sb->h_fix_end = 0; }
+  }
   const u32 b0 = i0 - joff;   // position the k-mers in w stand before
   bool gave_up = false;
   for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
+    const u32 jj = lane0 + j;   // the lane's place in the chunk
     TM_BEGIN(t_roll);
     // roll the six k-mers J symbols forward in closed form: only the last min(J, k) new symbols matter
     u64 fw = 0, rv = 0;   // new symbols packed oldest-first (fw) and complemented newest-first (rv)
@@ -2201,13 +2207,13 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
     Kmer pu = km_roll(w.pm_u, cfg->gp, J, fw, rv, L), su = km_roll(w.sm_u, cfg->gs, J, fw, rv, L), bu = km_roll(w.bm_u, cfg->gb, J, fw, rv, L);
     km_insert_zero(pm, cfg->gp); km_insert_zero(sk, cfg->gs); km_insert_zero(bm, cfg->gb);
     km_insert_zero(pu, cfg->gp); km_insert_zero(su, cfg->gs); km_insert_zero(bu, cfg->gb);
-    w.sb->sp_sdir[0][j] = pm.dir; w.sb->sp_src[0][j] = pm.rc; w.sb->sp_scur[0][j] = (u8)pm.cur;
-    w.sb->sp_sdir[1][j] = sk.dir; w.sb->sp_src[1][j] = sk.rc; w.sb->sp_scur[1][j] = (u8)sk.cur;
-    w.sb->sp_sdir[2][j] = bm.dir; w.sb->sp_src[2][j] = bm.rc; w.sb->sp_scur[2][j] = (u8)bm.cur;
-    w.sb->sp_sdir[3][j] = pu.dir; w.sb->sp_src[3][j] = pu.rc; w.sb->sp_scur[3][j] = (u8)pu.cur;
-    w.sb->sp_sdir[4][j] = su.dir; w.sb->sp_src[4][j] = su.rc; w.sb->sp_scur[4][j] = (u8)su.cur;
-    w.sb->sp_sdir[5][j] = bu.dir; w.sb->sp_src[5][j] = bu.rc; w.sb->sp_scur[5][j] = (u8)bu.cur;
-    w.sb->sp_nrun[j] = (u8)(nrun > 255 ? 255 : nrun);
+    w.sb->sp_sdir[0][jj] = pm.dir; w.sb->sp_src[0][jj] = pm.rc; w.sb->sp_scur[0][jj] = (u8)pm.cur;
+    w.sb->sp_sdir[1][jj] = sk.dir; w.sb->sp_src[1][jj] = sk.rc; w.sb->sp_scur[1][jj] = (u8)sk.cur;
+    w.sb->sp_sdir[2][jj] = bm.dir; w.sb->sp_src[2][jj] = bm.rc; w.sb->sp_scur[2][jj] = (u8)bm.cur;
+    w.sb->sp_sdir[3][jj] = pu.dir; w.sb->sp_src[3][jj] = pu.rc; w.sb->sp_scur[3][jj] = (u8)pu.cur;
+    w.sb->sp_sdir[4][jj] = su.dir; w.sb->sp_src[4][jj] = su.rc; w.sb->sp_scur[4][jj] = (u8)su.cur;
+    w.sb->sp_sdir[5][jj] = bu.dir; w.sb->sp_src[5][jj] = bu.rc; w.sb->sp_scur[5][jj] = (u8)bu.cur;
+    w.sb->sp_nrun[jj] = (u8)(nrun > 255 ? 255 : nrun);
     const u32 i = i0 + j, sym = rd_sym(w, p, i, size);
     const u64 symk = sym == 4 ? 0 : sym;
     u32 flag = 0, rep = 0xff;
@@ -2251,8 +2257,8 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           u64 lev[7];
           if (!reversed) ctx_codes(lev, cfg, c, w.s_let, i, LV_BMER, cz, 0, size);
           else ctx_codes(lev, cfg, c, w.s_let, size - i - 1, LV_BMER, cz, 0, ~0u);  // dna.cpp:750-752
-          for (u32 l = 0; l < 7; ++l) w.sb->sp_key[j][l] = lev[l];
-          w.sb->sp_rsym[j] = (u8)rank_sym(w, c, sym);
+          for (u32 l = 0; l < 7; ++l) w.sb->sp_key[jj][l] = lev[l];
+          w.sb->sp_rsym[jj] = (u8)rank_sym(w, c, sym);
           // repair_kmers_existing decision (dna.cpp:333-360)
           rep = repair_decide(w, c, sym);
         }
@@ -2275,34 +2281,34 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           ++nlp;
           if (c4_any(l)) {
             xf |= SX_LB;
-            w.sb->sx_lb[j] = l.c[0] | (l.c[1] << 8) | (l.c[2] << 16) | (l.c[3] << 24);
+            w.sb->sx_lb[jj] = l.c[0] | (l.c[1] << 8) | (l.c[2] << 16) | (l.c[3] << 24);
           } else if (unc && (tab_rest(cfg->g_b, fu, ku, ndu, l, ns), ++np, c4_any(l))) {
             xf |= SX_UNC;
-            w.sb->sx_s[j] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
+            w.sb->sx_s[jj] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
           } else {
             c4_zero(l);
             tab_rest(cfg->g_s, fs, ks, nds, l, ns);
             ++np;
             if (c4_any(l)) {
               xf |= SX_S;
-              w.sb->sx_s[j] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
+              w.sb->sx_s[jj] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
             } else {
               tab_rest(cfg->l_s, fls, ks, nds, l, nls);
               ++nlp;
               if (c4_any(l)) {
                 xf |= SX_LS;
-                w.sb->sx_ls[j] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
+                w.sb->sx_ls[jj] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
               }
             }
           }
         }
-        w.sb->sx_flag[j] = (u8)xf;
+        w.sb->sx_flag[jj] = (u8)xf;
         TM_END_SP(w, TM_SP_MISS, t_hit);
       }
     }
-    w.sb->sp_flag[j] = (u8)flag;
-    w.sb->sp_kind[j] = flag == 1 ? SK_RANK : SK_NONE;
-    w.sb->sp_rep[j] = (u8)rep;
+    w.sb->sp_flag[jj] = (u8)flag;
+    w.sb->sp_kind[jj] = flag == 1 ? SK_RANK : SK_NONE;
+    w.sb->sp_rep[jj] = (u8)rep;
     // mailbox entries of this position (dna.cpp:818-852), k-mers after replace_last(sym)
     km_replace_last(pm, symk); km_replace_last(sk, symk); km_replace_last(bm, symk);
     u32 pf = 0;
@@ -2314,17 +2320,20 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
         if (flag == 1) pf |= (b_full && c4_get(c, sym) >= 3) ? PV_PHID : PV_P;
       }
     }
-    w.sb->pv_b[j] = km_norm(bm, cfg->gb);
-    w.sb->pv_s[j] = km_norm(sk, cfg->gs);
-    w.sb->pv_pd[j] = km_aligned_dir(pm);
-    w.sb->pv_pr[j] = km_aligned_rc(pm);
-    w.sb->pv_flag[j] = (u8)pf;
+    w.sb->pv_b[jj] = km_norm(bm, cfg->gb);
+    w.sb->pv_s[jj] = km_norm(sk, cfg->gs);
+    w.sb->pv_pd[jj] = km_aligned_dir(pm);
+    w.sb->pv_pr[jj] = km_aligned_rc(pm);
+    w.sb->pv_flag[jj] = (u8)pf;
   }
   if (wave_any(gave_up)) return false;   // (decided for the whole wave: the lanes beyond the chunk did not ask)
   FQ_SYNC();
   np = wave_sum32(np); nlp = wave_sum32(nlp);
   ns = wave_sum64(ns); nls = wave_sum64(nls);
-  if (FQ_LANE == 0) { w.sb->h_np = np; w.sb->h_nlp = nlp; w.sb->h_ns = ns; w.sb->h_nls = nls; }
+  if (FQ_LANE == 0) {
+    if (lane0 == 0) { w.sb->h_np = np; w.sb->h_nlp = nlp; w.sb->h_ns = ns; w.sb->h_nls = nls; }
+    else { w.sb->h_np += np; w.sb->h_nlp += nlp; w.sb->h_ns += ns; w.sb->h_nls += nls; }
+  }
   FQ_SYNC();
   return true;
 }
@@ -2336,6 +2345,48 @@ FQ_DEV void spec_adopt(Wk &w) {
   w.st[ST_GSLOT] += w.sb->h_ns;
   w.st[ST_LPROBE] += w.sb->h_nlp;
   w.st[ST_LSLOT] += w.sb->h_nls;
+}
+
+FQ_DEV void load_state(Wk &w, u32 j);
+FQ_DEV void replace_last_all(Wk &w, u64 symk);
+// Scout waves, after stage P of a chunk.  If the chunk's first repair (repair_kmers_existing firing at a settled
+// position, dna.cpp:362-369) comes with every lane before it settled, what the resolving wave will do there is known,
+// and so is the state after it: the lanes inside the correction window (see suffix()) are speculated again from that
+// state, in place, so that the resolving wave finds them ready instead of running stage P for the window itself.
+// Returns false if the wave gave the chunk up (a restart request came in).
+FQ_DEV bool scout_fix(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed) {
+#if FQ_WAVE > 1
+  SpecBuf *sb = w.sb;
+  const u32 lane = FQ_LANE;
+  FQ_SYNC();
+  const bool f = lane < n && sb->sp_flag[lane] == 1, r = f && sb->sp_rep[lane] != 0xff;
+  const u64 Fm = wave_ballot(f), Rm = wave_ballot(r);
+  if (!Rm) return true;
+  const u32 js = ctz64(Rm);
+  // (the window may run past the chunk's last position into the buffer's spare lanes -- a 150 bp read's chunks have 45 of
+  // the 64 -- which then hold positions of the next chunk as they look after the repair)
+  const u32 lanes_left = FQSX_SPEC - (js + 1), pos_left = size - (i0 + js + 1);
+  if ((~Fm & ((1ull << js) - 1ull)) != 0 || lanes_left == 0 || pos_left == 0) return true;
+  const Kmer s0 = w.pm, s1 = w.sm_, s2 = w.bm, s3 = w.pm_u, s4 = w.sm_u, s5 = w.bm_u;
+  const u32 s_cor = w.cor_pos, s_nrun = w.N_run;
+  const u32 sym = rd_sym(w, p, i0 + js, size), rep = sb->sp_rep[js];
+  load_state(w, js);
+  replace_last_all(w, sym == 4 ? 0 : sym);
+  km_replace_last(w.pm, rep); km_replace_last(w.sm_, rep); km_replace_last(w.bm, rep);
+  w.cor_pos = i0 + js;
+  w.N_run = sym == 4 ? w.N_run + 1 : 0;
+  u32 cnt = w.cfg->bmer - 1;
+  if (cnt > lanes_left) cnt = lanes_left;
+  if (cnt > pos_left) cnt = pos_left;
+  const bool whole = speculate(w, p, size, i0 + js + 1, cnt, reversed, 0, js + 1);
+  w.pm = s0; w.sm_ = s1; w.bm = s2; w.pm_u = s3; w.sm_u = s4; w.bm_u = s5;
+  w.cor_pos = s_cor; w.N_run = s_nrun;
+  if (!whole) return false;
+  FQ_SYNC();
+  if (lane == 0) { sb->h_fix_lane = js; sb->h_fix_end = js + 1 + cnt; }
+  FQ_SYNC();
+#endif
+  return true;
 }
 
 // Stage Q: append the mailbox entries of chunk positions [a,b) to this worker's lists, lane-parallel,
@@ -2948,7 +2999,7 @@ FQ_DEV void scout_unhold(Wk &w) {   // the chunk held across an early restart is
 }
 // The scouts' chunk that covers position `at` of the current read / request becomes w.sb; chunks that lie wholly before
 // it (inside a window the resolving wave has just covered itself) are released on the way.  False: go on without them.
-FQ_DEV bool scout_seek(Wk &w, u32 at) {
+FQ_DEV bool scout_seek(Wk &w, u32 at, const SpecBuf *fixed, u32 fixed_pub) {
   WgShared *sm = w.sm;
   for (;;) {
     SpecBuf *b = &sm->sb[1 + (w.sc_base + w.sc_taken) % w.nsc];
@@ -2961,7 +3012,8 @@ FQ_DEV bool scout_seek(Wk &w, u32 at) {
     const i32 older = (i32)(b->h_read - w.sc_read);
     if (older < 0) { scout_release(w); continue; }   // a chunk of an earlier read that ended inside a window
     if (older > 0 || at < b->h_i0) { w.sc_abandoned = true; return false; }   // (cannot happen: the waves enumerate the chunks alike)
-    if (at < b->h_i0 + b->h_n) { w.sb = b; return true; }
+    const u32 lanes = fixed == b && fixed_pub == b->h_pub && b->h_fix_end > b->h_n ? b->h_fix_end : b->h_n;   // (scout_fix's spare lanes count once its repair has been taken)
+    if (at < b->h_i0 + lanes) { w.sb = b; return true; }
     scout_release(w);
   }
 }
@@ -2990,7 +3042,9 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
   // resolving wave runs stage P itself for the window (`own_end`: positions below it are its own) and then goes on in
   // the scouts' chunk that covers the next position, from whatever lane that is.
   u32 at = i;               // next position to resolve
-  u32 own_end = 0;          // positions below this one are speculated by this wave itself
+  u32 own_lo = 0, own_hi = 0;   // positions in [own_lo, own_hi) are speculated by this wave itself
+  const SpecBuf *fixed = nullptr;   // ring chunk whose predicted repair (scout_fix) this wave has taken: its fixed lanes stand
+  u32 fixed_pub = 0;
   const u32 at_first = at;
   const SpecBuf *counted = nullptr;   // ring chunk whose probes have been accounted (a chunk can be entered more than once)
   u32 counted_pub = 0;
@@ -2999,16 +3053,27 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
     if ((dbg & FQSX_DBG_ABANDON) && w.scout && w.sc_read % 3 == 2 && at != at_first) w.sc_abandoned = true;   // ... this one after its first chunk
     bool pre = false;
     u32 n, j0 = 0;
-    if (at >= own_end && w.scout && !w.sc_abandoned) pre = scout_seek(w, at);   // stage P done ahead of time by a scout wave
+    if (!(at >= own_lo && at < own_hi) && w.scout && !w.sc_abandoned) pre = scout_seek(w, at, fixed, fixed_pub);   // stage P done ahead of time by a scout wave
+    if (pre) {
+      // lanes a scout has speculated again for a repair it foresaw (scout_fix) are only good if this wave took that
+      // very repair from the chunk; entered from elsewhere they are covered by this wave itself
+      const u32 fl = w.sb->h_fix_lane, fe = w.sb->h_fix_end, jx = at - w.sb->h_i0;
+      if (fl != 0xff && jx > fl && jx < fe && !(fixed == w.sb && fixed_pub == w.sb->h_pub)) {
+        own_lo = at;
+        if (own_hi < w.sb->h_i0 + fe) own_hi = w.sb->h_i0 + fe;
+        pre = false;
+      }
+    }
     if (pre) {
       i = w.sb->h_i0; n = w.sb->h_n; j0 = at - i;
+      if (fixed == w.sb && fixed_pub == w.sb->h_pub && w.sb->h_fix_end > n) n = w.sb->h_fix_end;   // (the spare lanes scout_fix filled)
       w.pq_lo[0] = w.sb->h_pq_lo[0];
       w.pq_lo[1] = w.sb->h_pq_lo[1];
       if (counted != w.sb || counted_pub != w.sb->h_pub) { counted = w.sb; counted_pub = w.sb->h_pub; spec_adopt(w); }
     } else {
       i = at;
       n = chunk_len(size - at);
-      if (w.scout && !w.sc_abandoned && at < own_end && own_end - at < n) n = own_end - at;   // (just the window: a scout's chunk takes over behind it)
+      if (w.scout && !w.sc_abandoned && at >= own_lo && at < own_hi && own_hi - at < n) n = own_hi - at;   // (just the window: a scout's chunk takes over behind it)
       w.sb = &sm->sb[0];
       TM_BEGIN(t_own);
       speculate(w, p, size, i, n, reversed);
@@ -3034,6 +3099,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
     u32 w_pos = j0;   // w's k-mers = state before position w_pos of the chunk
     u32 m = j0;       // committed positions (lanes [j0, m) of the chunk)
     bool dirty = false;  // corrected k-mers were modified: the speculation of the next bmer - 1 positions is stale
+    bool foreseen = false;   // ... by the repair of a settled position, which a scout may have allowed for (scout_fix)
     for (u32 j = j0; j < n && !dirty && !w.err; ++j) {
       const u32 pos = i + j;
       const u32 sym = rd_sym(w, p, pos, size);
@@ -3113,6 +3179,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           push_b_local(w);
           w_pos = j + 1;
           dirty = true;
+          foreseen = true;
         }
       } else {
         // not settled by stage P alone
@@ -3342,7 +3409,16 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       w.N_run = sym == 4 ? w.N_run + 1 : 0;
     }
     at = i + m;
-    if (dirty || (dbg & FQSX_DBG_RESTART)) own_end = at + cfg->bmer - 1;   // (test switch: the window after every chunk, corrected or not)
+    if (dirty || (dbg & FQSX_DBG_RESTART)) {   // (test switch: the window after every chunk, corrected or not)
+      own_lo = at;
+      own_hi = at + cfg->bmer - 1;
+      if (pre && dirty && foreseen && !(dbg & FQSX_DBG_RESTART) && w.sb->h_fix_lane == m - 1) {   // the scout has the window's lanes of this chunk ready
+        own_lo = i + w.sb->h_fix_end;
+        fixed = w.sb;
+        fixed_pub = w.sb->h_pub;
+        if (w.sb->h_fix_end > n) n = w.sb->h_fix_end;   // (the chunk goes on into its spare lanes: not finished yet)
+      }
+    }
     if (pre && m == n) scout_release(w);   // (a chunk left in its middle stays the head of the ring: the position after the window may lie in it)
   }
 }
@@ -3874,7 +3950,9 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         TM_BEGIN(t_se);
         if (i0 == base_pos) { scout_early(w, n); scout_settle_early(w, i0, n); }   // (the look-ups of positions whose b-mer is still partial, if any)
         TM_END(w, TM_SC_EARLY, t_se);
-        const u32 front0 = scout_rough_first(w, n);
+        if (!scout_fix(w, p, size, i0, n, false)) { TM_COUNT(w, CN_SC_ABORT); restart = true; break; }
+        const u32 n_sw = uniform32(w.sb->h_fix_end) > n ? uniform32(w.sb->h_fix_end) : n;   // (lanes whose sweeps are probed ahead: scout_fix's spare lanes too)
+        const u32 front0 = scout_rough_first(w, n_sw);
 #else
         const u32 front0 = FQSX_SPEC;
 #endif
@@ -3883,7 +3961,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         lds_store_rel(&w.sb->h_pub, seq + 1);   // the resolving wave may start on the chunk ...
 #if FQ_WAVE > 1
         TM_BEGIN(t_sr);
-        scout_rough(w, n);                       // ... while its sweeps are still being probed (rr_front)
+        scout_rough(w, n_sw);                    // ... while its sweeps are still being probed (rr_front)
         TM_END(w, TM_SC_ROUGH, t_sr);
 #endif
       }
@@ -3973,7 +4051,9 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
       TM_COUNT(w, CN_SC_CHUNK);
 #if FQ_WAVE > 1
       if (i0 == base_pos) { scout_early(w, n); scout_settle_early(w, i0, n); }   // (the look-ups of positions whose b-mer is still partial, if any)
-      const u32 front0 = scout_rough_first(w, n);
+      if (!scout_fix(w, p, size, i0, n, reversed)) { TM_COUNT(w, CN_SC_ABORT); break; }
+      const u32 n_sw = uniform32(w.sb->h_fix_end) > n ? uniform32(w.sb->h_fix_end) : n;
+      const u32 front0 = scout_rough_first(w, n_sw);
 #else
       const u32 front0 = FQSX_SPEC;
 #endif
@@ -3982,7 +4062,7 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
       lds_store_rel(&w.sb->h_pub, seq + 1);   // the resolving wave may start on the chunk ...
 #if FQ_WAVE > 1
       TM_BEGIN(t_sr);
-      scout_rough(w, n);                       // ... while its sweeps are still being probed (rr_front)
+      scout_rough(w, n_sw);                    // ... while its sweeps are still being probed (rr_front)
       TM_END(w, TM_SC_ROUGH, t_sr);
 #endif
     }
