@@ -291,20 +291,27 @@ def sharded_main(a, rank, local_rank, world):
     import torch
     import torch.distributed as dist
     from fqsqueezer_amd import hostpipe as hp
-    from fqsqueezer_amd.sharded import ShardedDnaCodec
-    from fqsqueezer_amd.synth import read_id, synth_quals, synth_reads
+    from fqsqueezer_amd.sharded import NativeShardedDnaCodec
+    from fqsqueezer_amd.synth import read_id, synth_reads
     reads = synth_reads(a.reads, a.len, a.genome, 2)
-    rec = hp.Records([read_id(i) for i in range(a.reads)], reads, synth_quals(a.reads, a.len, 2))
+    rec = hp.Records([read_id(i) for i in range(a.reads)], reads, reads)
     header = hp.make_header(a.threads, "se_sorted", a.gs)
-    host_blocks = [hp.block_arrays(rec, idx) for idx in hp.form_blocks(rec, "se_sorted")]
+    dev_blocks = []   # the blocks resident in HBM before the timed region, as in the unsharded bench
+    for idx in hp.form_blocks(rec, "se_sorted"):
+        bases, off = hp.block_arrays(rec, idx)
+        dev_blocks.append((torch.from_numpy(np.ascontiguousarray(bases)).cuda(), torch.from_numpy(off.view(np.int64)).cuda(), off))
     n_bases = int(a.reads) * int(a.len)
     traffic = {}
 
     def one_step():
-        c = ShardedDnaCodec(header, rank, world, device=local_rank)
+        # native driver: the phase loop, RCCL calls included, inside libfqsx.so (fqsx_shard_encode_block); the RCCL id travels
+        # through torch.distributed's object broadcast
+        ids = [NativeShardedDnaCodec.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        c = NativeShardedDnaCodec(header, rank, world, device=local_rank, transport="rccl", id_bytes=ids[0])
         nb = 0
-        for g, (bases, off) in enumerate(host_blocks):
-            nb += sum(len(x) for x in c.encode_block(bases, off, g).values())
+        for g, (d_b, d_o, off) in enumerate(dev_blocks):
+            nb += c.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g)
         traffic.update(c.traffic)
         c.close()
         return nb
@@ -330,7 +337,7 @@ def sharded_main(a, rank, local_rank, world):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2), -om s -gs {a.gs} -qm n -im n", "workers_T": a.threads,
-                       "blocks": len(host_blocks), "per_gpu": f"one file sharded over {world} GPU(s): workers w % {world}, RCCL all-to-all of the mailboxes per phase"},
+                       "blocks": len(dev_blocks), "per_gpu": f"one file sharded over {world} GPU(s): workers w % {world}, RCCL all-to-all of the mailboxes per phase"},
             "bits_per_base": round(8.0 * int(tot.item()) / n_bases, 5),
             "exchange_rank0_per_file": traffic, "roofline": None, "cpu_baseline": None}), flush=True)
     dist.barrier()

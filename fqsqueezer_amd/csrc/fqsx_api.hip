@@ -15,6 +15,10 @@
 #include "fqsx_qual.h"
 #include "../../include/fqsx.h"
 
+#ifndef FQSX_EMU
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // (types only: librccl is loaded with dlopen on first use, see fqsx_rccl_comm_create)
+#endif
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -256,6 +260,69 @@ FQ_KERNEL64 void k_shard_counts(DevCfg cfg) {   // grid = 3 * T: (kind, source)
     cfg.shard_cnt[((u64)kind * T + s) * T + o] = n;
   }
 }
+// ---- native sharded driver (fqsx_shard_encode_block): the words that ride along with the collectives ------------
+// tail of the count matrix: [3 T^2 + s] = paired-end triples source s pushed in this phase (own sources, else 0)
+FQ_KERNEL64 void k_shard_counts_tail(DevCfg cfg) {
+  const u32 T = cfg.T;
+  for (u32 s = FQ_LANE; s < T; s += FQ_WAVE) cfg.shard_cnt[3ull * T * T + s] = (cfg.pe_n && shard_mine(cfg, s)) ? cfg.pe_n[s] : 0u;
+}
+// after the all-reduce of the counts: out[0/1] = table demand of the coming insert phase (occupied + incoming slots of the
+// fullest s- / b-mer sub-table: every rank holds a replica of every sub-table, so every rank computes the same numbers),
+// out[2] = the device error word
+FQ_KERNEL64 void k_shard_need(DevCfg cfg, const u32 *C, u64 *out) {
+  const u32 T = cfg.T;
+  for (u32 which = 0; which < 2; ++which) {
+    const KTab &t = which ? cfg.g_b : cfg.g_s;
+    const u32 *Ck = C + (u64)(which ? MAIL_B : MAIL_S) * T * T;
+    u64 need = 0;
+    for (u32 o = FQ_LANE; o < T; o += FQ_WAVE) {
+      u64 n = t.filled[o];
+      for (u32 s = 0; s < T; ++s) n += Ck[(u64)s * T + o];
+      need = n > need ? n : need;
+    }
+#if FQ_WAVE > 1
+    for (int off = 32; off > 0; off >>= 1) { const u64 y = __shfl_xor(need, off, 64); need = y > need ? y : need; }
+#endif
+    if (FQ_LANE == 0) out[which] = need;
+  }
+  if (FQ_LANE == 0) out[2] = cfg.err[0];
+}
+// this rank's paired-end triples, sources in ascending order -> out (the all-gather's payload)
+FQ_KERNEL64 void k_shard_pe_pack(DevCfg cfg, u64 *out) {   // grid = T (source)
+  const u32 s = FQ_BLOCK;
+  if (!shard_mine(cfg, s)) return;
+  u64 off = 0;
+  for (u32 t = cfg.shard_rank; t < s; t += cfg.shard_world) off += cfg.pe_n[t];
+  const u64 n = 3ull * cfg.pe_n[s];
+  const u64 *src = cfg.pe_list + (u64)s * cfg.pe_cap * 3;
+  for (u64 i = FQ_LANE; i < n; i += FQ_WAVE) out[3 * off + i] = src[i];
+}
+// ... and the other ranks' triples into the per-source lists, so that the pair-table insert runs over all T sources on
+// every rank: its inserts commute and draw nothing, so every replica of the pair table ends up with the same content.
+// gathered = [world][stride] words, a rank's triples at word pe_off; pe_cnt[s] = triples of source s (count matrix tail)
+FQ_KERNEL64 void k_shard_pe_unpack(DevCfg cfg, const u64 *gathered, u64 stride, u64 pe_off, const u32 *pe_cnt) {   // grid = T (source)
+  const u32 s = FQ_BLOCK, q = s % cfg.shard_world;
+  if (q == cfg.shard_rank) return;
+  u64 off = 0;
+  for (u32 t = q; t < s; t += cfg.shard_world) off += pe_cnt[t];
+  const u64 n = 3ull * pe_cnt[s];
+  const u64 *src = gathered + (u64)q * stride + pe_off + 3 * off;
+  u64 *dst = cfg.pe_list + (u64)s * cfg.pe_cap * 3;
+  for (u64 i = FQ_LANE; i < n; i += FQ_WAVE) dst[i] = src[i];
+  if (FQ_LANE == 0) cfg.pe_n[s] = pe_cnt[s];
+}
+// p-mer vector statistics: this rank's contribution of the phase (after - before) into the payload ...
+FQ_KERNEL64 void k_shard_siv_delta(DevCfg cfg, const u64 *before, u64 *out) {
+  for (u32 i = FQ_LANE; i < 2; i += FQ_WAVE) out[i] = cfg.siv_stats[i] - before[i];
+}
+// ... and, after the all-gather, the sum over the ranks on top of the value before the phase (every rank alike)
+FQ_KERNEL64 void k_shard_siv_sum(DevCfg cfg, const u64 *before, const u64 *gathered, u64 stride, u64 off) {
+  for (u32 i = FQ_LANE; i < 2; i += FQ_WAVE) {
+    u64 v = before[i];
+    for (u32 q = 0; q < cfg.shard_world; ++q) v += gathered[(u64)q * stride + off + i];
+    cfg.siv_stats[i] = v;
+  }
+}
 // Received entries -> this rank's owners' groups in (owner, source, push) order (the order InsertKmersToHT drains
 // its column in).  recv = the chunks of ranks 0..G-1 one after the other; the chunk of rank q holds, for every owner
 // of this rank in ascending order, the entries of q's sources in ascending order.  C = the summed count matrix.
@@ -450,8 +517,17 @@ struct fqsx_dna {
   u8 *d_vmap;
   u64 *d_xbuf;        // received entries / upsert items
   u64 xbuf_cap;
-  u32 *d_cglob;       // [3][T][T] the all-reduced count matrix of the phase
+  u32 *d_cglob;       // [3][T][T] (+ [T] paired-end triples per source) the all-reduced count matrix of the phase
   u64 siv_before[2];
+  // native sharded driver (fqsx_shard_attach / fqsx_shard_encode_block)
+  fqsx_comm comm;     // the world's collectives (RCCL on the codec's stream, or the caller's)
+  bool comm_set, shard_apply_own;
+  u64 *d_xrecv[3];    // received mailbox entries per kind
+  u64 xrecv_cap[3];
+  u64 *d_items, *d_gathered, *d_small;   // all-gather payload of this rank / of all ranks; [0..1] siv statistics before the phase, [2..4] demand + error word
+  u64 items_cap, gathered_cap;
+  std::vector<u32> h_cglob;
+  u64 sh_phases, sh_collectives, sh_a2a_words, sh_gather_words;
 };
 
 namespace {
@@ -1207,6 +1283,11 @@ int fqsx_dna_create_on_partition(const uint8_t *h, int device, uint32_t part, ui
   c->compact_cap = 0;
   c->din_cap = c->dout_cap = 0;
   c->shard_rank = 0; c->shard_world = 1;
+  c->comm_set = false; c->shard_apply_own = false;
+  memset(&c->comm, 0, sizeof(c->comm));
+  for (int k = 0; k < 3; ++k) { c->d_xrecv[k] = nullptr; c->xrecv_cap[k] = 0; }
+  c->d_items = c->d_gathered = c->d_small = nullptr; c->items_cap = c->gathered_cap = 0;
+  c->sh_phases = c->sh_collectives = c->sh_a2a_words = c->sh_gather_words = 0;
   c->dev_bytes = c->dev_bytes_peak = 0; c->n_growths = 0;
   c->h_pin = nullptr; c->d_end = nullptr; c->filled_valid = false;
   c->d_vmap = nullptr; c->d_xbuf = nullptr; c->xbuf_cap = 0; c->d_cglob = nullptr;
@@ -1317,7 +1398,6 @@ int fqsx_dna_decode_block(fqsx_dna *c, const uint8_t *const *streams, const uint
 // Pointers marked [codec] are in the codec's memory space: device memory for the HIP build.
 int fqsx_shard_config(fqsx_dna *c, uint32_t rank, uint32_t world) {
   if (!c || world == 0 || rank >= world || world > c->T) { g_err = "bad rank / world size"; return FQSX_E_ARG; }
-  if (c->paired && world > 1) { g_err = "the sharded mode covers the single-end modes"; return FQSX_E_ARG; }
 #ifndef FQSX_EMU
   HIPCHK(hipSetDevice(c->device));
 #endif
@@ -1334,10 +1414,13 @@ int fqsx_shard_config(fqsx_dna *c, uint32_t rank, uint32_t world) {
   void *p = nullptr;
   if ((rc = h2d(c, c->d_vmap, vm, 256))) return rc;
   if (!c->cfg.shard_cnt) {
-    if ((rc = dalloc(c, &p, 3ull * T * T * sizeof(u32), true))) return rc;
+    if ((rc = dalloc(c, &p, (3ull * T * T + T) * sizeof(u32), true))) return rc;   // (+ T: paired-end triples per source)
     c->cfg.shard_cnt = (u32 *)p;
-    if ((rc = dalloc(c, &p, 3ull * T * T * sizeof(u32), true))) return rc;
+    if ((rc = dalloc(c, &p, (3ull * T * T + T) * sizeof(u32), true))) return rc;
     c->d_cglob = (u32 *)p;
+    if ((rc = dalloc(c, &p, 8 * sizeof(u64), true))) return rc;
+    c->d_small = (u64 *)p;
+    c->h_cglob.assign(3ull * T * T + T, 0);
   }
 #ifndef FQSX_EMU
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1482,6 +1565,259 @@ int fqsx_shard_finish_block(fqsx_dna *c, const uint64_t *h_off, const uint8_t **
   HIPCHK(hipSetDevice(c->device));
 #endif
   return block_finish(c, h_off, streams, lens, nullptr);
+}
+
+// ---- the phase loop inside the library ------------------------------------------------------------------------------
+namespace {
+int xbuf_fit(fqsx_dna *c, u64 *&buf, u64 &cap, u64 words) {
+  if (words <= cap) return FQSX_OK;
+  void *p = nullptr;
+  if (buf) dfree(c, buf);
+  const u64 ncap = words + words / 4 + 1024;
+  int rc = dalloc(c, &p, ncap * sizeof(u64), false);
+  if (rc) { buf = nullptr; cap = 0; return rc; }
+  buf = (u64 *)p;
+  cap = ncap;
+  return FQSX_OK;
+}
+#define COMMCHK(x, what) do { if ((x) != 0) { if (g_err.empty() || g_err.find(what) == std::string::npos) g_err = std::string(what) + " failed"; return FQSX_E_HIP; } } while (0)
+
+int shard_phase_native(fqsx_dna *c, u32 seg) {
+  const u32 T = c->T, G = c->shard_world, me = c->shard_rank;
+  DevCfg &cfg = c->cfg;
+  const u64 NC = 3ull * T * T + T;
+  int rc;
+  // ---- encode own workers, count what they pushed for whom
+  if ((rc = launch_segment(c, false, c->cur_n_reads, c->cur_S, seg))) return rc;
+  const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
+  LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
+  LAUNCH(c, 2, k_shard_counts, 3 * T, 64, cfg);
+  LAUNCH(c, 2, k_shard_counts_tail, 1, 64, cfg);
+  if ((rc = d2d(c, c->d_cglob, cfg.shard_cnt, NC * sizeof(u32)))) return rc;
+  COMMCHK(c->comm.allreduce_sum_u32(c->comm.ctx, c->d_cglob, NC), "all-reduce of the mailbox counts");   // collective 1
+  LAUNCH(c, 2, k_shard_need, 1, 64, cfg, (const u32 *)c->d_cglob, c->d_small + 2);
+  // ---- the phase's one host round trip: every transfer size, the table demand, the error word
+  u64 small[3];
+#ifndef FQSX_EMU
+  HIPCHK(hipMemcpyAsync(c->h_cglob.data(), c->d_cglob, NC * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+#else
+  memcpy(c->h_cglob.data(), c->d_cglob, NC * sizeof(u32));
+#endif
+  if ((rc = d2h_sync(c, small, c->d_small + 2, sizeof(small)))) return rc;
+  if (small[2]) { g_err = "device error " + std::to_string(small[2]) + " in encode kernel"; return FQSX_E_DEVICE; }
+  const u32 *C = c->h_cglob.data();
+  std::vector<u64> vol(3ull * G * G, 0);   // [kind][from rank][to rank]
+  for (u32 k = 0; k < 3; ++k)
+    for (u32 s = 0; s < T; ++s)
+      for (u32 o = 0; o < T; ++o) vol[((u64)k * G + s % G) * G + o % G] += C[((u64)k * T + s) * T + o];
+  // ---- own entries in send order (destination rank, owner, source, push) = the partitioned mailbox with rank-major groups
+  LAUNCH(c, 2, k_part_scan, 3 * T, 64, cfg);
+  LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand, 0u);
+  LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, 0u, (u32 *)nullptr);
+  std::vector<u64> sc(3ull * G), rcnt(3ull * G);
+  const u64 *send[3];
+  u64 *recv[3];
+  for (u32 k = 0; k < 3; ++k) {
+    u64 n_in = 0;
+    for (u32 q = 0; q < G; ++q) {
+      sc[(u64)k * G + q] = vol[((u64)k * G + me) * G + q];
+      rcnt[(u64)k * G + q] = vol[((u64)k * G + q) * G + me];
+      n_in += rcnt[(u64)k * G + q];
+      if (q != me) c->sh_a2a_words += sc[(u64)k * G + q];
+    }
+    if ((rc = xbuf_fit(c, c->d_xrecv[k], c->xrecv_cap[k], n_in + 1))) return rc;
+    send[k] = cfg.mail[k].sorted;
+    recv[k] = c->d_xrecv[k];
+  }
+  COMMCHK(c->comm.alltoallv_u64(c->comm.ctx, 3, send, sc.data(), recv, rcnt.data()), "all-to-all of the mailboxes");   // collective 2
+  for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_shard_merge, T, 64, cfg, k, (const u64 *)c->d_xrecv[k], (const u32 *)c->d_cglob);
+  // ---- growth (every rank sees the same demand: the replicas are exact), insert phase of own owners
+  if (small[0] * 2 > c->gs_cap && (rc = grow_global(c, cfg.g_s, c->gs_cap, pow2_at_least(small[0] * 2 + 2)))) return rc;
+  if (small[1] * 2 > c->gb_cap && (rc = grow_global(c, cfg.g_b, c->gb_cap, pow2_at_least(small[1] * 2 + 2)))) return rc;
+  if ((rc = d2d(c, c->d_small, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
+  LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
+  // ---- one all-gather: the applied items of every kind (padded to the largest rank's), the p-mer statistics, the triples
+  u64 M[3] = {0, 0, 0}, PM = 0;
+  std::vector<u64> n_items(3ull * G, 0), pe_tot(G, 0);
+  for (u32 k = 0; k < 3; ++k)
+    for (u32 q = 0; q < G; ++q) {
+      for (u32 f = 0; f < G; ++f) n_items[(u64)k * G + q] += vol[((u64)k * G + f) * G + q];
+      M[k] = std::max(M[k], n_items[(u64)k * G + q]);
+    }
+  if (c->paired)
+    for (u32 s = 0; s < T; ++s) { pe_tot[s % G] += C[3ull * T * T + s]; PM = std::max(PM, pe_tot[s % G]); }
+  const u64 off_k[3] = {0, M[0], M[0] + M[1]}, off_siv = M[0] + M[1] + M[2], off_pe = off_siv + 2, W = off_pe + 3 * PM;
+  if ((rc = xbuf_fit(c, c->d_items, c->items_cap, W))) return rc;
+  if ((rc = xbuf_fit(c, c->d_gathered, c->gathered_cap, W * G))) return rc;
+  for (u32 k = 0; k < 3; ++k)
+    if (n_items[(u64)k * G + me]) LAUNCH(c, 2, k_shard_collect, REHASH_GRID, 256, cfg, k, c->d_items + off_k[k]);
+  LAUNCH(c, 2, k_shard_siv_delta, 1, 64, cfg, (const u64 *)c->d_small, c->d_items + off_siv);
+  if (c->paired && PM) LAUNCH(c, 2, k_shard_pe_pack, T, 64, cfg, c->d_items + off_pe);
+  COMMCHK(c->comm.allgather_u64(c->comm.ctx, c->d_items, W, c->d_gathered), "all-gather of the applied items");   // collective 3
+  c->sh_gather_words += W * (G - 1);
+  for (u32 q = 0; q < G; ++q)
+    if (q != me || c->shard_apply_own)
+      for (u32 k = 0; k < 3; ++k)
+        if (n_items[(u64)k * G + q]) LAUNCH(c, 2, k_shard_apply, REHASH_GRID, 256, cfg, k, (const u64 *)(c->d_gathered + (u64)q * W + off_k[k]), (u32)n_items[(u64)k * G + q]);
+  LAUNCH(c, 2, k_shard_siv_sum, 1, 64, cfg, (const u64 *)c->d_small, (const u64 *)c->d_gathered, W, off_siv);
+  // ---- paired-end: every rank applies every source's triples to its replica of the pair table
+  if (c->paired) {
+    if (G > 1 && PM) LAUNCH(c, 2, k_shard_pe_unpack, T, 64, cfg, (const u64 *)c->d_gathered, W, off_pe, (const u32 *)(c->d_cglob + 3ull * T * T));
+    LAUNCH(c, 2, k_pe_demand, T, 64, cfg, c->d_demand);
+    if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, T * sizeof(u32)))) return rc;
+    if ((rc = d2h_sync(c, c->h_filled.data(), cfg.g_pe.filled, T * sizeof(u32)))) return rc;
+    u64 need = 0;
+    for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_filled[o] + c->h_demand[o]);
+    if (need * 2 > c->gpe_cap && (rc = grow_gpe(c, pow2_at_least(need * 2 + 2)))) return rc;
+    LAUNCH(c, 2, k_pe_insert, T, 64, cfg);
+    if ((rc = dzero(c, cfg.l_pe.key, c->cur_need_lpe * T * sizeof(u64)))) return rc;
+    if ((rc = dzero(c, cfg.l_pe.val, c->cur_need_lpe * T * sizeof(u64)))) return rc;
+    if ((rc = dzero(c, cfg.l_pe.filled, T * sizeof(u32)))) return rc;
+    c->filled_valid = false;   // (h_filled was borrowed for the pair table's occupancies)
+  }
+  c->sh_phases += 1;
+  c->sh_collectives += 3;
+  return clear_local_tables(c);
+}
+}  // namespace
+
+int fqsx_shard_attach(fqsx_dna *c, uint32_t rank, uint32_t world, const fqsx_comm *comm) {
+  if (!c || !comm || !comm->allreduce_sum_u32 || !comm->alltoallv_u64 || !comm->allgather_u64) { g_err = "incomplete transport"; return FQSX_E_ARG; }
+  int rc = fqsx_shard_config(c, rank, world);
+  if (rc) return rc;
+  c->comm = *comm;
+  c->comm_set = true;
+  if (const char *e = getenv("FQSX_SHARD_APPLY_OWN")) c->shard_apply_own = atoi(e) != 0;   // (tests: the replica update on this rank's own items must change nothing)
+  return FQSX_OK;
+}
+
+int fqsx_shard_encode_block(fqsx_dna *c, const uint8_t *bases, const uint64_t *off, const uint64_t *h_off, uint32_t n_reads,
+                            uint32_t generation, const uint8_t **streams, uint64_t *lens) {
+  if (!c || !bases || !off || !h_off || !streams || !lens) { g_err = "null argument"; return FQSX_E_ARG; }
+  if (!c->comm_set) { g_err = "no transport attached (fqsx_shard_attach)"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  int rc = block_prepare(c, bases, off, h_off, n_reads, generation);
+  for (u32 seg = 0; !rc && seg <= c->cur_S; ++seg) rc = shard_phase_native(c, seg);
+  if (rc) return rc;
+  return block_finish(c, h_off, streams, lens, nullptr);
+}
+
+int fqsx_shard_traffic(fqsx_dna *c, uint64_t out[4]) {
+  if (!c || !out) return FQSX_E_ARG;
+  out[0] = c->sh_phases; out[1] = c->sh_collectives; out[2] = c->sh_a2a_words; out[3] = c->sh_gather_words;
+  return FQSX_OK;
+}
+
+// ---- RCCL transport (loaded on first use: the library itself does not link against librccl) ---------------------------
+#ifndef FQSX_EMU
+namespace {
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+bool rccl_load() {
+  if (g_rccl.lib) return true;
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { g_err = std::string("librccl not found: ") + dlerror(); return false; }
+#define RSYM(field, name) do { *(void **)&g_rccl.field = dlsym(h, name); if (!g_rccl.field) { g_err = std::string("librccl lacks ") + name; return false; } } while (0)
+  RSYM(GetUniqueId, "ncclGetUniqueId"); RSYM(CommInitRank, "ncclCommInitRank"); RSYM(CommDestroy, "ncclCommDestroy");
+  RSYM(AllReduce, "ncclAllReduce"); RSYM(AllGather, "ncclAllGather"); RSYM(Send, "ncclSend"); RSYM(Recv, "ncclRecv");
+  RSYM(GroupStart, "ncclGroupStart"); RSYM(GroupEnd, "ncclGroupEnd"); RSYM(GetErrorString, "ncclGetErrorString");
+#undef RSYM
+  g_rccl.lib = h;
+  return true;
+}
+struct RcclCtx { ncclComm_t comm; hipStream_t stream; u32 world; };
+#define NCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { g_err = std::string(#x) + ": " + g_rccl.GetErrorString(r_); return 1; } } while (0)
+int rccl_allreduce(void *ctx, uint32_t *buf, uint64_t n) {
+  RcclCtx *x = (RcclCtx *)ctx;
+  NCHK(g_rccl.AllReduce(buf, buf, n, ncclUint32, ncclSum, x->comm, x->stream));
+  return 0;
+}
+int rccl_alltoallv(void *ctx, uint32_t n_buf, const uint64_t *const *send, const uint64_t *sc, uint64_t *const *recv, const uint64_t *rcnt) {
+  RcclCtx *x = (RcclCtx *)ctx;
+  NCHK(g_rccl.GroupStart());
+  for (u32 b = 0; b < n_buf; ++b) {
+    u64 so = 0, ro = 0;
+    for (u32 r = 0; r < x->world; ++r) {
+      const u64 ns = sc[(u64)b * x->world + r], nr = rcnt[(u64)b * x->world + r];
+      if (ns) NCHK(g_rccl.Send(send[b] + so, ns, ncclUint64, (int)r, x->comm, x->stream));
+      if (nr) NCHK(g_rccl.Recv(recv[b] + ro, nr, ncclUint64, (int)r, x->comm, x->stream));
+      so += ns; ro += nr;
+    }
+  }
+  NCHK(g_rccl.GroupEnd());
+  return 0;
+}
+int rccl_allgather(void *ctx, const uint64_t *send, uint64_t n, uint64_t *recv) {
+  RcclCtx *x = (RcclCtx *)ctx;
+  NCHK(g_rccl.AllGather(send, recv, n, ncclUint64, x->comm, x->stream));
+  return 0;
+}
+}  // namespace
+#endif
+
+int fqsx_rccl_unique_id(uint8_t id[128]) {
+#ifndef FQSX_EMU
+  if (!id) return FQSX_E_ARG;
+  if (!rccl_load()) return FQSX_E_HIP;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId u;
+  if (g_rccl.GetUniqueId(&u) != ncclSuccess) { g_err = "ncclGetUniqueId failed"; return FQSX_E_HIP; }
+  memcpy(id, &u, 128);
+  return FQSX_OK;
+#else
+  (void)id;
+  g_err = "the emulation build has no RCCL transport";
+  return FQSX_E_NO_DEVICE;
+#endif
+}
+int fqsx_rccl_comm_create(fqsx_dna *c, const uint8_t id[128], uint32_t rank, uint32_t world, fqsx_comm *out) {
+#ifndef FQSX_EMU
+  if (!c || !id || !out || world == 0 || rank >= world) { g_err = "bad argument"; return FQSX_E_ARG; }
+  if (!rccl_load()) return FQSX_E_HIP;
+  HIPCHK(hipSetDevice(c->device));
+  ncclUniqueId u;
+  memcpy(&u, id, 128);
+  RcclCtx *x = new RcclCtx();
+  x->stream = c->stream;
+  x->world = world;
+  ncclResult_t r = g_rccl.CommInitRank(&x->comm, (int)world, u, (int)rank);
+  if (r != ncclSuccess) { g_err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); delete x; return FQSX_E_HIP; }
+  out->ctx = x;
+  out->allreduce_sum_u32 = rccl_allreduce;
+  out->alltoallv_u64 = rccl_alltoallv;
+  out->allgather_u64 = rccl_allgather;
+  return FQSX_OK;
+#else
+  (void)c; (void)id; (void)rank; (void)world; (void)out;
+  g_err = "the emulation build has no RCCL transport";
+  return FQSX_E_NO_DEVICE;
+#endif
+}
+void fqsx_rccl_comm_destroy(fqsx_comm *m) {
+#ifndef FQSX_EMU
+  if (!m || !m->ctx) return;
+  RcclCtx *x = (RcclCtx *)m->ctx;
+  if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(x->comm);
+  delete x;
+  m->ctx = nullptr;
+#else
+  (void)m;
+#endif
 }
 
 int fqsx_dna_stats(fqsx_dna *c, uint64_t out[64]) {

@@ -4141,7 +4141,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   // load state
   FQ_SYNC();
   mt_copy((u64 *)&sm->mt[0][0], (const u64 *)&ws->mt[0][0]);
-  if (FQ_LANE < 4) sm->mt_idx[FQ_LANE] = ws->mt_idx[FQ_LANE];
+  for (u32 g = FQ_LANE; g < 4; g += FQ_WAVE) sm->mt_idx[g] = ws->mt_idx[g];
   w.mn[0] = w.mn[1] = w.mn[2] = 0;
   {  // avg_filling_factor (bit_vec.h:204-210) only changes in insert phases (dna.cpp:2416-2418)
     u64 nu = cfg.siv_stats[0], nf = cfg.siv_stats[1];
@@ -4251,7 +4251,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   }
   FQ_SYNC();
   mt_copy((u64 *)&ws->mt[0][0], (const u64 *)&sm->mt[0][0]);
-  if (FQ_LANE < 4) ws->mt_idx[FQ_LANE] = sm->mt_idx[FQ_LANE];
+  for (u32 g = FQ_LANE; g < 4; g += FQ_WAVE) ws->mt_idx[g] = sm->mt_idx[g];
   for (u32 k = 0; k < 3; ++k) cfg.mail[k].n[tid] = w.mn[k];
   if (paired) cfg.pe_n[tid] = w.pe_n;
   if (w.err) *cfg.err = w.err;

@@ -29,6 +29,11 @@ int fqsx_launch_encode_pe(hipStream_t s, const EncArgs &a) {
 static void fqsx_emu_encode_pe(const EncArgs &a) {
   for (u32 b = 0; b < a.cfg.T; ++b) {
     fq_emu_block = b;
+    if (!shard_mine(a.cfg, b)) {   // sharded run: a worker that lives on another rank only reports empty lists here
+      for (u32 k = 0; k < 3; ++k) a.cfg.mail[k].n[b] = 0;
+      a.cfg.pe_n[b] = 0;
+      continue;
+    }
     if (a.cfg.mode == 2) encode_segment_body<2, false, false>(a.cfg, fq_wg(), b, a.n_reads, a.S, a.seg);
     else encode_segment_body<3, false, false>(a.cfg, fq_wg(), b, a.n_reads, a.S, a.seg);
   }

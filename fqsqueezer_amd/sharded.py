@@ -138,3 +138,133 @@ class ShardedDnaCodec:
 
     def close(self) -> None:
         self.codec.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The native driver: the phase loop lives in libfqsx.so (fqsx_shard_encode_block), three collectives and one host round
+# trip per phase, single- and paired-end.  The transport is a C struct of three functions (include/fqsx.h: fqsx_comm):
+#   * RCCL inside the library, on the codec's own stream (fqsx_rccl_comm_create) -- the product path on MI355X;
+#   * callbacks into torch.distributed on buffers in host memory -- what the gloo tests run with the emulation build.
+class _Comm(C.Structure):
+    _AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
+    _A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64))
+    _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+    _fields_ = [("ctx", C.c_void_p), ("allreduce_sum_u32", _AR), ("alltoallv_u64", _A2A), ("allgather_u64", _AG)]
+
+
+def _host_tensor(addr: int, n: int, ctype, dtype) -> torch.Tensor:
+    """n elements at a host address as a tensor that shares the memory"""
+    return torch.from_numpy(np.ctypeslib.as_array((ctype * max(n, 1)).from_address(addr))[:n]).view(dtype)
+
+
+def _torch_comm(world: int, group=None) -> _Comm:
+    """fqsx_comm over torch.distributed for a codec whose memory space is host memory (the emulation build)."""
+    def allreduce(_ctx, buf, n):
+        try:
+            dist.all_reduce(_host_tensor(buf, n, C.c_uint32, torch.int32), op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception as e:   # noqa: BLE001 -- reported through the C ABI
+            print("fqsx transport:", e)
+            return 1
+
+    def alltoallv(_ctx, n_buf, send, scnt, recv, rcnt):
+        try:
+            for b in range(n_buf):
+                n_out = [int(scnt[b * world + r]) for r in range(world)]
+                n_in = [int(rcnt[b * world + r]) for r in range(world)]
+                s = _host_tensor(send[b], sum(n_out), C.c_uint64, torch.int64)
+                r = _host_tensor(recv[b], sum(n_in), C.c_uint64, torch.int64)
+                dist.all_to_all_single(r, s, n_in, n_out, group=group)
+            return 0
+        except Exception as e:   # noqa: BLE001
+            print("fqsx transport:", e)
+            return 1
+
+    def allgather(_ctx, send, n, recv):
+        try:
+            out = _host_tensor(recv, n * world, C.c_uint64, torch.int64)
+            dist.all_gather_into_tensor(out, _host_tensor(send, n, C.c_uint64, torch.int64).clone(), group=group)
+            return 0
+        except Exception as e:   # noqa: BLE001
+            print("fqsx transport:", e)
+            return 1
+
+    return _Comm(None, _Comm._AR(allreduce), _Comm._A2A(alltoallv), _Comm._AG(allgather))
+
+
+class NativeShardedDnaCodec:
+    """One file's DNA path over `world` ranks with the phase loop inside the library (fqsx_shard_encode_block).
+    transport = "rccl": RCCL on the codec's stream; `id_bytes` = the 128-byte id rank 0 made with rccl_unique_id() and
+    every rank received (e.g. through torch.distributed's store).  transport = "torch": torch.distributed collectives on
+    host buffers (gloo; emulation build)."""
+
+    def __init__(self, header: bytes, rank: int, world: int, device: int = 0, lib_path: Optional[str] = None, transport: str = "rccl",
+                 id_bytes: Optional[bytes] = None, group=None):
+        self.codec = DnaCodec(header, device=device, lib_path=lib_path)
+        self._lib, self._h, self.T = self.codec._lib, self.codec._h, self.codec.T
+        self.rank, self.world, self.device = rank, world, device
+        L = self._lib
+        L.fqsx_shard_attach.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(_Comm)]
+        L.fqsx_shard_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.fqsx_shard_traffic.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.fqsx_rccl_comm_create.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(_Comm)]
+        L.fqsx_rccl_comm_destroy.argtypes = [C.POINTER(_Comm)]
+        self._rccl = transport == "rccl"
+        if self._rccl:
+            if id_bytes is None or len(id_bytes) != 128:
+                raise ValueError("the RCCL transport needs the 128-byte unique id (rccl_unique_id on rank 0)")
+            self._comm = _Comm()
+            self._ck(L.fqsx_rccl_comm_create(self._h, bytes(id_bytes), rank, world, C.byref(self._comm)), "fqsx_rccl_comm_create")
+        else:
+            self._comm = _torch_comm(world, group)
+        self._ck(L.fqsx_shard_attach(self._h, rank, world, C.byref(self._comm)), "fqsx_shard_attach")
+        self.own_workers = list(range(rank, self.T, world))
+        self._streams = (C.c_void_p * self.T)()
+        self._lens = (C.c_uint64 * self.T)()
+
+    @staticmethod
+    def rccl_unique_id(lib_path: Optional[str] = None) -> bytes:
+        from .codec import load_library
+        lib = load_library(lib_path)
+        buf = C.create_string_buffer(128)
+        lib.fqsx_rccl_unique_id.argtypes = [C.c_char_p]
+        if lib.fqsx_rccl_unique_id(buf):
+            raise FqsxError(f"fqsx_rccl_unique_id: {lib.fqsx_last_error().decode()}")
+        return buf.raw
+
+    def _ck(self, rc: int, what: str) -> None:
+        if rc:
+            raise FqsxError(f"{what}: {rc}: {self._lib.fqsx_last_error().decode()}")
+
+    def encode_block(self, bases: np.ndarray, read_off: np.ndarray, generation: int) -> Dict[int, bytes]:
+        """All ranks call this with the same block; returns {worker: DNA stream} for this rank's workers."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        if self._rccl:   # the codec's memory space is HBM
+            dev = torch.device("cuda", self.device)
+            t_b, t_o = torch.from_numpy(bases).to(dev), torch.from_numpy(read_off.view(np.int64)).to(dev)
+            torch.cuda.synchronize(dev)
+            pb, po = t_b.data_ptr(), t_o.data_ptr()
+        else:
+            pb, po = bases.ctypes.data, read_off.ctypes.data
+        self._ck(self._lib.fqsx_shard_encode_block(self._h, pb, po, read_off.ctypes.data, len(read_off) - 1, generation, self._streams, self._lens),
+                 "fqsx_shard_encode_block")
+        return {w: (C.string_at(self._streams[w], self._lens[w]) if self._lens[w] else b"") for w in self.own_workers}
+
+    def encode_block_dev(self, d_bases_ptr: int, d_off_ptr: int, read_off: np.ndarray, generation: int) -> int:
+        """block already in HBM; returns the bytes of this rank's streams"""
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        self._ck(self._lib.fqsx_shard_encode_block(self._h, d_bases_ptr, d_off_ptr, read_off.ctypes.data, len(read_off) - 1, generation, self._streams, self._lens),
+                 "fqsx_shard_encode_block")
+        return sum(self._lens[w] for w in self.own_workers)
+
+    @property
+    def traffic(self) -> dict:
+        a = (C.c_uint64 * 4)()
+        self._lib.fqsx_shard_traffic(self._h, a)
+        return {"phases": a[0], "collectives": a[1], "all_to_all_bytes": 8 * a[2], "all_gather_bytes": 8 * a[3]}
+
+    def close(self) -> None:
+        if self._rccl and self._comm.ctx:
+            self._lib.fqsx_rccl_comm_destroy(C.byref(self._comm))
+        self.codec.close()

@@ -30,6 +30,22 @@ extern "C" {
 
 typedef struct fqsx_dna fqsx_dna;
 
+/* Transport of the sharded mode: the collectives among the `world` ranks (one process per GPU) that share one file, on
+ * buffers in the codec's memory space (device memory).  fqsx_rccl_comm_create gives the RCCL one (xGMI inside a node);
+ * a caller with a transport of its own (MPI, a test harness) fills in the three functions.  Each returns 0 on success
+ * and may return before the operation has completed as long as later work on the codec's stream waits for it. */
+typedef struct fqsx_comm {
+  void *ctx;
+  /* in-place sum over the ranks of n 32-bit words */
+  int (*allreduce_sum_u32)(void *ctx, uint32_t *buf, uint64_t n);
+  /* n_buf variable all-to-alls of 64-bit words in one go: buffer b sends send_counts[b * world + r] words to rank r (the
+   * parts lie back to back in send[b], in rank order) and receives recv_counts[b * world + q] words from rank q likewise */
+  int (*alltoallv_u64)(void *ctx, uint32_t n_buf, const uint64_t *const *send, const uint64_t *send_counts,
+                       uint64_t *const *recv, const uint64_t *recv_counts);
+  /* every rank contributes n 64-bit words; recv = [world][n] */
+  int (*allgather_u64)(void *ctx, const uint64_t *send, uint64_t n, uint64_t *recv);
+} fqsx_comm;
+
 enum {
   FQSX_OK = 0,
   FQSX_E_ARG = -1,        /* bad argument / malformed header / unsupported dna_mode */
@@ -109,6 +125,23 @@ int fqsx_shard_insert(fqsx_dna *, uint64_t need_s, uint64_t need_b, uint64_t *co
 int fqsx_shard_apply(fqsx_dna *, uint32_t kind, const uint64_t *items /*[codec]*/, uint64_t n);
 int fqsx_shard_end_phase(fqsx_dna *, const uint64_t siv_delta_sum[2]);
 int fqsx_shard_finish_block(fqsx_dna *, const uint64_t *h_read_off, const uint8_t **streams, uint64_t *lens);
+
+/* The same phase loop inside the library (the reference's phase is three barrier waits, fqs/application.cpp:643-655):
+ * fqsx_shard_attach = fqsx_shard_config + the transport; fqsx_shard_encode_block runs a whole reads block -- per phase three
+ * collectives (all-reduce of the count matrix; the three mailboxes in one grouped all-to-all; one all-gather carrying the
+ * applied items, the p-mer statistics and, paired-end, the pair-table triples) and one host round trip (transfer sizes,
+ * table demand, error word).  All four dna_modes.  bases / read_off: the block in the codec's memory space, the same on
+ * every rank; streams[w] / lens[w] are meaningful for this rank's workers (w % world == rank).
+ * fqsx_shard_traffic: [0] phases [1] collectives issued [2] all-to-all words sent to other ranks [3] all-gather words sent. */
+int fqsx_shard_attach(fqsx_dna *, uint32_t rank, uint32_t world, const fqsx_comm *comm);
+int fqsx_shard_encode_block(fqsx_dna *, const uint8_t *bases /*[codec]*/, const uint64_t *read_off /*[codec]*/, const uint64_t *h_read_off,
+                            uint32_t n_reads, uint32_t generation, const uint8_t **streams, uint64_t *lens);
+int fqsx_shard_traffic(fqsx_dna *, uint64_t out[4]);
+/* RCCL transport on the codec's own stream (collectives and kernels are ordered by the stream; librccl is loaded on first
+ * use).  Rank 0 calls fqsx_rccl_unique_id and hands the 128 bytes to the other ranks by any means (a file, a TCP store). */
+int fqsx_rccl_unique_id(uint8_t id[128]);
+int fqsx_rccl_comm_create(fqsx_dna *, const uint8_t id[128], uint32_t rank, uint32_t world, fqsx_comm *out);
+void fqsx_rccl_comm_destroy(fqsx_comm *);
 
 /* Kernel timing: when enabled every launch is bracketed by HIP events on the codec's stream.
  * out[0..2] = accumulated milliseconds of the encode-segment, insert-phase and all other

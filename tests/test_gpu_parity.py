@@ -202,6 +202,39 @@ def test_sharded_path_on_the_gpu_matches_plain_run():
     dist.destroy_process_group()
 
 
+def test_native_sharded_driver_on_the_gpu_over_rccl():
+    """fqsx_shard_encode_block with the RCCL transport inside the library (a world of one rank: every collective runs through
+    librccl on the codec's stream, every kernel of the native phase loop runs), single- and paired-end, with the replica
+    update on the rank's own items switched on.  The multi-rank exchange is covered on CPU (tests/test_sharded_cpu.py)."""
+    from fqsqueezer_amd.sharded import NativeShardedDnaCodec
+    from fqsqueezer_amd.synth import synth_reads
+    os.environ["FQSX_SHARD_APPLY_OWN"] = "1"
+    try:
+        reads = synth_reads(20000, 100, 150000, 37)
+        rec = hp.Records([b"@r%d" % i for i in range(len(reads))], reads, reads)
+        header = hp.make_header(16, "se_sorted", 1)
+        sh = NativeShardedDnaCodec(header, 0, 1, device=0, transport="rccl", id_bytes=NativeShardedDnaCodec.rccl_unique_id())
+        one = gpu(header)
+        for g, idx in enumerate(hp.form_blocks(rec, "se_sorted")[:60]):
+            bases, off = hp.block_arrays(rec, idx)
+            mine, ref = sh.encode_block(bases, off, g), one.encode_block(bases, off, g)
+            assert [mine[w] for w in range(16)] == ref, f"block {g}"
+        tr = sh.traffic
+        assert tr["phases"] >= 60 and tr["collectives"] == 3 * tr["phases"]
+        sh.close()
+        rec1, rec2 = c5_records()
+        header = hp.make_header(8, "pe_sorted", 1)
+        sh = NativeShardedDnaCodec(header, 0, 1, device=0, transport="rccl", id_bytes=NativeShardedDnaCodec.rccl_unique_id())
+        one = gpu(header)
+        for g, idx in enumerate(hp.form_blocks_pe(rec1, rec2, "pe_sorted")[:30]):
+            bases, off = hp.block_arrays_pe(rec1, rec2, idx)
+            mine, ref = sh.encode_block(bases, off, g), one.encode_block(bases, off, g)
+            assert [mine[w] for w in range(8)] == ref, f"paired-end block {g}"
+        sh.close()
+    finally:
+        os.environ.pop("FQSX_SHARD_APPLY_OWN", None)
+
+
 def test_device_and_host_entry_points_agree():
     import torch
     rec = c1_records()

@@ -56,3 +56,61 @@ def test_sharded_streams_identical_to_one_process_run(tmp_path, built, world, T,
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "SHARDED_OK" in r.stdout
+
+
+# ---- the native driver (fqsx_shard_encode_block: phase loop inside the library, three collectives per phase) over a
+# callback transport into torch.distributed / gloo, single- and paired-end
+NATIVE_WORKER = r'''
+import os, sys, hashlib
+sys.path.insert(0, os.environ["FQSX_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.codec import DnaCodec
+from fqsqueezer_amd.sharded import NativeShardedDnaCodec
+from fqsqueezer_amd.synth import synth_pairs, synth_reads
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = os.environ["FQSX_EMU_LIB"]
+T, mode = int(os.environ["FQSX_T"]), os.environ["FQSX_MODE"]
+header = hp.make_header(T, mode, 1)
+if mode.startswith("pe"):
+    r1, r2 = synth_pairs(2500, 90, 40000, 33)
+    rec1 = hp.Records([b"@a%d" % i for i in range(len(r1))], r1, r1)
+    rec2 = hp.Records([b"@b%d" % i for i in range(len(r2))], r2, r2)
+    order = np.concatenate(hp.sorted_order_exact(rec1)) if mode == "pe_sorted" else np.arange(len(r1))
+    blocks = [hp.block_arrays_pe(rec1, rec2, order[lo:lo + 300]) for lo in range(0, len(order), 300)]
+else:
+    reads = synth_reads(6000, 90, 40000, 31)
+    rec = hp.Records([b"@r%d" % i for i in range(len(reads))], reads, reads)
+    order = np.concatenate(hp.sorted_order(rec)) if mode == "se_sorted" else np.arange(len(reads))
+    blocks = [hp.block_arrays(rec, order[lo:lo + 600]) for lo in range(0, len(order), 600)]
+sh = NativeShardedDnaCodec(header, rank, world, lib_path=lib, transport="torch")
+one = DnaCodec(header, lib_path=lib)                # the one-process run, for comparison (every rank runs it)
+for g, (bases, off) in enumerate(blocks):
+    mine = sh.encode_block(bases, off, g)
+    ref = one.encode_block(bases, off, g)
+    assert sorted(mine) == list(range(rank, T, world))
+    for w, s in mine.items():
+        assert s == ref[w], f"rank {rank}: block {g} worker {w} differs from the one-process run"
+tr = sh.traffic
+assert tr["collectives"] == 3 * tr["phases"] and tr["phases"] > len(blocks)
+lst = [None] * world
+dist.all_gather_object(lst, tr)
+if rank == 0:
+    assert tr["all_to_all_bytes"] > 0 and tr["all_gather_bytes"] > 0
+    print("NATIVE_SHARDED_OK", world, T, mode, lst[0])
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,T,mode,port", [(2, 5, "se_sorted", 29533), (3, 4, "se_original", 29534), (2, 4, "pe_sorted", 29535), (3, 5, "pe_original", 29536)])
+def test_native_sharded_driver_streams_identical_to_one_process_run(tmp_path, built, world, T, mode, port):
+    script = tmp_path / "w.py"
+    script.write_text(NATIVE_WORKER)
+    env = dict(os.environ, FQSX_ROOT=ROOT, FQSX_EMU_LIB=os.path.join(ROOT, "tests", "emu", "libfqsx_emu.so"), FQSX_T=str(T), FQSX_MODE=mode,
+               FQSX_SHARD_APPLY_OWN="1" if world == 2 else "0")   # (world 2 also applies the rank's own items to its replica: must change nothing)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:] + r.stderr[-3000:])
+    assert "NATIVE_SHARDED_OK" in r.stdout
