@@ -8,6 +8,80 @@
 // insert phases are shared with the encoder, which is what makes the decoder rebuild identical state.
 #pragma once
 
+// find_rc_code_context / find_rc_letters_context (dna.cpp:2107-2286) for the decoder, whose chain per symbol is two or
+// three DEPENDENT context-table round trips in find_leveled: here every level's slot is looked up at once, one level per
+// lane (read-only: the table cannot change in between, the wave is the worker's only writer), and the level search then
+// walks the cached answers.  Same decisions, same stores, same creations / clones as find_leveled.
+FQ_DEV u32 dec_level_get(WgShared *sm, u32 l, Slot4 &s, const u64 *lev, u64 rs) {
+  const u32 idx = sm->fr_idx[l];
+  if (idx == FQSX_NIL) return FQSX_NIL;
+  s.q0 = LEVKEY(l); s.q1 = sm->fr_q1[l]; s.q2 = sm->fr_q2[l]; s.q3 = sm->fr_q3[l];
+  return idx;
+}
+FQ_DEV u32 find_leveled_dec(Wk &w, u32 tag, const u64 *lev, u64 rs, int n_levels, double &avg, u64 tpl_q2, u64 tpl_q3, u32 tpl_total, Slot4 &s) {
+  WgShared *sm = w.sm;
+  FQ_SYNC();
+  for (u32 l = FQ_LANE; l < (u32)n_levels; l += FQ_WAVE) {
+    u32 vis = 0;
+    const RoHit h = ctx_probe_ro(w, tag, LEVKEY(l), vis);
+    sm->fr_idx[l] = h.present ? h.idx : FQSX_NIL;
+    sm->fr_q1[l] = h.q1; sm->fr_q2[l] = h.q2; sm->fr_q3[l] = h.q3;
+    sm->fr_vis[l] = vis;
+  }
+  FQ_SYNC();
+  int i;
+  Slot4 q;
+  const bool letters = tag == 2;
+  int start = (int)(avg + 0.49);
+  u32 p = dec_level_get(sm, (u32)start, s, lev, rs);
+  w.st[ST_CTX] += sm->fr_vis[start];
+  if (p != FQSX_NIL && slot_counter(s) < (letters ? letters_thr(start) : code_thr(start))) {
+    ctx_store_counter(w, p, s, slot_counter(s) + 1);
+    avg = ema_update(avg, (double)start);
+    return p;
+  }
+  if (p == FQSX_NIL) {
+    for (i = start - 1; i >= 0; --i) {
+      p = dec_level_get(sm, (u32)i, s, lev, rs);
+      w.st[ST_CTX] += sm->fr_vis[i];
+      if (p != FQSX_NIL) break;
+    }
+  } else {
+    for (i = start + 1; i < n_levels; ++i) {
+      u32 qi = dec_level_get(sm, (u32)i, q, lev, rs);
+      w.st[ST_CTX] += sm->fr_vis[i];
+      if (qi == FQSX_NIL) break;
+      if (slot_counter(q) < code_thr(i)) {  // both routines use the *code* thresholds here (quirk, dna.cpp:2244)
+        avg = ema_update(avg, (double)i);
+        ctx_store_counter(w, qi, q, slot_counter(q) + 1);
+        s = q;
+        return qi;
+      }
+      p = qi;
+      s = q;
+    }
+    --i;
+  }
+  if (p == FQSX_NIL) {  // nothing known: create level 0 from the template
+    p = ctx_insert(w, tag, LEVKEY(0), tpl_q2, tpl_q3, tpl_total, s);
+    if (p == FQSX_NIL) return p;
+    ctx_store_counter(w, p, s, slot_counter(s) + 1);
+    i = 0;
+  }
+  if (slot_counter(s) >= code_thr(i) && i + 1 < n_levels) {  // clone into the next level (dna.cpp:2177-2184)
+    u32 total = (u32)(s.q1 >> 48);
+    Slot4 c;
+    u32 ci = ctx_insert(w, tag, LEVKEY(i + 1), s.q2, s.q3, total, c);
+    if (ci == FQSX_NIL) return ci;
+    ctx_store_counter(w, ci, c, slot_counter(c) + 1);
+    s = c;
+    p = ci;
+  } else
+    ctx_store_counter(w, p, s, slot_counter(s) + 1);
+  avg = ema_update(avg, (double)i);
+  return p;
+}
+
 // the worker's reads are decoded into 0..4 codes in a per-worker HBM scratch line (codes) and written as
 // ASCII to the output block; a second line holds the reverse-complement part of an anchored second mate
 FQ_DEV u8 dec_alpha(u32 sym) { return sym == 0 ? 'A' : sym == 1 ? 'C' : sym == 2 ? 'G' : sym == 3 ? 'T' : 'N'; }
@@ -139,7 +213,7 @@ FQ_DEV u32 dec_letter(Wk &w, const u8 *codes, u32 pos, u32 read_len, u32 hist_st
   for (u32 l = 0; l < 10; ++l) w.sm->lev_tmp[l] = lev[l];
   FQ_SYNC();
   Slot4 s;
-  u32 idx = find_leveled(w, 2, w.sm->lev_tmp, 0, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
+  u32 idx = find_leveled_dec(w, 2, w.sm->lev_tmp, 0, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
   return idx != FQSX_NIL ? slot_decode(w, idx, s) : 0;
 }
 FQ_DEV u32 dec_un_rank(const Wk &w, const C4 &counts, u32 r) {  // un_rank, dna.cpp:197-207
@@ -158,11 +232,49 @@ FQ_DEV void suffix_dec(Wk &w, u8 *codes, u8 *p_out, u32 size, bool original_orde
   const DevCfg *cfg = w.cfg;
   WgShared *sm = w.sm;
   u64 ctx_r_sym = 0;
+  // The cluster a b-mer look-up starts in is fixed by the k-mer's kernel (symbols 2 .. k-3), so the look-up of position
+  // i + 1 -- sub-table, home slot, orientation -- is known before symbol i is decoded: its first two slots are requested
+  // while the context search and the range decoder of position i run, and matched against the full k-mer afterwards.
+  TabIt nf;
+  nf.s = nullptr; nf.p = 0; nf.it0 = nf.it1 = 0;
   for (u32 i = start_pos ? start_pos : original_order ? cfg->prefix : cfg->pmer; i < size && !w.err; ++i) {
     km_insert_zero(w.pm, cfg->gp); km_insert_zero(w.sm_, cfg->gs); km_insert_zero(w.bm, cfg->gb);
     km_insert_zero(w.pm_u, cfg->gp); km_insert_zero(w.sm_u, cfg->gs); km_insert_zero(w.bm_u, cfg->gb);
     C4 counts;
-    u32 level = find_counts(w, counts, false);
+    u32 level;
+    TM_BEGIN(t_fc);
+    if (km_full(w.bm, cfg->gb)) {   // find_counts' first look-up (dna.cpp:461-476), with the slots requested a position ahead
+      const bool nd = km_norm_dir(w.bm, cfg->gb);
+      const u64 key = nd ? w.bm.dir : w.bm.rc;
+      const u32 sub = sb_owner(cfg, key);
+      const u64 *sl = cfg->g_b.slots + (u64)sub * cfg->g_b.stride;
+      u64 ns = 0;
+      c4_zero(counts);
+      if (nf.s == sl && nf.p == tab_home(cfg->g_b, key >> (64 - 2 * cfg->g_b.k))) tab_rest(cfg->g_b, nf, key, nd, counts, ns);
+      else tab_scan(cfg->g_b, sub, key, nd, counts, ns);   // (a correction changed the k-mer's kernel: ask again)
+      w.st[ST_GPROBE] += 1;
+      w.st[ST_GSLOT] += ns;
+      if (c4_any(counts)) {
+        level = LV_BMER;
+        if ((counts.c[0] == 63) + (counts.c[1] == 63) + (counts.c[2] == 63) + (counts.c[3] == 63) > 1) {
+          C4 c2;
+          kt_find(w, cfg->g_s, true, cfg->gs, w.sm_, RNG_S, CINC_S, c2);
+          counts.c[0] += c2.c[0]; counts.c[1] += c2.c[1]; counts.c[2] += c2.c[2]; counts.c[3] += c2.c[3];
+          level = LV_MIXED;
+        }
+      } else
+        level = find_counts(w, counts, true);
+    } else
+      level = find_counts(w, counts, false);
+    nf.s = nullptr;
+    if (w.bm.cur + 1 >= cfg->gb.k && i + 1 < size) {   // the next position's b-mer will be full: request its cluster's first slots
+      Kmer nb = w.bm;
+      km_insert_zero(nb, cfg->gb);
+      const u64 nkey = km_norm_dir(nb, cfg->gb) ? nb.dir : nb.rc;
+      nf = tab_first(cfg->g_b, sb_owner(cfg, nkey), nkey);
+    }
+    TM_END(w, TM_FINDC, t_fc);
+    TM_BEGIN(t_rg);
     if (level == LV_BMER_UNC) {
       w.bm = w.bm_u; w.sm_ = w.sm_u; w.pm = w.pm_u;
       w.cor_pos = 0;
@@ -178,8 +290,10 @@ FQ_DEV void suffix_dec(Wk &w, u8 *codes, u8 *p_out, u32 size, bool original_orde
         if (rough_p(w, counts)) { level = LV_PMER; rough = true; }
       }
     }
+    TM_END(w, TM_ROUGH, t_rg);
     u32 sym;
     if (level != LV_NONE && w.N_run < 2) {
+      TM_BEGIN(t_k);
       int cor_dist = level == LV_PMER ? (int)cfg->pmer : level == LV_SMER ? (int)cfg->smer : (int)cfg->bmer;
       int d = (int)i - (int)w.cor_pos;
       u32 cor_zone = d < cor_dist ? (u32)(1 + 2 * (cor_dist - d) / cor_dist) : 0u;
@@ -191,14 +305,20 @@ FQ_DEV void suffix_dec(Wk &w, u8 *codes, u8 *p_out, u32 size, bool original_orde
       for (u32 l = 0; l < 7; ++l) sm->lev_tmp[l] = lev[l];
       FQ_SYNC();
       Slot4 s;
-      u32 idx = find_leveled(w, 1, sm->lev_tmp, 0, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
+      TM_END(w, TM_KEYS, t_k);
+      TM_BEGIN(t_l);
+      u32 idx = find_leveled_dec(w, 1, sm->lev_tmp, 0, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
+      TM_END(w, TM_CR_S, t_l);
+      TM_BEGIN(t_d);
       u32 r_sym = idx != FQSX_NIL ? slot_decode(w, idx, s) : 0;
       sym = dec_un_rank(w, counts, r_sym);
+      TM_END(w, TM_CR_RC, t_d);
       ctx_r_sym = ((ctx_r_sym << 1) + (r_sym == 0 ? 1u : 0u)) & 0xff;
     } else {
       sym = dec_letter(w, codes, i, size, hist_start);
       ctx_r_sym = (ctx_r_sym << 1) & 0xff;
     }
+    TM_BEGIN(t_q);
     dec_put(codes, p_out, i, sym);
     const u64 sym_k = sym == 4 ? 0 : sym;
     if (sym == 4) ++w.N_run; else w.N_run = 0;
@@ -220,6 +340,7 @@ FQ_DEV void suffix_dec(Wk &w, u8 *codes, u8 *p_out, u32 size, bool original_orde
       else if (level == LV_NONE || level == LV_PMER) rep = repair_missing(w, i);
       if (rep) push_b_local(w);
     }
+    TM_END(w, TM_POST, t_q);
   }
 }
 
