@@ -253,6 +253,8 @@ def main() -> None:
             tj = json.load(open(tf))
             if tj.get("workers_T") == a.threads and tj.get("reads") == a.reads and tj.get("len") == a.len:
                 traffic = tj.get("bytes_per_launch")
+                roofline["traffic_source"] = ("profiles/traffic.json: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this "
+                                              "workload on the build named there (" + str(tj.get("build", "?"))[:60] + "); NOT measured by this run")
         except Exception:
             traffic = None
     roofline["traffic"] = traffic
