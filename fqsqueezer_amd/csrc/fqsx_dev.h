@@ -2145,21 +2145,55 @@ FQ_DEV u32 repair_decide(const Wk &w, const C4 &c, u32 sym) {
 // Returns false if the wave gave the chunk up because a restart request came in (scout waves only).
 // lane0 != 0: a second pass over part of a chunk (scout_fix): the results go to lanes lane0 .. lane0 + n - 1, the chunk's
 // header (snapshot of the local lists, sweep bookkeeping) stands and the probe counts are added to it.
-FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed, u32 joff = 0, u32 lane0 = 0) {
+// DEFER (scout waves, n <= 64: one position per lane): nothing is written to w.sb -- the lane's results come back in *Lout,
+// the chunk's header values in *Hout, and spec_commit() stores them once the ring slot is free: a scout wave runs stage P
+// of its next chunk while that chunk's slot is still in use, which makes the ring one chunk per scout deeper without any LDS.
+struct SpecLane {
+  u64 sdir[6], src[6], key[7], pv_b, pv_s, pv_pd, pv_pr, sx_s, sx_ls;
+  u32 sx_lb;
+  u8 scur[6], nrun, kind, flag, rsym, rep, pv_flag, sx_flag, valid;
+};
+struct SpecHead { u32 lo0, lo1, np, nlp; u64 ns, nls; };
+FQ_DEV void spec_store_lane(SpecBuf *sb, u32 jj, const SpecLane &L) {
+  for (u32 x = 0; x < 6; ++x) { sb->sp_sdir[x][jj] = L.sdir[x]; sb->sp_src[x][jj] = L.src[x]; sb->sp_scur[x][jj] = L.scur[x]; }
+  sb->sp_nrun[jj] = L.nrun;
+  if (L.flag == 1) {
+    for (u32 l = 0; l < 7; ++l) sb->sp_key[jj][l] = L.key[l];
+    sb->sp_rsym[jj] = L.rsym;
+  }
+  if (L.flag == 3) { sb->sx_lb[jj] = L.sx_lb; sb->sx_s[jj] = L.sx_s; sb->sx_ls[jj] = L.sx_ls; sb->sx_flag[jj] = L.sx_flag; }
+  sb->sp_flag[jj] = L.flag; sb->sp_kind[jj] = L.kind; sb->sp_rep[jj] = L.rep;
+  sb->pv_b[jj] = L.pv_b; sb->pv_s[jj] = L.pv_s; sb->pv_pd[jj] = L.pv_pd; sb->pv_pr[jj] = L.pv_pr; sb->pv_flag[jj] = L.pv_flag;
+}
+FQ_DEV void spec_store_head(SpecBuf *sb, u32 lo0, u32 lo1) {
+  if (FQ_LANE == 0) { sb->h_pq_lo[0] = lo0; sb->h_pq_lo[1] = lo1; }
+  for (u32 j = FQ_LANE; j < FQSX_SPEC; j += FQ_WAVE) { sb->rr_idx[j] = 0xff; sb->ep_off[j][0] = 0xff; sb->ep_off[j][1] = 0xff; }
+  if (FQ_LANE == 0) { sb->rr_front = FQSX_SPEC; sb->h_fix_lane = 0xff; sb->h_fix_end = 0; }
+}
+// the deferred chunk into its buffer (scout waves)
+FQ_DEV void spec_commit(Wk &w, const SpecLane &L, const SpecHead &H) {
+  FQ_SYNC();
+  spec_store_head(w.sb, H.lo0, H.lo1);
+  if (L.valid) spec_store_lane(w.sb, FQ_LANE, L);
+  if (FQ_LANE == 0) { w.sb->h_np = H.np; w.sb->h_nlp = H.nlp; w.sb->h_ns = H.ns; w.sb->h_nls = H.nls; }
+  FQ_SYNC();
+}
+template <bool DEFER>
+FQ_DEV bool speculate_t(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed, u32 joff, u32 lane0, SpecLane *Lout, SpecHead *Hout) {
   const DevCfg *cfg = w.cfg;
   u64 ns = 0, nls = 0;
   u32 np = 0, nlp = 0;
   const u32 lo0 = lq_done_now(w, 0), lo1 = lq_done_now(w, 1);   // everything below is in the local tables before the probes start
   FQ_SYNC();
-  if (lane0 == 0) {
-    if (FQ_LANE == 0) { w.sb->h_pq_lo[0] = lo0; w.sb->h_pq_lo[1] = lo1; }
-    for (u32 j = FQ_LANE; j < FQSX_SPEC; j += FQ_WAVE) { w.sb->rr_idx[j] = 0xff; w.sb->ep_off[j][0] = 0xff; w.sb->ep_off[j][1] = 0xff; }
-    if (FQ_LANE == 0) { w.sb->rr_front = FQSX_SPEC; w.sb->h_fix_lane = 0xff; w.sb->h_fix_end = 0; }
-  }
+  if (!DEFER && lane0 == 0) spec_store_head(w.sb, lo0, lo1);
+  if (DEFER) Lout->valid = 0;
   const u32 b0 = i0 - joff;   // position the k-mers in w stand before
   bool gave_up = false;
   for (u32 j = FQ_LANE; j < n; j += FQ_WAVE) {
     const u32 jj = lane0 + j;   // the lane's place in the chunk
+    SpecLane O;
+    O.valid = 1; O.sx_lb = 0; O.sx_s = 0; O.sx_ls = 0; O.sx_flag = 0; O.rsym = 0;
+    for (u32 l = 0; l < 7; ++l) O.key[l] = 0;
     TM_BEGIN(t_roll);
     // roll the six k-mers J symbols forward in closed form: only the last min(J, k) new symbols matter
     u64 fw = 0, rv = 0;   // new symbols packed oldest-first (fw) and complemented newest-first (rv)
@@ -2207,13 +2241,13 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
     Kmer pu = km_roll(w.pm_u, cfg->gp, J, fw, rv, L), su = km_roll(w.sm_u, cfg->gs, J, fw, rv, L), bu = km_roll(w.bm_u, cfg->gb, J, fw, rv, L);
     km_insert_zero(pm, cfg->gp); km_insert_zero(sk, cfg->gs); km_insert_zero(bm, cfg->gb);
     km_insert_zero(pu, cfg->gp); km_insert_zero(su, cfg->gs); km_insert_zero(bu, cfg->gb);
-    w.sb->sp_sdir[0][jj] = pm.dir; w.sb->sp_src[0][jj] = pm.rc; w.sb->sp_scur[0][jj] = (u8)pm.cur;
-    w.sb->sp_sdir[1][jj] = sk.dir; w.sb->sp_src[1][jj] = sk.rc; w.sb->sp_scur[1][jj] = (u8)sk.cur;
-    w.sb->sp_sdir[2][jj] = bm.dir; w.sb->sp_src[2][jj] = bm.rc; w.sb->sp_scur[2][jj] = (u8)bm.cur;
-    w.sb->sp_sdir[3][jj] = pu.dir; w.sb->sp_src[3][jj] = pu.rc; w.sb->sp_scur[3][jj] = (u8)pu.cur;
-    w.sb->sp_sdir[4][jj] = su.dir; w.sb->sp_src[4][jj] = su.rc; w.sb->sp_scur[4][jj] = (u8)su.cur;
-    w.sb->sp_sdir[5][jj] = bu.dir; w.sb->sp_src[5][jj] = bu.rc; w.sb->sp_scur[5][jj] = (u8)bu.cur;
-    w.sb->sp_nrun[jj] = (u8)(nrun > 255 ? 255 : nrun);
+    O.sdir[0] = pm.dir; O.src[0] = pm.rc; O.scur[0] = (u8)pm.cur;
+    O.sdir[1] = sk.dir; O.src[1] = sk.rc; O.scur[1] = (u8)sk.cur;
+    O.sdir[2] = bm.dir; O.src[2] = bm.rc; O.scur[2] = (u8)bm.cur;
+    O.sdir[3] = pu.dir; O.src[3] = pu.rc; O.scur[3] = (u8)pu.cur;
+    O.sdir[4] = su.dir; O.src[4] = su.rc; O.scur[4] = (u8)su.cur;
+    O.sdir[5] = bu.dir; O.src[5] = bu.rc; O.scur[5] = (u8)bu.cur;
+    O.nrun = (u8)(nrun > 255 ? 255 : nrun);
     const u32 i = i0 + j, sym = rd_sym(w, p, i, size);
     const u64 symk = sym == 4 ? 0 : sym;
     u32 flag = 0, rep = 0xff;
@@ -2257,8 +2291,8 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           u64 lev[7];
           if (!reversed) ctx_codes(lev, cfg, c, w.s_let, i, LV_BMER, cz, 0, size);
           else ctx_codes(lev, cfg, c, w.s_let, size - i - 1, LV_BMER, cz, 0, ~0u);  // dna.cpp:750-752
-          for (u32 l = 0; l < 7; ++l) w.sb->sp_key[jj][l] = lev[l];
-          w.sb->sp_rsym[jj] = (u8)rank_sym(w, c, sym);
+          for (u32 l = 0; l < 7; ++l) O.key[l] = lev[l];
+          O.rsym = (u8)rank_sym(w, c, sym);
           // repair_kmers_existing decision (dna.cpp:333-360)
           rep = repair_decide(w, c, sym);
         }
@@ -2281,34 +2315,34 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
           ++nlp;
           if (c4_any(l)) {
             xf |= SX_LB;
-            w.sb->sx_lb[jj] = l.c[0] | (l.c[1] << 8) | (l.c[2] << 16) | (l.c[3] << 24);
+            O.sx_lb = l.c[0] | (l.c[1] << 8) | (l.c[2] << 16) | (l.c[3] << 24);
           } else if (unc && (tab_rest(cfg->g_b, fu, ku, ndu, l, ns), ++np, c4_any(l))) {
             xf |= SX_UNC;
-            w.sb->sx_s[jj] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
+            O.sx_s = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
           } else {
             c4_zero(l);
             tab_rest(cfg->g_s, fs, ks, nds, l, ns);
             ++np;
             if (c4_any(l)) {
               xf |= SX_S;
-              w.sb->sx_s[jj] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
+              O.sx_s = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
             } else {
               tab_rest(cfg->l_s, fls, ks, nds, l, nls);
               ++nlp;
               if (c4_any(l)) {
                 xf |= SX_LS;
-                w.sb->sx_ls[jj] = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
+                O.sx_ls = (u64)l.c[0] | ((u64)l.c[1] << 16) | ((u64)l.c[2] << 32) | ((u64)l.c[3] << 48);
               }
             }
           }
         }
-        w.sb->sx_flag[jj] = (u8)xf;
+        O.sx_flag = (u8)xf;
         TM_END_SP(w, TM_SP_MISS, t_hit);
       }
     }
-    w.sb->sp_flag[jj] = (u8)flag;
-    w.sb->sp_kind[jj] = flag == 1 ? SK_RANK : SK_NONE;
-    w.sb->sp_rep[jj] = (u8)rep;
+    O.flag = (u8)flag;
+    O.kind = flag == 1 ? SK_RANK : SK_NONE;
+    O.rep = (u8)rep;
     // mailbox entries of this position (dna.cpp:818-852), k-mers after replace_last(sym)
     km_replace_last(pm, symk); km_replace_last(sk, symk); km_replace_last(bm, symk);
     u32 pf = 0;
@@ -2320,22 +2354,27 @@ FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed
         if (flag == 1) pf |= (b_full && c4_get(c, sym) >= 3) ? PV_PHID : PV_P;
       }
     }
-    w.sb->pv_b[jj] = km_norm(bm, cfg->gb);
-    w.sb->pv_s[jj] = km_norm(sk, cfg->gs);
-    w.sb->pv_pd[jj] = km_aligned_dir(pm);
-    w.sb->pv_pr[jj] = km_aligned_rc(pm);
-    w.sb->pv_flag[jj] = (u8)pf;
+    O.pv_b = km_norm(bm, cfg->gb);
+    O.pv_s = km_norm(sk, cfg->gs);
+    O.pv_pd = km_aligned_dir(pm);
+    O.pv_pr = km_aligned_rc(pm);
+    O.pv_flag = (u8)pf;
+    if (DEFER) *Lout = O; else spec_store_lane(w.sb, jj, O);
   }
   if (wave_any(gave_up)) return false;   // (decided for the whole wave: the lanes beyond the chunk did not ask)
   FQ_SYNC();
   np = wave_sum32(np); nlp = wave_sum32(nlp);
   ns = wave_sum64(ns); nls = wave_sum64(nls);
-  if (FQ_LANE == 0) {
+  if (DEFER) { Hout->lo0 = lo0; Hout->lo1 = lo1; Hout->np = np; Hout->nlp = nlp; Hout->ns = ns; Hout->nls = nls; }
+  else if (FQ_LANE == 0) {
     if (lane0 == 0) { w.sb->h_np = np; w.sb->h_nlp = nlp; w.sb->h_ns = ns; w.sb->h_nls = nls; }
     else { w.sb->h_np += np; w.sb->h_nlp += nlp; w.sb->h_ns += ns; w.sb->h_nls += nls; }
   }
   FQ_SYNC();
   return true;
+}
+FQ_DEV bool speculate(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool reversed, u32 joff = 0, u32 lane0 = 0) {
+  return speculate_t<false>(w, p, size, i0, n, reversed, joff, lane0, nullptr, nullptr);
 }
 // a stage-P chunk becomes the one the resolving wave works on
 FQ_DEV void spec_adopt(Wk &w) {
@@ -3930,6 +3969,14 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       for (u32 i0 = base_pos, n = 0; i0 < size && !quit && !restart && (n = chunk_len(size - i0)) != 0; i0 += n, ++seq) {
         if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch) { restart = true; break; }
         if ((sbase + seq) % FQSX_NSC != me) continue;   // another wave's chunk
+        // stage P into registers first (one position per lane), the wait for the ring slot after it: the wave is a chunk
+        // ahead of its slot, i.e. the ring is one chunk per scout deeper than its three buffers
+        SpecLane spl;
+        SpecHead sph;
+        TM_BEGIN(t_sp);
+        const bool whole = speculate_t<true>(w, p, size, i0, n, false, i0 - base_pos, 0, &spl, &sph);
+        TM_END(w, TM_SC_SPEC, t_sp);
+        if (!whole) { TM_COUNT(w, CN_SC_ABORT); restart = true; break; }
         spins = 0;
         TM_BEGIN(t_w2);
         while ((i32)(seq - lds_load_acq(&sm->sc_taken)) >= (i32)FQSX_SCR) {   // the chunk's ring slot still holds an unreleased one
@@ -3941,10 +3988,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         if (quit || restart) break;
         w.sb = &sm->sb[1 + me];
         lds_store_rel(&w.sb->h_pub, 0u);   // (the slot may hold a chunk of the same number from an earlier epoch)
-        TM_BEGIN(t_sp);
-        const bool whole = speculate(w, p, size, i0, n, false, i0 - base_pos);
-        TM_END(w, TM_SC_SPEC, t_sp);
-        if (!whole) { TM_COUNT(w, CN_SC_ABORT); restart = true; break; }
+        spec_commit(w, spl, sph);
         TM_COUNT(w, CN_SC_CHUNK);
 #if FQ_WAVE > 1
         TM_BEGIN(t_se);
@@ -4032,6 +4076,12 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
     for (u32 i0 = base_pos, n = 0; i0 < size && (n = chunk_len(size - i0)) != 0; i0 += n, ++seq) {
       if (lds_load_acq(&sm->sc_req_seq) != w.sc_epoch || lds_load_acq(&sm->cq_done)) break;
       if ((sbase + seq) % nsc != me) continue;   // another wave's chunk
+      SpecLane spl;   // (stage P into registers, then the wait for the ring slot: see scout_segment_body)
+      SpecHead sph;
+      TM_BEGIN(t_sp);
+      const bool whole = speculate_t<true>(w, p, size, i0, n, reversed, i0 - base_pos, 0, &spl, &sph);
+      TM_END(w, TM_SC_SPEC, t_sp);
+      if (!whole) { TM_COUNT(w, CN_SC_ABORT); break; }
       spins = 0;
       bool stop = false;
       TM_BEGIN(t_w2);
@@ -4044,10 +4094,7 @@ FQ_DEV void scout_request_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 me,
       if (stop) break;
       w.sb = &sm->sb[1 + me];
       lds_store_rel(&w.sb->h_pub, 0u);   // (the slot may hold a chunk of the same number from an earlier epoch)
-      TM_BEGIN(t_sp);
-      const bool whole = speculate(w, p, size, i0, n, reversed, i0 - base_pos);
-      TM_END(w, TM_SC_SPEC, t_sp);
-      if (!whole) { TM_COUNT(w, CN_SC_ABORT); break; }
+      spec_commit(w, spl, sph);
       TM_COUNT(w, CN_SC_CHUNK);
 #if FQ_WAVE > 1
       if (i0 == base_pos) { scout_early(w, n); scout_settle_early(w, i0, n); }   // (the look-ups of positions whose b-mer is still partial, if any)
