@@ -2991,6 +2991,58 @@ FQ_DEV u64 quiet_miss_mask(Wk &w, u32 n) {
 }
 #endif
 
+// A scout made the chunk's local look-ups against the local tables as they were when its probes started; entries this
+// worker has pushed since (typically: the read before, which overlaps this one -- two reads of a worker per launch in the
+// warm-up blocks) may change them, and the per-position path would then wait for the inserter wave and ask again, position
+// by position.  Where a chunk has several such positions it is cheaper to do that once for the whole chunk: wait until
+// every entry pushed so far is in the tables, redo the two local look-ups of the miss cascade one position per lane, and
+// let the validation (pend_conflict, quiet_miss_mask) start from the current end of the lists -- only the chunk's own
+// earlier entries remain to be checked, exactly.  Lanes [j0, n); the sweeps a scout made for positions whose cascade was
+// empty stay valid for the positions it is still empty for (the tables only grow inside a segment).
+FQ_DEV void local_refresh(Wk &w, u32 j0, u32 n) {
+  const DevCfg *cfg = w.cfg;
+  SpecBuf *sb = w.sb;
+  const u32 lane = FQ_LANE;
+  if (w.mn[MAIL_B] == w.pq_lo[0] && w.mn[MAIL_S] == w.pq_lo[1]) return;   // nothing pushed since the snapshot
+  FQ_SYNC();
+  const bool cand = lane >= j0 && lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & SX_VALID) != 0;
+  if (popc64(wave_ballot(cand)) < 6) return;   // (the per-position path handles a few)
+  lq_flush(w, MAIL_B);
+  lq_flush(w, MAIL_S);
+  if (w.err) return;
+  u64 nls = 0;
+  u32 nlp = 0;
+  if (cand) {
+    const u64 bd = sb->sp_sdir[2][lane], br = sb->sp_src[2][lane], sd = sb->sp_sdir[1][lane], sr = sb->sp_src[1][lane];
+    const bool ndb = (bd & cfg->gb.kernel_mask) < (br & cfg->gb.kernel_mask), nds = (sd & cfg->gs.kernel_mask) < (sr & cfg->gs.kernel_mask);
+    const u64 kb = ndb ? bd : br, ks = nds ? sd : sr;
+    const TabIt fb = tab_first(cfg->l_b, w.tid, kb), fs = tab_first(cfg->l_s, w.tid, ks);
+    u32 xf = sb->sx_flag[lane] & (SX_VALID | SX_UNC | SX_S);
+    C4 c;
+    c4_zero(c);
+    tab_rest(cfg->l_b, fb, kb, ndb, c, nls);
+    ++nlp;
+    if (c4_any(c)) {
+      xf = SX_VALID | SX_LB;
+      sb->sx_lb[lane] = c.c[0] | (c.c[1] << 8) | (c.c[2] << 16) | (c.c[3] << 24);
+    } else if (!(xf & (SX_UNC | SX_S))) {
+      c4_zero(c);
+      tab_rest(cfg->l_s, fs, ks, nds, c, nls);
+      ++nlp;
+      if (c4_any(c)) {
+        xf |= SX_LS;
+        sb->sx_ls[lane] = (u64)c.c[0] | ((u64)c.c[1] << 16) | ((u64)c.c[2] << 32) | ((u64)c.c[3] << 48);
+      }
+    }
+    sb->sx_flag[lane] = (u8)xf;
+  }
+  FQ_SYNC();
+  w.st[ST_LPROBE] += wave_sum32(nlp);
+  w.st[ST_LSLOT] += wave_sum64(nls);
+  w.pq_lo[0] = w.mn[MAIL_B];
+  w.pq_lo[1] = w.mn[MAIL_S];
+}
+
 // Length of the next chunk when `rem` suffix positions are left: as few chunks as the lanes allow, of equal length (a
 // 150 bp read: 45 + 45 + 45 rather than 64 + 64 + 7), so that the scout waves share a read's probes and sweeps evenly.
 // The resolving wave and the scout waves enumerate the chunks with this one rule.
@@ -3132,7 +3184,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
     }
     u64 Qm = 0;       // positions nothing is found for anywhere unless their Hamming-1 sweep finds something (quiet_miss_mask)
 #if FQ_WAVE > 1
-    { TM_BEGIN(t_qm); if (pre && !w.repm_gate) Qm = quiet_miss_mask(w, n); TM_END(w, TX_QMM, t_qm); }   // (with the gate open repair_kmers_missing may fire: per-position path)
+    { TM_BEGIN(t_qm); if (pre) local_refresh(w, j0, n); if (pre && !w.repm_gate) Qm = quiet_miss_mask(w, n); TM_END(w, TX_QMM, t_qm); }   // (with the gate open repair_kmers_missing may fire: per-position path)
 #endif
     u32 q_done = j0;  // chunk positions whose mailbox entries are already in the lists
     u32 w_pos = j0;   // w's k-mers = state before position w_pos of the chunk
