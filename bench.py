@@ -55,6 +55,9 @@ def main() -> None:
     ap.add_argument("--no-t255", action="store_true", help="skip the extra pass with 255 workers")
     ap.add_argument("--concurrent", type=int, default=4, help="extra pass: this many codec instances at once (0/1 = skip)")
     ap.add_argument("--no-rows", action="store_true", help="skip the extra passes over the other rows (decoder, quality, PE, original order)")
+    ap.add_argument("--partition", action="store_true",
+                    help="with --sharded: the k-mer tables partitioned over the ranks (each GPU holds 1/N of them, look-ups of the "
+                         "rest over xGMI through peer mappings; fqsx_shard_partition_tables) instead of a replica on every rank")
     ap.add_argument("--sharded", action="store_true",
                     help="ONE file sharded over the N GPUs (workers w %% N on rank w, RCCL all-to-all of the mailboxes, "
                          "replica refresh; fqsqueezer_amd/sharded.py) instead of N independent files: strong scaling")
@@ -310,11 +313,12 @@ def sharded_main(a, rank, local_rank, world):
         # through torch.distributed's object broadcast
         ids = [NativeShardedDnaCodec.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        c = NativeShardedDnaCodec(header, rank, world, device=local_rank, transport="rccl", id_bytes=ids[0])
+        c = NativeShardedDnaCodec(header, rank, world, device=local_rank, transport="rccl", id_bytes=ids[0], partition=a.partition)
         nb = 0
         for g, (d_b, d_o, off) in enumerate(dev_blocks):
             nb += c.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g)
         traffic.update(c.traffic)
+        traffic["table_bytes_held_rank0"] = c.codec.capacity()["table_bytes_held"]
         c.close()
         return nb
 
@@ -339,7 +343,8 @@ def sharded_main(a, rank, local_rank, world):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2), -om s -gs {a.gs} -qm n -im n", "workers_T": a.threads,
-                       "blocks": len(dev_blocks), "per_gpu": f"one file sharded over {world} GPU(s): workers w % {world}, RCCL all-to-all of the mailboxes per phase"},
+                       "blocks": len(dev_blocks), "per_gpu": f"one file sharded over {world} GPU(s): workers w % {world}, RCCL all-to-all of the mailboxes per phase"
+                                  + (", k-mer tables partitioned over the ranks (peer-mapped look-ups)" if a.partition else ", table replicas on every rank")},
             "bits_per_base": round(8.0 * int(tot.item()) / n_bases, 5),
             "exchange_rank0_per_file": traffic, "roofline": None, "cpu_baseline": None}), flush=True)
     dist.barrier()

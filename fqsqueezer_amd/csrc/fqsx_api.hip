@@ -14,6 +14,7 @@
 #include "fqsx_kernels.h"
 #include "fqsx_qual.h"
 #include "../../include/fqsx.h"
+#include "fqsx_vm.h"
 
 #ifndef FQSX_EMU
 #include <dlfcn.h>
@@ -200,7 +201,8 @@ FQ_KERNEL void k_rehash_ptab(PTab o, PTab n, u32 n_sub) {
   }
 }
 // re-insert every occupied slot of `o` into the (empty, larger) table `n`; layout-free, so parallel
-FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub) {
+// (sub-tables first, first + step, ...: all of them on one GPU; a rank's own ones when the tables are partitioned)
+FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub, u32 first, u32 step) {
   const u64 ocap = o.cap_mask + 1;
   const u64 total = ocap * n_sub;
 #ifndef FQSX_EMU
@@ -209,7 +211,7 @@ FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub) {
 #else
   for (u64 g = 0; g < total; ++g) {
 #endif
-    u32 sub = (u32)(g / ocap);
+    u32 sub = first + (u32)(g / ocap) * step;
     u64 it = o.slots[(u64)sub * o.stride + (g % ocap)];
     if (!it) continue;
     u64 *s = n.slots + (u64)sub * n.stride;
@@ -321,6 +323,25 @@ FQ_KERNEL64 void k_shard_siv_sum(DevCfg cfg, const u64 *before, const u64 *gathe
     u64 v = before[i];
     for (u32 q = 0; q < cfg.shard_world; ++q) v += gathered[(u64)q * stride + off + i];
     cfg.siv_stats[i] = v;
+  }
+}
+// Partitioned tables: a sub-table's occupancy counter is only kept by its owner's rank, but every rank needs all of them
+// for the growth rule (k_shard_need).  They ride along with the all-gather: out[which * n_max + j] = filled of this rank's
+// j-th own sub-table of the s- (which 0) / b-mer (1) table ...
+FQ_KERNEL64 void k_shard_fill_pack(DevCfg cfg, u64 *out, u32 n_max) {
+  for (u32 i = FQ_LANE; i < 2 * n_max; i += FQ_WAVE) {
+    const u32 which = i / n_max, o = cfg.shard_rank + (i % n_max) * cfg.shard_world;
+    out[i] = o < cfg.T ? (which ? cfg.g_b : cfg.g_s).filled[o] : 0;
+  }
+}
+// ... and the other ranks' counters into this rank's copy of the arrays
+FQ_KERNEL64 void k_shard_fill_unpack(DevCfg cfg, const u64 *gathered, u64 stride, u64 off, u32 n_max) {
+  for (u32 q = 0; q < cfg.shard_world; ++q) {
+    if (q == cfg.shard_rank) continue;
+    for (u32 i = FQ_LANE; i < 2 * n_max; i += FQ_WAVE) {
+      const u32 which = i / n_max, o = q + (i % n_max) * cfg.shard_world;
+      if (o < cfg.T) (which ? cfg.g_b : cfg.g_s).filled[o] = (u32)gathered[(u64)q * stride + off + i];
+    }
   }
 }
 // Received entries -> this rank's owners' groups in (owner, source, push) order (the order InsertKmersToHT drains
@@ -528,6 +549,18 @@ struct fqsx_dna {
   u64 items_cap, gathered_cap;
   std::vector<u32> h_cglob;
   u64 sh_phases, sh_collectives, sh_a2a_words, sh_gather_words;
+  // partitioned tables (fqsx_shard_partition_tables): this rank holds the physical memory of its owners' sub-tables of
+  // g_s / g_b and maps the other ranks' next to them (fqsx_vm.h)
+  bool part;
+  u64 vm_gran;
+  fqsx_vm::FdMesh mesh;
+  struct VmTab {
+    u8 *va = nullptr;
+    u64 va_bytes = 0, chunk_bytes = 0;
+    std::vector<fqsx_vm::Handle> h;   // [T] own (created) and imported chunks
+    bool live = false;
+  } vm_s, vm_b;
+  u64 vm_own_bytes;   // physical table memory held by this rank
 };
 
 namespace {
@@ -692,15 +725,90 @@ int ktab_alloc(fqsx_dna *c, KTab &t, u32 n_sub, u64 cap, u32 k, u32 cbits, bool 
   return FQSX_OK;
 }
 
+// ---- partitioned tables: one address range, the sub-tables' memory spread over the ranks (fqsx_vm.h) -------------------
+#define VMCHK(x) do { std::string e_; if (g_vm_dbg) fprintf(stderr, "[fqsx vm] %s\n", #x); if ((x)) { g_err = "partitioned tables: " + e_; return FQSX_E_HIP; } } while (0)
+static const bool g_vm_dbg = getenv("FQSX_VM_DEBUG") != nullptr;
+void vtab_free(fqsx_dna *c, fqsx_dna::VmTab &v) {
+  if (!v.live) return;
+  std::string e;
+  const u32 T = c->T, G = c->shard_world, me = c->shard_rank;
+  (void)fqsx_vm::unmap(v.va, v.va_bytes, e);
+  for (u32 o = 0; o < T; ++o) {
+    (void)fqsx_vm::release(v.h[o], e);
+    if (o % G == me) { c->dev_bytes -= v.chunk_bytes; c->vm_own_bytes -= v.chunk_bytes; }
+  }
+  (void)fqsx_vm::unreserve(v.va, v.va_bytes, e);
+  v = fqsx_dna::VmTab();
+}
+// Collective (every rank of the world calls it at the same point): an empty table of T sub-tables with `cap` slots each
+int vtab_alloc(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 cbits) {
+  const u32 T = c->T, G = c->shard_world, me = c->shard_rank;
+  const u64 stride = std::max<u64>(cap, c->vm_gran / sizeof(u64));   // (both powers of two: a sub-table is whole chunks)
+  v = fqsx_dna::VmTab();
+  v.chunk_bytes = stride * sizeof(u64);
+  v.va_bytes = v.chunk_bytes * T;
+  v.h.assign(T, fqsx_vm::Handle());
+  VMCHK(fqsx_vm::reserve(v.va_bytes, c->vm_gran, &v.va, e_));
+  v.live = true;
+  std::vector<int> mine;
+  for (u32 o = me; o < T; o += G) {
+    VMCHK(fqsx_vm::create(c->device, v.chunk_bytes, &v.h[o], e_));
+    c->dev_bytes += v.chunk_bytes; c->vm_own_bytes += v.chunk_bytes;
+    c->dev_bytes_peak = std::max(c->dev_bytes_peak, c->dev_bytes);
+    VMCHK(fqsx_vm::map(c->device, v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, v.h[o], e_));
+    int fd = -1;
+    VMCHK(fqsx_vm::export_fd(v.h[o], &fd, e_));
+    mine.push_back(fd);
+  }
+  for (u32 i = 1; i < G; ++i) VMCHK(fqsx_vm::send_fds(c->mesh.peer[(me + i) % G], mine.data(), (u32)mine.size(), e_));
+  for (int fd : mine) close(fd);
+  for (u32 i = 1; i < G; ++i) {
+    const u32 q = (me + G - i) % G, n_q = (T - q + G - 1) / G;
+    std::vector<int> theirs(n_q, -1);
+    VMCHK(fqsx_vm::recv_fds(c->mesh.peer[q], theirs.data(), n_q, e_));
+    for (u32 j = 0; j < n_q; ++j) {
+      const u32 o = q + j * G;
+      VMCHK(fqsx_vm::import_fd(theirs[j], &v.h[o], e_));
+      close(theirs[j]);
+      VMCHK(fqsx_vm::map(c->device, v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, v.h[o], e_));
+    }
+  }
+  for (u32 o = me; o < T; o += G) {   // own chunks empty (a peer reads them only after a collective that follows on this stream)
+    int rc = dzero(c, v.va + (u64)o * v.chunk_bytes, v.chunk_bytes);
+    if (rc) return rc;
+  }
+  t.slots = (u64 *)v.va;
+  t.cap_mask = cap - 1;
+  t.stride = stride;
+  t.k = k;
+  t.cbits = cbits;
+  return FQSX_OK;
+}
+
 int grow_global(fqsx_dna *c, KTab &t, u64 &cap_field, u64 new_cap) {
   KTab n = t;
-  int rc = ktab_alloc(c, n, c->T, new_cap, t.k, t.cbits, false);
-  if (rc) return rc;
-  LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, c->T);
+  int rc;
+  if (c->part) {
+    // every rank takes the same decision in the same phase (the demand is computed from the all-reduced counts and the
+    // exchanged occupancies), so the allocation's descriptor exchange is collective; each rank re-inserts its own
+    // sub-tables, and the phase's all-gather orders that before anybody's next look-up
+    fqsx_dna::VmTab &v = &t == &c->cfg.g_s ? c->vm_s : c->vm_b, nv;
+    if ((rc = vtab_alloc(c, n, nv, new_cap, t.k, t.cbits))) return rc;
+    const u32 n_own = (c->T - c->shard_rank + c->shard_world - 1) / c->shard_world;
+    LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, n_own, c->shard_rank, c->shard_world);
 #ifndef FQSX_EMU
-  HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
 #endif
-  dfree(c, t.slots);
+    vtab_free(c, v);
+    v = nv;
+  } else {
+    if ((rc = ktab_alloc(c, n, c->T, new_cap, t.k, t.cbits, false))) return rc;
+    LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, c->T, 0u, 1u);
+#ifndef FQSX_EMU
+    HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+    dfree(c, t.slots);
+  }
   t = n;
   cap_field = new_cap;
   c->n_growths += 1;
@@ -1288,6 +1396,7 @@ int fqsx_dna_create_on_partition(const uint8_t *h, int device, uint32_t part, ui
   for (int k = 0; k < 3; ++k) { c->d_xrecv[k] = nullptr; c->xrecv_cap[k] = 0; }
   c->d_items = c->d_gathered = c->d_small = nullptr; c->items_cap = c->gathered_cap = 0;
   c->sh_phases = c->sh_collectives = c->sh_a2a_words = c->sh_gather_words = 0;
+  c->part = false; c->vm_gran = 0; c->vm_own_bytes = 0;
   c->dev_bytes = c->dev_bytes_peak = 0; c->n_growths = 0;
   c->h_pin = nullptr; c->d_end = nullptr; c->filled_valid = false;
   c->d_vmap = nullptr; c->d_xbuf = nullptr; c->xbuf_cap = 0; c->d_cglob = nullptr;
@@ -1326,6 +1435,9 @@ void fqsx_dna_destroy(fqsx_dna *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
 #endif
+  vtab_free(c, c->vm_s);
+  vtab_free(c, c->vm_b);
+  fqsx_vm::mesh_close(c->mesh);
   std::vector<void *> a = c->allocs;
   for (void *p : a) dfree(c, p);
 #ifndef FQSX_EMU
@@ -1431,6 +1543,7 @@ int fqsx_shard_config(fqsx_dna *c, uint32_t rank, uint32_t world) {
 int fqsx_shard_begin_block(fqsx_dna *c, const uint8_t *bases /*[codec]*/, const uint64_t *off /*[codec]*/, const uint64_t *h_off,
                            uint32_t n_reads, uint32_t generation, uint32_t *n_segments) {
   if (!c || !bases || !off || !h_off || !n_segments) { g_err = "null argument"; return FQSX_E_ARG; }
+  if (c->part) { g_err = "partitioned tables are driven through fqsx_shard_encode_block"; return FQSX_E_ARG; }
 #ifndef FQSX_EMU
   HIPCHK(hipSetDevice(c->device));
 #endif
@@ -1637,21 +1750,26 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   if ((rc = d2d(c, c->d_small, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
   LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
   // ---- one all-gather: the applied items of every kind (padded to the largest rank's), the p-mer statistics, the triples
+  // (partitioned tables: no s-/b-mer items -- the look-ups read the owner's memory -- but the owners' occupancy counters)
   u64 M[3] = {0, 0, 0}, PM = 0;
   std::vector<u64> n_items(3ull * G, 0), pe_tot(G, 0);
   for (u32 k = 0; k < 3; ++k)
     for (u32 q = 0; q < G; ++q) {
+      if (c->part && k != MAIL_P) continue;
       for (u32 f = 0; f < G; ++f) n_items[(u64)k * G + q] += vol[((u64)k * G + f) * G + q];
       M[k] = std::max(M[k], n_items[(u64)k * G + q]);
     }
+  const u32 n_own_max = (T + G - 1) / G;
+  const u64 FW = c->part ? 2ull * n_own_max : 0;
   if (c->paired)
     for (u32 s = 0; s < T; ++s) { pe_tot[s % G] += C[3ull * T * T + s]; PM = std::max(PM, pe_tot[s % G]); }
-  const u64 off_k[3] = {0, M[0], M[0] + M[1]}, off_siv = M[0] + M[1] + M[2], off_pe = off_siv + 2, W = off_pe + 3 * PM;
+  const u64 off_k[3] = {0, M[0], M[0] + M[1]}, off_siv = M[0] + M[1] + M[2], off_fill = off_siv + 2, off_pe = off_fill + FW, W = off_pe + 3 * PM;
   if ((rc = xbuf_fit(c, c->d_items, c->items_cap, W))) return rc;
   if ((rc = xbuf_fit(c, c->d_gathered, c->gathered_cap, W * G))) return rc;
   for (u32 k = 0; k < 3; ++k)
     if (n_items[(u64)k * G + me]) LAUNCH(c, 2, k_shard_collect, REHASH_GRID, 256, cfg, k, c->d_items + off_k[k]);
   LAUNCH(c, 2, k_shard_siv_delta, 1, 64, cfg, (const u64 *)c->d_small, c->d_items + off_siv);
+  if (FW) LAUNCH(c, 2, k_shard_fill_pack, 1, 64, cfg, c->d_items + off_fill, n_own_max);
   if (c->paired && PM) LAUNCH(c, 2, k_shard_pe_pack, T, 64, cfg, c->d_items + off_pe);
   COMMCHK(c->comm.allgather_u64(c->comm.ctx, c->d_items, W, c->d_gathered), "all-gather of the applied items");   // collective 3
   c->sh_gather_words += W * (G - 1);
@@ -1660,6 +1778,7 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
       for (u32 k = 0; k < 3; ++k)
         if (n_items[(u64)k * G + q]) LAUNCH(c, 2, k_shard_apply, REHASH_GRID, 256, cfg, k, (const u64 *)(c->d_gathered + (u64)q * W + off_k[k]), (u32)n_items[(u64)k * G + q]);
   LAUNCH(c, 2, k_shard_siv_sum, 1, 64, cfg, (const u64 *)c->d_small, (const u64 *)c->d_gathered, W, off_siv);
+  if (FW) LAUNCH(c, 2, k_shard_fill_unpack, 1, 64, cfg, (const u64 *)c->d_gathered, W, off_fill, n_own_max);
   // ---- paired-end: every rank applies every source's triples to its replica of the pair table
   if (c->paired) {
     if (G > 1 && PM) LAUNCH(c, 2, k_shard_pe_unpack, T, 64, cfg, (const u64 *)c->d_gathered, W, off_pe, (const u32 *)(c->d_cglob + 3ull * T * T));
@@ -1688,6 +1807,46 @@ int fqsx_shard_attach(fqsx_dna *c, uint32_t rank, uint32_t world, const fqsx_com
   c->comm = *comm;
   c->comm_set = true;
   if (const char *e = getenv("FQSX_SHARD_APPLY_OWN")) c->shard_apply_own = atoi(e) != 0;   // (tests: the replica update on this rank's own items must change nothing)
+  return FQSX_OK;
+}
+
+// Collective, after fqsx_shard_attach and before the first block: from here on this rank holds only the sub-tables of the
+// s- and b-mer tables its workers own; the others' are mapped from their ranks (one node: descriptors over Unix sockets).
+int fqsx_shard_partition_tables(fqsx_dna *c) {
+  if (!c || !c->comm_set) { g_err = "no transport attached (fqsx_shard_attach)"; return FQSX_E_ARG; }
+  if (c->part) return FQSX_OK;
+  if (c->k_n[0]) { g_err = "the tables can only be partitioned before the first block"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  const u32 G = c->shard_world, me = c->shard_rank;
+  int rc;
+  VMCHK(fqsx_vm::granularity(c->device, &c->vm_gran, e_));
+  if (c->vm_gran < sizeof(u64) || (c->vm_gran & (c->vm_gran - 1))) { g_err = "unexpected allocation granularity"; return FQSX_E_HIP; }
+  // ---- the descriptor mesh: listen, exchange the names through the transport, connect
+  VMCHK(fqsx_vm::mesh_listen(c->mesh, me, G, e_));
+  std::vector<u64> words(G, 0);
+  if ((rc = xbuf_fit(c, c->d_items, c->items_cap, 1))) return rc;
+  if ((rc = xbuf_fit(c, c->d_gathered, c->gathered_cap, G))) return rc;
+  if ((rc = h2d(c, c->d_items, &c->mesh.word, sizeof(u64)))) return rc;
+  COMMCHK(c->comm.allgather_u64(c->comm.ctx, c->d_items, 1, c->d_gathered), "all-gather of the descriptor-socket names");
+  if ((rc = d2h_sync(c, words.data(), c->d_gathered, G * sizeof(u64)))) return rc;
+  VMCHK(fqsx_vm::mesh_connect(c->mesh, words.data(), e_));
+  // ---- the (still empty) tables again, partitioned
+  c->part = true;
+  dfree(c, c->cfg.g_s.slots);
+  dfree(c, c->cfg.g_b.slots);
+  c->cfg.g_s.slots = c->cfg.g_b.slots = nullptr;
+  if ((rc = vtab_alloc(c, c->cfg.g_s, c->vm_s, c->gs_cap, c->cfg.smer, 12))) return rc;
+  if ((rc = vtab_alloc(c, c->cfg.g_b, c->vm_b, c->gb_cap, c->cfg.bmer, 6))) return rc;
+  // nobody looks a k-mer up before every rank's chunks are cleared
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  COMMCHK(c->comm.allgather_u64(c->comm.ctx, c->d_items, 1, c->d_gathered), "barrier after the table partition");
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
   return FQSX_OK;
 }
 
@@ -1857,6 +2016,7 @@ int fqsx_dna_capacity(fqsx_dna *c, uint64_t out[16]) {
     out[11] = c->gpe_cap * T;
   }
   out[12] = sizeof(u64);   // bytes per global-table slot
+  out[13] = c->part ? c->vm_own_bytes : (c->gs_cap + c->gb_cap) * T * sizeof(u64);   // s- + b-mer table memory this rank holds
   return FQSX_OK;
 }
 

@@ -192,14 +192,71 @@ def _torch_comm(world: int, group=None) -> _Comm:
     return _Comm(None, _Comm._AR(allreduce), _Comm._A2A(alltoallv), _Comm._AG(allgather))
 
 
+def _staged_comm(world: int, group=None) -> _Comm:
+    """fqsx_comm for a codec whose memory space is HBM when RCCL cannot carry the world -- several ranks on ONE device, which
+    RCCL refuses (the two-process test of the partitioned tables on a one-GPU box): every collective is staged through host
+    memory (hipMemcpy) and done by torch.distributed on the CPU (gloo).  A test and bring-up transport, not a fast one."""
+    # (device buffers are wrapped as torch tensors in place: loading libamdhip64 a second time beside torch's own copy
+    # would put two HIP runtimes into the process)
+    class _Dev:
+        def __init__(self, ptr, n, typestr):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+    def dev(ptr, n, dtype):
+        return torch.as_tensor(_Dev(ptr, n, "<i4" if dtype == torch.int32 else "<i8"), device="cuda")
+
+    def down(ptr, n, dtype):
+        return dev(ptr, n, dtype).cpu() if n else torch.empty(0, dtype=dtype)
+
+    def up(ptr, t):
+        if t.numel():
+            dev(ptr, t.numel(), t.dtype).copy_(t)
+            torch.cuda.synchronize()
+
+    def guarded(f):
+        def g(*a):
+            try:
+                torch.cuda.synchronize()   # (the codec's stream included: a device-wide wait)
+                f(*a)
+                return 0
+            except Exception as e:   # noqa: BLE001 -- reported through the C ABI
+                print("fqsx transport:", e)
+                return 1
+        return g
+
+    @guarded
+    def allreduce(_ctx, buf, n):
+        t = down(buf, n, torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        up(buf, t)
+
+    @guarded
+    def alltoallv(_ctx, n_buf, send, scnt, recv, rcnt):
+        for b in range(n_buf):
+            n_out = [int(scnt[b * world + r]) for r in range(world)]
+            n_in = [int(rcnt[b * world + r]) for r in range(world)]
+            r = torch.empty(max(sum(n_in), 1), dtype=torch.int64)[:sum(n_in)]
+            dist.all_to_all_single(r, down(send[b], sum(n_out), torch.int64), n_in, n_out, group=group)
+            up(recv[b], r)
+
+    @guarded
+    def allgather(_ctx, send, n, recv):
+        out = torch.empty(n * world, dtype=torch.int64)
+        dist.all_gather_into_tensor(out, down(send, n, torch.int64).clone(), group=group)
+        up(recv, out)
+
+    return _Comm(None, _Comm._AR(allreduce), _Comm._A2A(alltoallv), _Comm._AG(allgather))
+
+
 class NativeShardedDnaCodec:
     """One file's DNA path over `world` ranks with the phase loop inside the library (fqsx_shard_encode_block).
+    partition = True: the k-mer tables are partitioned over the ranks (fqsx_shard_partition_tables; one node).
     transport = "rccl": RCCL on the codec's stream; `id_bytes` = the 128-byte id rank 0 made with rccl_unique_id() and
     every rank received (e.g. through torch.distributed's store).  transport = "torch": torch.distributed collectives on
-    host buffers (gloo; emulation build)."""
+    host buffers (gloo; emulation build).  transport = "staged": HBM buffers staged through the host (see _staged_comm)."""
 
     def __init__(self, header: bytes, rank: int, world: int, device: int = 0, lib_path: Optional[str] = None, transport: str = "rccl",
-                 id_bytes: Optional[bytes] = None, group=None):
+                 id_bytes: Optional[bytes] = None, group=None, partition: bool = False, comm: Optional[_Comm] = None):
         self.codec = DnaCodec(header, device=device, lib_path=lib_path)
         self._lib, self._h, self.T = self.codec._lib, self.codec._h, self.codec.T
         self.rank, self.world, self.device = rank, world, device
@@ -210,14 +267,21 @@ class NativeShardedDnaCodec:
         L.fqsx_rccl_comm_create.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(_Comm)]
         L.fqsx_rccl_comm_destroy.argtypes = [C.POINTER(_Comm)]
         self._rccl = transport == "rccl"
+        self._staged = transport == "staged"
         if self._rccl:
             if id_bytes is None or len(id_bytes) != 128:
                 raise ValueError("the RCCL transport needs the 128-byte unique id (rccl_unique_id on rank 0)")
             self._comm = _Comm()
             self._ck(L.fqsx_rccl_comm_create(self._h, bytes(id_bytes), rank, world, C.byref(self._comm)), "fqsx_rccl_comm_create")
+        elif transport == "staged":
+            self._comm = _staged_comm(world, group)
         else:
-            self._comm = _torch_comm(world, group)
+            self._comm = comm if comm is not None else _torch_comm(world, group)
         self._ck(L.fqsx_shard_attach(self._h, rank, world, C.byref(self._comm)), "fqsx_shard_attach")
+        self.partitioned = partition
+        if partition:   # (collective) each rank keeps 1/world of the k-mer tables and maps the rest from its peers
+            L.fqsx_shard_partition_tables.argtypes = [C.c_void_p]
+            self._ck(L.fqsx_shard_partition_tables(self._h), "fqsx_shard_partition_tables")
         self.own_workers = list(range(rank, self.T, world))
         self._streams = (C.c_void_p * self.T)()
         self._lens = (C.c_uint64 * self.T)()
@@ -240,7 +304,7 @@ class NativeShardedDnaCodec:
         """All ranks call this with the same block; returns {worker: DNA stream} for this rank's workers."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
-        if self._rccl:   # the codec's memory space is HBM
+        if self._rccl or self._staged:   # the codec's memory space is HBM
             dev = torch.device("cuda", self.device)
             t_b, t_o = torch.from_numpy(bases).to(dev), torch.from_numpy(read_off.view(np.int64)).to(dev)
             torch.cuda.synchronize(dev)

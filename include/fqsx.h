@@ -104,7 +104,8 @@ int fqsx_dna_stats(fqsx_dna *, uint64_t out[64]);
  * fqs/application.cpp:733-741): [0] distinct s-mers stored [1] distinct b-mers stored [2] s-mer table slots (all owners)
  * [3] b-mer table slots [4] p-mer vector bytes [5] context-table slots (all workers) [6] contexts stored
  * [7] device bytes held now [8] ... at most so far (old + new table during a growth included) [9] table growth events
- * [10] minimizer pairs stored (paired-end) [11] pair-table slots [12] bytes per k-mer table slot. */
+ * [10] minimizer pairs stored (paired-end) [11] pair-table slots [12] bytes per k-mer table slot
+ * [13] bytes of s- + b-mer table memory this rank holds (all of it, or its owners' share with partitioned tables). */
 int fqsx_dna_capacity(fqsx_dna *, uint64_t out[16]);
 
 /* Sharded mode (reference: the T x T mailboxes of fqs/application.h:56-59 and their owner-side
@@ -137,6 +138,17 @@ int fqsx_shard_attach(fqsx_dna *, uint32_t rank, uint32_t world, const fqsx_comm
 int fqsx_shard_encode_block(fqsx_dna *, const uint8_t *bases /*[codec]*/, const uint64_t *read_off /*[codec]*/, const uint64_t *h_read_off,
                             uint32_t n_reads, uint32_t generation, const uint8_t **streams, uint64_t *lens);
 int fqsx_shard_traffic(fqsx_dna *, uint64_t out[4]);
+/* Partitioned look-ups (SURVEY.md 8e option (i); the reference shares ONE table among its threads, fqs/application.h:51-54,
+ * with the owner functions of fqs/dna.cpp:825 and :2381-2386 deciding who writes a key).  Collective over the ranks of one
+ * node, after fqsx_shard_attach and before the first block: from then on a rank holds the physical memory of only the s- and
+ * b-mer sub-tables its workers own (1/world of the k-mer tables) and maps the other ranks' sub-tables beside them
+ * (hipMemCreate -> POSIX descriptor over a Unix socket -> hipMemImportFromShareableHandle -> hipMemMap), so that every rank
+ * sees one table in one address range and a look-up of a foreign sub-table is a load over xGMI.  Writes stay with the owner
+ * (insert phase); the phase's collectives order them before the next look-ups.  The all-gather of a phase then carries no
+ * k-mer items, only the owners' occupancy counters, the p-mer items and statistics and the paired-end triples (the p-mer
+ * vector and the pair table stay replicated).  Streams are bit-identical to the one-GPU run's.
+ * fqsx_dna_capacity()[13] = bytes of k-mer table memory this rank holds. */
+int fqsx_shard_partition_tables(fqsx_dna *);
 /* RCCL transport on the codec's own stream (collectives and kernels are ordered by the stream; librccl is loaded on first
  * use).  Rank 0 calls fqsx_rccl_unique_id and hands the 128 bytes to the other ranks by any means (a file, a TCP store). */
 int fqsx_rccl_unique_id(uint8_t id[128]);

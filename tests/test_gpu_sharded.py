@@ -1,0 +1,101 @@
+"""Partitioned tables of the sharded mode on real hardware (SURVEY.md 8e option (i); fqsx_shard_partition_tables).
+
+A gpurun box has ONE GPU and RCCL refuses two ranks on one device, so the multi-rank run here is two processes on device 0
+whose collectives are staged through the host and done by gloo (`transport="staged"`).  What the GPU run adds to the gloo /
+emulation tests of tests/test_sharded_cpu.py: the HIP virtual-memory path itself -- hipMemCreate, the dma-buf export, the
+descriptor hand-over between the processes, hipMemImportFromShareableHandle, hipMemMap into one address range -- look-ups of
+the encode kernels through imported mappings, owner-only inserts, collective growth with re-export, and the occupancy
+counters riding on the all-gather.  Every worker's stream must equal the one-GPU run's (which is pinned to the reference).
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import faulthandler, os, sys
+faulthandler.enable()
+sys.path.insert(0, os.environ["FQSX_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.codec import DnaCodec
+from fqsqueezer_amd.sharded import NativeShardedDnaCodec
+from fqsqueezer_amd.synth import synth_pairs, synth_reads
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+T, mode = int(os.environ["FQSX_T"]), os.environ["FQSX_MODE"]
+header = hp.make_header(T, mode, 1)
+if mode.startswith("pe"):
+    r1, r2 = synth_pairs(6000, 100, 120000, 33)
+    rec1 = hp.Records([b"@a%d" % i for i in range(len(r1))], r1, r1)
+    rec2 = hp.Records([b"@b%d" % i for i in range(len(r2))], r2, r2)
+    blocks = [hp.block_arrays_pe(rec1, rec2, idx) for idx in hp.form_blocks_pe(rec1, rec2, mode)[:24]]
+else:
+    reads = synth_reads(20000, 100, 150000, 37)
+    rec = hp.Records([b"@r%d" % i for i in range(len(reads))], reads, reads)
+    blocks = [hp.block_arrays(rec, idx) for idx in hp.form_blocks(rec, mode)[:48]]
+sh = NativeShardedDnaCodec(header, rank, world, device=0, transport="staged", partition=True)
+one = DnaCodec(header, device=0)                    # the one-GPU run, for comparison (every rank runs it)
+for g, (bases, off) in enumerate(blocks):
+    mine = sh.encode_block(bases, off, g)
+    ref = one.encode_block(bases, off, g)
+    assert sorted(mine) == list(range(rank, T, world))
+    for w, s in mine.items():
+        assert s == ref[w], f"rank {rank}: block {g} worker {w} differs from the one-GPU run"
+cap, cap1 = sh.codec.capacity(), one.capacity()
+assert (cap["smers"], cap["bmers"]) == (cap1["smers"], cap1["bmers"]), (cap, cap1)
+assert cap["growths"] >= 2, cap
+lst = [None] * world
+dist.all_gather_object(lst, (cap["table_bytes_held"], 8 * (cap["smer_slots"] + cap["bmer_slots"]), sh.traffic))
+if rank == 0:
+    held, whole = [x[0] for x in lst], lst[0][1]
+    assert sum(held) == whole and max(held) <= whole * ((T + world - 1) // world) // T, (held, whole)
+    print("PARTITIONED_GPU_OK", world, T, mode, held, whole, lst[0][2])
+sh.close(); one.close()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,T,mode,port", [(2, 16, "se_sorted", 29561), (3, 8, "pe_sorted", 29562)])
+def test_partitioned_tables_ranks_share_one_gpu(tmp_path, world, T, mode, port):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, FQSX_ROOT=ROOT, FQSX_T=str(T), FQSX_MODE=mode, FQSX_GTAB_INIT="1024")   # (small tables: several collective growths)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    i = r.stderr.find("Fatal Python error")   # (faulthandler of a rank: the interesting part of a native crash)
+    assert r.returncode == 0, (r.stdout[-1500:] + (r.stderr[max(0, i - 500):i + 2500] if i >= 0 else r.stderr[-3000:]))
+    assert "PARTITIONED_GPU_OK" in r.stdout
+
+
+def test_partitioned_tables_world_of_one_over_rccl():
+    """the same entry points with the RCCL transport inside the library (one rank: no peer mappings, but the tables live in
+    hipMemCreate chunks inside one reserved range, growth re-creates them, the all-gather carries the occupancy words)"""
+    import numpy as np
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.codec import DnaCodec
+    from fqsqueezer_amd.sharded import NativeShardedDnaCodec
+    from fqsqueezer_amd.synth import synth_reads
+    os.environ["FQSX_GTAB_INIT"] = "1024"
+    try:
+        reads = synth_reads(20000, 100, 150000, 37)
+        rec = hp.Records([b"@r%d" % i for i in range(len(reads))], reads, reads)
+        header = hp.make_header(16, "se_sorted", 1)
+        sh = NativeShardedDnaCodec(header, 0, 1, device=0, transport="rccl", id_bytes=NativeShardedDnaCodec.rccl_unique_id(), partition=True)
+        one = DnaCodec(header, device=0)
+        for g, idx in enumerate(hp.form_blocks(rec, "se_sorted")[:60]):
+            bases, off = hp.block_arrays(rec, idx)
+            mine, ref = sh.encode_block(bases, off, g), one.encode_block(bases, off, g)
+            assert [mine[w] for w in range(16)] == ref, f"block {g}"
+        cap = sh.codec.capacity()
+        assert cap["growths"] >= 2 and cap["table_bytes_held"] == 8 * (cap["smer_slots"] + cap["bmer_slots"])
+        sh.close()
+        one.close()
+    finally:
+        os.environ.pop("FQSX_GTAB_INIT", None)

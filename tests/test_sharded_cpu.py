@@ -84,7 +84,8 @@ else:
     rec = hp.Records([b"@r%d" % i for i in range(len(reads))], reads, reads)
     order = np.concatenate(hp.sorted_order(rec)) if mode == "se_sorted" else np.arange(len(reads))
     blocks = [hp.block_arrays(rec, order[lo:lo + 600]) for lo in range(0, len(order), 600)]
-sh = NativeShardedDnaCodec(header, rank, world, lib_path=lib, transport="torch")
+part = os.environ.get("FQSX_PARTITION") == "1"
+sh = NativeShardedDnaCodec(header, rank, world, lib_path=lib, transport="torch", partition=part)
 one = DnaCodec(header, lib_path=lib)                # the one-process run, for comparison (every rank runs it)
 for g, (bases, off) in enumerate(blocks):
     mine = sh.encode_block(bases, off, g)
@@ -94,20 +95,34 @@ for g, (bases, off) in enumerate(blocks):
         assert s == ref[w], f"rank {rank}: block {g} worker {w} differs from the one-process run"
 tr = sh.traffic
 assert tr["collectives"] == 3 * tr["phases"] and tr["phases"] > len(blocks)
+cap, cap1 = sh.codec.capacity(), one.capacity()
+assert (cap["smers"], cap["bmers"]) == (cap1["smers"], cap1["bmers"])     # every rank knows every sub-table's occupancy
+assert cap["growths"] >= 2, cap                                              # the tables grew on the way (from 64-slot sub-tables)
 lst = [None] * world
-dist.all_gather_object(lst, tr)
+dist.all_gather_object(lst, (tr, cap["table_bytes_held"], 8 * (cap["smer_slots"] + cap["bmer_slots"])))
 if rank == 0:
     assert tr["all_to_all_bytes"] > 0 and tr["all_gather_bytes"] > 0
-    print("NATIVE_SHARDED_OK", world, T, mode, lst[0])
+    held, whole = [x[1] for x in lst], lst[0][2]
+    if part:   # a rank holds the memory of its owners' sub-tables only: ceil(T / world) or floor(T / world) of the T
+        assert sum(held) == whole and max(held) <= whole * ((T + world - 1) // world) // T, (held, whole)
+    else:
+        assert all(h == whole for h in held), (held, whole)
+    print("NATIVE_SHARDED_OK", world, T, mode, "partitioned" if part else "replicas", held, whole, lst[0][0])
 dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,T,mode,port", [(2, 5, "se_sorted", 29533), (3, 4, "se_original", 29534), (2, 4, "pe_sorted", 29535), (3, 5, "pe_original", 29536)])
-def test_native_sharded_driver_streams_identical_to_one_process_run(tmp_path, built, world, T, mode, port):
+# partition = 1: the k-mer tables partitioned over the ranks (fqsx_shard_partition_tables) -- each rank holds the memory of its
+# owners' sub-tables (memfd chunks in the emulation build, handed over as descriptors like the HIP build's dma-buf exports)
+# and looks the others' up through the mapping; the tables start at 64 slots per sub-table so that they grow several times
+@pytest.mark.parametrize("world,T,mode,port,partition", [(2, 5, "se_sorted", 29533, 0), (3, 4, "se_original", 29534, 0), (2, 4, "pe_sorted", 29535, 0),
+                                                         (3, 5, "pe_original", 29536, 0), (2, 5, "se_sorted", 29537, 1), (3, 7, "se_original", 29538, 1),
+                                                         (3, 4, "pe_sorted", 29539, 1)])
+def test_native_sharded_driver_streams_identical_to_one_process_run(tmp_path, built, world, T, mode, port, partition):
     script = tmp_path / "w.py"
     script.write_text(NATIVE_WORKER)
     env = dict(os.environ, FQSX_ROOT=ROOT, FQSX_EMU_LIB=os.path.join(ROOT, "tests", "emu", "libfqsx_emu.so"), FQSX_T=str(T), FQSX_MODE=mode,
+               FQSX_PARTITION=str(partition), FQSX_GTAB_INIT="64",
                FQSX_SHARD_APPLY_OWN="1" if world == 2 else "0")   # (world 2 also applies the rank's own items to its replica: must change nothing)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
