@@ -55,6 +55,8 @@ def main() -> None:
     ap.add_argument("--no-t255", action="store_true", help="skip the extra pass with 255 workers")
     ap.add_argument("--concurrent", type=int, default=4, help="extra pass: this many codec instances at once (0/1 = skip)")
     ap.add_argument("--no-rows", action="store_true", help="skip the extra passes over the other rows (decoder, quality, PE, original order)")
+    ap.add_argument("--chunked-tables", action="store_true",
+                    help="the capacity mode (fqsx_dna_use_chunked_tables): k-mer tables in per-sub-table chunks, growth without old + new side by side")
     ap.add_argument("--partition", action="store_true",
                     help="with --sharded: the k-mer tables partitioned over the ranks (each GPU holds 1/N of them, look-ups of the "
                          "rest over xGMI through peer mappings; fqsx_shard_partition_tables) instead of a replica on every rank")
@@ -109,7 +111,7 @@ def main() -> None:
     block_done = []   # host clock after every block of the most recent pass (a block call returns when its streams are back)
 
     def one_step(profile: bool = False):
-        codec = DnaCodec(header, device=local_rank)
+        codec = DnaCodec(header, device=local_rank, chunked_tables=a.chunked_tables)
         if profile:
             codec.set_profiling(True)
         out_bytes = 0

@@ -83,8 +83,10 @@ def load_library(path: Optional[str] = None):
 class DnaCodec:
     """One .fqs file's DNA-stream encoder state on one GPU (fqsx_dna_*)."""
 
-    def __init__(self, header: bytes, device: int = 0, lib_path: Optional[str] = None, partition: Optional[tuple] = None):
-        """partition = (k, n): confine the codec's kernels to the k-th of n equal sets of compute units (several files at once on one GPU)."""
+    def __init__(self, header: bytes, device: int = 0, lib_path: Optional[str] = None, partition: Optional[tuple] = None,
+                 chunked_tables: bool = False):
+        """partition = (k, n): confine the codec's kernels to the k-th of n equal sets of compute units (several files at once on one GPU).
+        chunked_tables: the capacity mode (fqsx_dna_use_chunked_tables): a growth never holds the old and the new table side by side."""
         if len(header) != 17:
             raise ValueError("header must be the 17 .fqs parameter bytes")
         self._lib = load_library(lib_path)
@@ -96,6 +98,10 @@ class DnaCodec:
             rc = self._lib.fqsx_dna_create_on_partition(bytes(header), device, partition[0], partition[1], C.byref(self._h))
         if rc:
             raise FqsxError(f"fqsx_dna_create: {rc}: {self._lib.fqsx_last_error().decode()}")
+        if chunked_tables:
+            self._lib.fqsx_dna_use_chunked_tables.argtypes = [C.c_void_p]
+            if self._lib.fqsx_dna_use_chunked_tables(self._h):
+                raise FqsxError(f"fqsx_dna_use_chunked_tables: {self._lib.fqsx_last_error().decode()}")
         self._streams = (C.c_void_p * self.T)()
         self._lens = (C.c_uint64 * self.T)()
 

@@ -201,6 +201,16 @@ FQ_KERNEL void k_rehash_ptab(PTab o, PTab n, u32 n_sub) {
   }
 }
 // re-insert every occupied slot of `o` into the (empty, larger) table `n`; layout-free, so parallel
+// n zero words at p (the chunks of a chunked table are cleared by a kernel of the codec's own stream, so that the order
+// against the re-insert kernel that follows does not hang on how the runtime treats a memset into a mapped range)
+FQ_KERNEL void k_zero_words(u64 *p, u64 n) {
+#ifndef FQSX_EMU
+  const u64 gstride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) p[i] = 0;
+#else
+  for (u64 i = 0; i < n; ++i) p[i] = 0;
+#endif
+}
 // (sub-tables first, first + step, ...: all of them on one GPU; a rank's own ones when the tables are partitioned)
 FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub, u32 first, u32 step) {
   const u64 ocap = o.cap_mask + 1;
@@ -558,6 +568,7 @@ struct fqsx_dna {
     u8 *va = nullptr;
     u64 va_bytes = 0, chunk_bytes = 0;
     std::vector<fqsx_vm::Handle> h;   // [T] own (created) and imported chunks
+    std::vector<u8> mapped;           // [T] chunk o is mapped (and its handle held)
     bool live = false;
   } vm_s, vm_b;
   u64 vm_own_bytes;   // physical table memory held by this rank
@@ -728,34 +739,66 @@ int ktab_alloc(fqsx_dna *c, KTab &t, u32 n_sub, u64 cap, u32 k, u32 cbits, bool 
 // ---- partitioned tables: one address range, the sub-tables' memory spread over the ranks (fqsx_vm.h) -------------------
 #define VMCHK(x) do { std::string e_; if (g_vm_dbg) fprintf(stderr, "[fqsx vm] %s\n", #x); if ((x)) { g_err = "partitioned tables: " + e_; return FQSX_E_HIP; } } while (0)
 static const bool g_vm_dbg = getenv("FQSX_VM_DEBUG") != nullptr;
+// one chunk out of the range (its memory goes back to the device once every rank that imported it has let go of it too)
+void vtab_drop(fqsx_dna *c, fqsx_dna::VmTab &v, u32 o) {
+  if (!v.live || !v.mapped[o]) return;
+  std::string e;
+  (void)fqsx_vm::unmap(v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, e);
+  (void)fqsx_vm::release(v.h[o], e);
+  v.mapped[o] = 0;
+  if (o % c->shard_world == c->shard_rank) { c->dev_bytes -= v.chunk_bytes; c->vm_own_bytes -= v.chunk_bytes; }
+}
 void vtab_free(fqsx_dna *c, fqsx_dna::VmTab &v) {
   if (!v.live) return;
   std::string e;
-  const u32 T = c->T, G = c->shard_world, me = c->shard_rank;
-  (void)fqsx_vm::unmap(v.va, v.va_bytes, e);
-  for (u32 o = 0; o < T; ++o) {
-    (void)fqsx_vm::release(v.h[o], e);
-    if (o % G == me) { c->dev_bytes -= v.chunk_bytes; c->vm_own_bytes -= v.chunk_bytes; }
-  }
+  for (u32 o = 0; o < c->T; ++o) vtab_drop(c, v, o);
+#ifdef FQSX_EMU
   (void)fqsx_vm::unreserve(v.va, v.va_bytes, e);
+#else
+  // The address range is NOT handed back (hipMemAddressFree): with the HIP runtime a PyTorch wheel loads (ROCm 7.0) a range
+  // that is freed and later reserved again -- by the next growth, or by another allocation that lands there -- is read through
+  // stale translations (found with tests/test_gpu_parity.py::test_hip_chunked_tables_*: wrong table contents from the first
+  // reuse on; never with the ranges kept).  Unmapped address space costs nothing; a codec's ranges add up to less than twice
+  // its final tables.
+#endif
   v = fqsx_dna::VmTab();
 }
-// Collective (every rank of the world calls it at the same point): an empty table of T sub-tables with `cap` slots each
-int vtab_alloc(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 cbits) {
-  const u32 T = c->T, G = c->shard_world, me = c->shard_rank;
+// the address range of a table of T sub-tables with `cap` slots each; nothing mapped yet
+int vtab_reserve(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 cbits) {
+  const u32 T = c->T;
   const u64 stride = std::max<u64>(cap, c->vm_gran / sizeof(u64));   // (both powers of two: a sub-table is whole chunks)
   v = fqsx_dna::VmTab();
   v.chunk_bytes = stride * sizeof(u64);
   v.va_bytes = v.chunk_bytes * T;
   v.h.assign(T, fqsx_vm::Handle());
-  VMCHK(fqsx_vm::reserve(v.va_bytes, c->vm_gran, &v.va, e_));
+  v.mapped.assign(T, 0);
+  // (2 MiB alignment once the chunks are that large, so that the driver can use large page-table fragments)
+  VMCHK(fqsx_vm::reserve(v.va_bytes, std::max<u64>(c->vm_gran, std::min<u64>(v.chunk_bytes, 2ull << 20)), &v.va, e_));
   v.live = true;
+  t.slots = (u64 *)v.va;
+  t.cap_mask = cap - 1;
+  t.stride = stride;
+  t.k = k;
+  t.cbits = cbits;
+  return FQSX_OK;
+}
+// this rank's sub-table o: physical memory, mapped, empty
+int vtab_create_own(fqsx_dna *c, fqsx_dna::VmTab &v, u32 o) {
+  VMCHK(fqsx_vm::create(c->device, v.chunk_bytes, &v.h[o], e_));
+  c->dev_bytes += v.chunk_bytes; c->vm_own_bytes += v.chunk_bytes;
+  c->dev_bytes_peak = std::max(c->dev_bytes_peak, c->dev_bytes);
+  VMCHK(fqsx_vm::map(c->device, v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, v.h[o], e_));
+  v.mapped[o] = 1;
+  const u64 words = v.chunk_bytes / sizeof(u64);   // (a peer reads the chunk only after a collective that follows on this stream)
+  LAUNCH(c, 2, k_zero_words, (u32)std::min<u64>(REHASH_GRID, (words + 255) / 256), 256, (u64 *)(v.va + (u64)o * v.chunk_bytes), words);
+  return FQSX_OK;
+}
+// Collective: every rank hands the descriptors of its own chunks to every other rank and maps what it receives
+int vtab_exchange(fqsx_dna *c, fqsx_dna::VmTab &v) {
+  const u32 T = c->T, G = c->shard_world, me = c->shard_rank;
+  if (G == 1) return FQSX_OK;
   std::vector<int> mine;
   for (u32 o = me; o < T; o += G) {
-    VMCHK(fqsx_vm::create(c->device, v.chunk_bytes, &v.h[o], e_));
-    c->dev_bytes += v.chunk_bytes; c->vm_own_bytes += v.chunk_bytes;
-    c->dev_bytes_peak = std::max(c->dev_bytes_peak, c->dev_bytes);
-    VMCHK(fqsx_vm::map(c->device, v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, v.h[o], e_));
     int fd = -1;
     VMCHK(fqsx_vm::export_fd(v.h[o], &fd, e_));
     mine.push_back(fd);
@@ -771,34 +814,38 @@ int vtab_alloc(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 cbi
       VMCHK(fqsx_vm::import_fd(theirs[j], &v.h[o], e_));
       close(theirs[j]);
       VMCHK(fqsx_vm::map(c->device, v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, v.h[o], e_));
+      v.mapped[o] = 1;
     }
   }
-  for (u32 o = me; o < T; o += G) {   // own chunks empty (a peer reads them only after a collective that follows on this stream)
-    int rc = dzero(c, v.va + (u64)o * v.chunk_bytes, v.chunk_bytes);
-    if (rc) return rc;
-  }
-  t.slots = (u64 *)v.va;
-  t.cap_mask = cap - 1;
-  t.stride = stride;
-  t.k = k;
-  t.cbits = cbits;
   return FQSX_OK;
+}
+// Collective: an empty table
+int vtab_alloc(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 cbits) {
+  int rc = vtab_reserve(c, t, v, cap, k, cbits);
+  for (u32 o = c->shard_rank; !rc && o < c->T; o += c->shard_world) rc = vtab_create_own(c, v, o);
+  return rc ? rc : vtab_exchange(c, v);
 }
 
 int grow_global(fqsx_dna *c, KTab &t, u64 &cap_field, u64 new_cap) {
   KTab n = t;
   int rc;
   if (c->part) {
-    // every rank takes the same decision in the same phase (the demand is computed from the all-reduced counts and the
-    // exchanged occupancies), so the allocation's descriptor exchange is collective; each rank re-inserts its own
-    // sub-tables, and the phase's all-gather orders that before anybody's next look-up
+    // Chunked tables (partitioned over the ranks, or one GPU's capacity mode).  Every rank takes the same decision in the
+    // same phase (the demand follows from the all-reduced counts and the exchanged occupancies), so the descriptor exchange
+    // is collective; each rank re-inserts its own sub-tables, and the phase's all-gather orders that before anybody's next
+    // look-up.  Sub-table by sub-table -- new chunk, re-insert, old chunk back to the device -- so that the old and the new
+    // table are never alive side by side: the peak is the new table plus ONE old sub-table.
     fqsx_dna::VmTab &v = &t == &c->cfg.g_s ? c->vm_s : c->vm_b, nv;
-    if ((rc = vtab_alloc(c, n, nv, new_cap, t.k, t.cbits))) return rc;
-    const u32 n_own = (c->T - c->shard_rank + c->shard_world - 1) / c->shard_world;
-    LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, n_own, c->shard_rank, c->shard_world);
+    if ((rc = vtab_reserve(c, n, nv, new_cap, t.k, t.cbits))) return rc;
+    for (u32 o = c->shard_rank; o < c->T; o += c->shard_world) {
+      if ((rc = vtab_create_own(c, nv, o))) return rc;
+      LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, 1u, o, 1u);
 #ifndef FQSX_EMU
-    HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
 #endif
+      vtab_drop(c, v, o);
+    }
+    if ((rc = vtab_exchange(c, nv))) return rc;
     vtab_free(c, v);
     v = nv;
   } else {
@@ -1421,6 +1468,7 @@ int fqsx_dna_create_on_partition(const uint8_t *h, int device, uint32_t part, ui
   }
 #endif
   int rc = create_impl(c, h);
+  if (!rc && getenv("FQSX_CHUNKED_TABLES") && atoi(getenv("FQSX_CHUNKED_TABLES"))) rc = fqsx_dna_use_chunked_tables(c);
   if (rc) {
     fqsx_dna_destroy(c);
     return rc;
@@ -1510,6 +1558,7 @@ int fqsx_dna_decode_block(fqsx_dna *c, const uint8_t *const *streams, const uint
 // Pointers marked [codec] are in the codec's memory space: device memory for the HIP build.
 int fqsx_shard_config(fqsx_dna *c, uint32_t rank, uint32_t world) {
   if (!c || world == 0 || rank >= world || world > c->T) { g_err = "bad rank / world size"; return FQSX_E_ARG; }
+  if (c->part && world > 1) { g_err = "a codec with chunked tables cannot be sharded afterwards (fqsx_shard_partition_tables after the attach)"; return FQSX_E_ARG; }
 #ifndef FQSX_EMU
   HIPCHK(hipSetDevice(c->device));
 #endif
@@ -1810,19 +1859,49 @@ int fqsx_shard_attach(fqsx_dna *c, uint32_t rank, uint32_t world, const fqsx_com
   return FQSX_OK;
 }
 
+namespace {
+// the (still empty) s- and b-mer tables again, as chunked tables
+int tables_to_chunks(fqsx_dna *c) {
+  int rc;
+  VMCHK(fqsx_vm::granularity(c->device, &c->vm_gran, e_));
+  if (c->vm_gran < sizeof(u64) || (c->vm_gran & (c->vm_gran - 1))) { g_err = "unexpected allocation granularity"; return FQSX_E_HIP; }
+  c->part = true;
+  dfree(c, c->cfg.g_s.slots);
+  dfree(c, c->cfg.g_b.slots);
+  c->cfg.g_s.slots = c->cfg.g_b.slots = nullptr;
+  if ((rc = vtab_alloc(c, c->cfg.g_s, c->vm_s, c->gs_cap, c->cfg.smer, 12))) return rc;
+  if ((rc = vtab_alloc(c, c->cfg.g_b, c->vm_b, c->gb_cap, c->cfg.bmer, 6))) return rc;
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  return FQSX_OK;
+}
+}  // namespace
+
+// One GPU's capacity mode: the s- and b-mer tables as one chunk of physical memory per sub-table inside a reserved address
+// range (the kernels see the same layout), so that a growth can re-insert sub-table by sub-table and hand each old chunk
+// back before the next new one is made: peak = the new table + one old sub-table, instead of old + new side by side.
+int fqsx_dna_use_chunked_tables(fqsx_dna *c) {
+  if (!c) { g_err = "null argument"; return FQSX_E_ARG; }
+  if (c->part) return FQSX_OK;
+  if (c->k_n[0] || c->shard_world > 1) { g_err = "chunked tables are chosen before the first block (sharded codecs: fqsx_shard_partition_tables)"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(c->device));
+#endif
+  return tables_to_chunks(c);
+}
+
 // Collective, after fqsx_shard_attach and before the first block: from here on this rank holds only the sub-tables of the
 // s- and b-mer tables its workers own; the others' are mapped from their ranks (one node: descriptors over Unix sockets).
 int fqsx_shard_partition_tables(fqsx_dna *c) {
   if (!c || !c->comm_set) { g_err = "no transport attached (fqsx_shard_attach)"; return FQSX_E_ARG; }
-  if (c->part) return FQSX_OK;
-  if (c->k_n[0]) { g_err = "the tables can only be partitioned before the first block"; return FQSX_E_ARG; }
+  if (c->part && (c->shard_world == 1 || !c->mesh.peer.empty())) return FQSX_OK;
+  if (c->part || c->k_n[0]) { g_err = "the tables can only be partitioned before the first block"; return FQSX_E_ARG; }
 #ifndef FQSX_EMU
   HIPCHK(hipSetDevice(c->device));
 #endif
   const u32 G = c->shard_world, me = c->shard_rank;
   int rc;
-  VMCHK(fqsx_vm::granularity(c->device, &c->vm_gran, e_));
-  if (c->vm_gran < sizeof(u64) || (c->vm_gran & (c->vm_gran - 1))) { g_err = "unexpected allocation granularity"; return FQSX_E_HIP; }
   // ---- the descriptor mesh: listen, exchange the names through the transport, connect
   VMCHK(fqsx_vm::mesh_listen(c->mesh, me, G, e_));
   std::vector<u64> words(G, 0);
@@ -1832,17 +1911,8 @@ int fqsx_shard_partition_tables(fqsx_dna *c) {
   COMMCHK(c->comm.allgather_u64(c->comm.ctx, c->d_items, 1, c->d_gathered), "all-gather of the descriptor-socket names");
   if ((rc = d2h_sync(c, words.data(), c->d_gathered, G * sizeof(u64)))) return rc;
   VMCHK(fqsx_vm::mesh_connect(c->mesh, words.data(), e_));
-  // ---- the (still empty) tables again, partitioned
-  c->part = true;
-  dfree(c, c->cfg.g_s.slots);
-  dfree(c, c->cfg.g_b.slots);
-  c->cfg.g_s.slots = c->cfg.g_b.slots = nullptr;
-  if ((rc = vtab_alloc(c, c->cfg.g_s, c->vm_s, c->gs_cap, c->cfg.smer, 12))) return rc;
-  if ((rc = vtab_alloc(c, c->cfg.g_b, c->vm_b, c->gb_cap, c->cfg.bmer, 6))) return rc;
-  // nobody looks a k-mer up before every rank's chunks are cleared
-#ifndef FQSX_EMU
-  HIPCHK(hipStreamSynchronize(c->stream));
-#endif
+  // ---- the (still empty) tables again, partitioned; nobody looks a k-mer up before every rank's chunks are cleared
+  if ((rc = tables_to_chunks(c))) return rc;
   COMMCHK(c->comm.allgather_u64(c->comm.ctx, c->d_items, 1, c->d_gathered), "barrier after the table partition");
 #ifndef FQSX_EMU
   HIPCHK(hipStreamSynchronize(c->stream));

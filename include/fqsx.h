@@ -108,6 +108,13 @@ int fqsx_dna_stats(fqsx_dna *, uint64_t out[64]);
  * [13] bytes of s- + b-mer table memory this rank holds (all of it, or its owners' share with partitioned tables). */
 int fqsx_dna_capacity(fqsx_dna *, uint64_t out[16]);
 
+/* One GPU's capacity mode (no counterpart in the reference, whose sub-tables are separate heap vectors that grow one by one,
+ * fqs/ht_kmer.h:88-112): before the first block, switch the s- and b-mer tables to one chunk of physical memory per
+ * sub-table inside one reserved address range (HIP virtual-memory API).  The kernels see the same layout; a growth then
+ * re-inserts sub-table by sub-table and returns each old chunk before the next new one is made, so the peak is the new table
+ * plus one old sub-table instead of old + new side by side.  Also chosen by the environment variable FQSX_CHUNKED_TABLES=1. */
+int fqsx_dna_use_chunked_tables(fqsx_dna *);
+
 /* Sharded mode (reference: the T x T mailboxes of fqs/application.h:56-59 and their owner-side
  * application, fqs/dna.cpp:825-847, :2393-2472): logical worker w -- coder state, RNG streams, local tables and the
  * sub-tables it owns -- lives on rank w % world; every rank keeps a replica of all sub-tables for the look-ups.

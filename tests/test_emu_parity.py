@@ -36,6 +36,24 @@ def test_growth_posted_by_the_device_is_recovered(name, monkeypatch):
     check_against_fqs(emu, c1_records(), name)
 
 
+@pytest.mark.parametrize("name", ["c1_10k_s_t4.fqs", "c1_10k_o_t4.fqs"])
+def test_chunked_tables_grow_sub_table_by_sub_table(name, monkeypatch):
+    """FQSX_CHUNKED_TABLES / fqsx_dna_use_chunked_tables: one chunk of memory per sub-table inside a reserved address range
+    (memfd + mmap in this build, hipMemCreate + hipMemMap on the GPU); a growth re-inserts sub-table by sub-table and returns
+    each old chunk before the next new one exists.  Streams stay the reference's; the peak stays below old + new."""
+    monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    monkeypatch.setenv("FQSX_CHUNKED_TABLES", "1")
+    codec = check_against_fqs(emu, c1_records(), name)
+    cap = codec.capacity()
+    assert cap["growths"] >= 4 and cap["table_bytes_held"] == 8 * (cap["smer_slots"] + cap["bmer_slots"])
+    monkeypatch.setenv("FQSX_CHUNKED_TABLES", "0")
+    plain = check_against_fqs(emu, c1_records(), name).capacity()
+    assert (plain["smers"], plain["bmers"], plain["growths"]) == (cap["smers"], cap["bmers"], cap["growths"])
+    # the last growth doubled one table: side by side that is + 1/2 of the new table on top of the final footprint; in chunks
+    # only one old sub-table (1/8 of that here: T = 4)
+    assert cap["device_bytes_peak"] - cap["device_bytes"] < (plain["device_bytes_peak"] - plain["device_bytes"]) // 2, (cap, plain)
+
+
 @pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
 def test_emu_matches_reference_ragged(name):
     check_against_fqs(emu, c4_records(), name)

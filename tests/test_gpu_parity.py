@@ -33,6 +33,18 @@ def test_hip_growth_posted_by_the_device_is_recovered(name, monkeypatch):
     check_against_fqs(gpu, c1_records(), name)
 
 
+@pytest.mark.parametrize("name", ["c1_10k_s_t4.fqs", "c1_10k_o_t1.fqs"])
+def test_hip_chunked_tables_grow_sub_table_by_sub_table(name, monkeypatch):
+    """fqsx_dna_use_chunked_tables: the k-mer tables in hipMemCreate chunks (one per sub-table) mapped into one reserved range;
+    growths re-insert sub-table by sub-table and give each old chunk back at once.  Same streams, same table contents."""
+    from fqsqueezer_amd.codec import DnaCodec
+    monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    codec = check_against_fqs(lambda h: DnaCodec(h, device=0, chunked_tables=True), c1_records(), name)
+    cap, plain = codec.capacity(), check_against_fqs(gpu, c1_records(), name).capacity()
+    assert cap["growths"] >= 4 and cap["table_bytes_held"] == 8 * (cap["smer_slots"] + cap["bmer_slots"])
+    assert (plain["smers"], plain["bmers"], plain["growths"]) == (cap["smers"], cap["bmers"], cap["growths"])
+
+
 @pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
 def test_hip_matches_reference_ragged(name):
     check_against_fqs(gpu, c4_records(), name)
