@@ -215,18 +215,24 @@ class MetaCodec:
             pass
 
 
-def sort_order(bases: np.ndarray, read_off: np.ndarray, device: int = 0, lib_path: Optional[str] = None) -> List[np.ndarray]:
+def sort_order(bases: np.ndarray, read_off: np.ndarray, device: int = 0, lib_path: Optional[str] = None,
+               max_batch_bases: int = 0, stats: Optional[dict] = None) -> List[np.ndarray]:
     """Read order of `fqs e -om s` (fqsx_sort_order: GPU radix sort + ranks, host replay of std::sort per bin).
-    Returns one index array per non-empty bin, in bin order -- the same shape hostpipe.sorted_order_exact returns."""
+    Returns one index array per non-empty bin, in bin order -- the same shape hostpipe.sorted_order_exact returns.
+    max_batch_bases > 0: bounded device memory (fqsx_sort_order_batched: bins packed into batches of at most that many bases)."""
     lib = load_library(lib_path)
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
     n = len(read_off) - 1
     order = np.empty(max(n, 1), dtype=np.uint32)
     bins = np.zeros(257, dtype=np.uint32)
-    rc = lib.fqsx_sort_order(bases.ctypes.data, read_off.ctypes.data, n, device, order.ctypes.data, bins.ctypes.data)
+    nb = C.c_uint32(0)
+    lib.fqsx_sort_order_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    rc = lib.fqsx_sort_order_batched(bases.ctypes.data, read_off.ctypes.data, n, device, max_batch_bases, order.ctypes.data, bins.ctypes.data, C.byref(nb))
     if rc:
         raise FqsxError(f"fqsx_sort_order: {rc}: {lib.fqsx_last_error().decode()}")
+    if stats is not None:
+        stats["batches"] = nb.value
     return [order[bins[b]:bins[b + 1]].astype(np.int64) for b in range(256) if bins[b + 1] > bins[b]]
 
 

@@ -2429,10 +2429,16 @@ static int sort_rank_impl(fqsx_dna *c, const u8 *bases, const u64 *off, u32 n, s
   return FQSX_OK;
 }
 
-extern "C" int fqsx_sort_order(const uint8_t *bases, const uint64_t *read_off, uint32_t n_reads, int device, uint32_t *order_out,
-                               uint32_t *bin_start /*[257]*/) {
+// The reference keeps device^Whost memory bounded by binning to disk first (preprocess_se, application.cpp:349-412) and
+// sorting bin after bin.  Same structure here: the reads are binned on the host by their first four bases (the bins are
+// ranges of the sort order), consecutive bins are packed into batches of at most `max_batch_bases` bases, and every batch
+// goes through the GPU sort on its own -- device memory is bounded by the largest batch (at least the largest bin), not
+// by the file.  max_batch_bases = 0: one batch (the whole file in one allocation).
+extern "C" int fqsx_sort_order_batched(const uint8_t *bases, const uint64_t *read_off, uint32_t n_reads, int device, uint64_t max_batch_bases,
+                                       uint32_t *order_out, uint32_t *bin_start /*[257]*/, uint32_t *n_batches_out) {
   if (!bases || !read_off || !order_out || !bin_start) { g_err = "null argument"; return FQSX_E_ARG; }
   for (u32 b = 0; b <= 256; ++b) bin_start[b] = 0;
+  if (n_batches_out) *n_batches_out = 0;
   if (n_reads == 0) return FQSX_OK;
 #ifndef FQSX_EMU
   int ndev = 0;
@@ -2440,44 +2446,87 @@ extern "C" int fqsx_sort_order(const uint8_t *bases, const uint64_t *read_off, u
   if (device < 0 || device >= ndev) { g_err = "bad device ordinal"; return FQSX_E_ARG; }
   HIPCHK(hipSetDevice(device));
 #endif
+  // bins in input order (preprocess_se, application.cpp:383-391: a position past the read counts as code 3 there
+  // because it lands on the line feed)
+  auto nt = [](u8 ch) -> u32 { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u; };
+  std::vector<u8> bin(n_reads);
+  std::vector<u64> bin_bases(256, 0);
+  for (u32 r = 0; r < n_reads; ++r) {
+    const u64 b = read_off[r];
+    const u32 len = (u32)(read_off[r + 1] - b);
+    u32 id = 0;
+    for (u32 i = 0; i < 4; ++i) id = (id << 2) | (i < len ? nt(bases[b + i]) : 3u);
+    bin[r] = (u8)id;
+    ++bin_start[id + 1];
+    bin_bases[id] += len;
+  }
+  for (u32 b = 0; b < 256; ++b) bin_start[b + 1] += bin_start[b];
+  std::vector<u32> cur(bin_start, bin_start + 256);
+  std::vector<u32> member(n_reads);   // reads grouped by bin, input order inside a bin
+  for (u32 r = 0; r < n_reads; ++r) member[cur[bin[r]]++] = r;
   fqsx_dna mem{};
   fqsx_dna *c = &mem;
   c->T = 1; c->device = device; c->profiling = false;
 #ifndef FQSX_EMU
   HIPCHK(hipStreamCreate(&c->stream));
 #endif
+  int rc = FQSX_OK;
+  u32 n_batches = 0;
+  std::vector<u8> gb;
+  std::vector<u64> go;
   std::vector<u32> rank;
-  int rc = sort_rank_impl(c, bases, read_off, n_reads, rank, nullptr);
+  std::vector<std::pair<u32, u32>> v;   // (rank, read)
+  for (u32 b0 = 0; b0 < 256 && !rc;) {
+    u32 b1 = b0 + 1;
+    u64 nb = bin_bases[b0];
+    while (b1 < 256 && (max_batch_bases == 0 || nb + bin_bases[b1] <= max_batch_bases)) nb += bin_bases[b1++];
+    const u32 lo = bin_start[b0], hi = bin_start[b1], n = hi - lo;
+    if (n) {
+      const u8 *pb = bases;
+      const u64 *po = read_off;
+      const bool whole = lo == 0 && hi == n_reads;
+      if (!whole) {   // the batch's reads side by side (what a bin file of the reference holds)
+        gb.resize(nb ? nb : 1);
+        go.resize((u64)n + 1);
+        u64 w = 0;
+        for (u32 i = 0; i < n; ++i) {
+          const u32 r = member[lo + i];
+          const u64 len = read_off[r + 1] - read_off[r];
+          go[i] = w;
+          memcpy(gb.data() + w, bases + read_off[r], len);
+          w += len;
+        }
+        go[n] = w;
+        pb = gb.data(); po = go.data();
+      }
+      rc = sort_rank_impl(c, pb, po, n, rank, nullptr);
 #ifndef FQSX_EMU
-  (void)hipStreamSynchronize(c->stream);
+      (void)hipStreamSynchronize(c->stream);
 #endif
-  std::vector<void *> a = c->allocs;
-  for (void *p : a) dfree(c, p);
+      std::vector<void *> a = c->allocs;
+      for (void *p : a) dfree(c, p);
+      if (rc) break;
+      // libstdc++'s std::sort per bin on the ranks (ranks of one batch are comparable; a bin never spans batches)
+      v.resize(n);
+      for (u32 i = 0; i < n; ++i) v[i] = std::make_pair(whole ? rank[member[lo + i]] : rank[i], member[lo + i]);
+      for (u32 b = b0; b < b1; ++b)
+        std::sort(v.begin() + (bin_start[b] - lo), v.begin() + (bin_start[b + 1] - lo),
+                  [](const std::pair<u32, u32> &x, const std::pair<u32, u32> &y) { return x.first < y.first; });
+      for (u32 i = 0; i < n; ++i) order_out[lo + i] = v[i].second;
+      ++n_batches;
+    }
+    b0 = b1;
+  }
 #ifndef FQSX_EMU
   (void)hipStreamDestroy(c->stream);
 #endif
-  if (rc) return rc;
-  // bins in input order (preprocess_se, application.cpp:383-391: a position past the read counts as code 3 there
-  // because it lands on the line feed), then libstdc++'s std::sort per bin on the ranks
-  auto nt = [](u8 ch) -> u32 { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u; };
-  std::vector<u32> bin(n_reads);
-  for (u32 r = 0; r < n_reads; ++r) {
-    const u64 b = read_off[r];
-    const u32 len = (u32)(read_off[r + 1] - b);
-    u32 id = 0;
-    for (u32 i = 0; i < 4; ++i) id = (id << 2) | (i < len ? nt(bases[b + i]) : 3u);
-    bin[r] = id;
-    ++bin_start[id + 1];
-  }
-  for (u32 b = 0; b < 256; ++b) bin_start[b + 1] += bin_start[b];
-  std::vector<u32> cur(bin_start, bin_start + 256);
-  std::vector<std::pair<u32, u32>> v(n_reads);   // (rank, read), grouped by bin, input order inside a bin
-  for (u32 r = 0; r < n_reads; ++r) v[cur[bin[r]]++] = std::make_pair(rank[r], r);
-  for (u32 b = 0; b < 256; ++b)
-    std::sort(v.begin() + bin_start[b], v.begin() + bin_start[b + 1],
-              [](const std::pair<u32, u32> &x, const std::pair<u32, u32> &y) { return x.first < y.first; });
-  for (u32 i = 0; i < n_reads; ++i) order_out[i] = v[i].second;
-  return FQSX_OK;
+  if (n_batches_out) *n_batches_out = n_batches;
+  return rc;
+}
+
+extern "C" int fqsx_sort_order(const uint8_t *bases, const uint64_t *read_off, uint32_t n_reads, int device, uint32_t *order_out,
+                               uint32_t *bin_start /*[257]*/) {
+  return fqsx_sort_order_batched(bases, read_off, n_reads, device, 0, order_out, bin_start, nullptr);
 }
 
 #ifdef FQSX_EMU   // the emulation build is one translation unit

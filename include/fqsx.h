@@ -221,6 +221,13 @@ void fqsx_id_destroy(fqsx_id *);
  * bin; bin_start[257] = offsets of the bins inside order_out. */
 int fqsx_sort_order(const uint8_t *bases, const uint64_t *read_off, uint32_t n_reads, int device,
                     uint32_t *order_out, uint32_t *bin_start);
+/* The same with bounded device memory, the way the reference bounds its host memory (bins on disk, sorted one after the
+ * other, fqs/application.cpp:349-412, 1595-1626): the reads are binned by their first four bases on the host, consecutive
+ * bins are packed into batches of at most max_batch_bases bases (a bin larger than that is a batch of its own), and every
+ * batch is uploaded and sorted separately.  Same order as fqsx_sort_order (= max_batch_bases 0: one batch).
+ * n_batches_out (optional): GPU passes made. */
+int fqsx_sort_order_batched(const uint8_t *bases, const uint64_t *read_off, uint32_t n_reads, int device, uint64_t max_batch_bases,
+                            uint32_t *order_out, uint32_t *bin_start, uint32_t *n_batches_out);
 
 /* Host-side read order inside one bin of `fqs e -om s`: std::sort with the comparator of
  * CSortedFASTQFile::sort_reads (fqs/io.h:499-528) applied to reads idx_in[0..n) (indices into off[]),
