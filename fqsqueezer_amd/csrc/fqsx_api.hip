@@ -1034,6 +1034,16 @@ int block_prepare(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u64 *h
     }
     cfg.l_pe.cap_mask = need_lpe - 1;
     cfg.l_pe.stride = need_lpe;
+    // mates longer than the LDS staging size: three scratch lines per worker (codes of either mate, reverse-complement line)
+    u64 max_len = 0;
+    for (u32 i = 0; i < n_reads; ++i) max_len = std::max(max_len, h_off[i + 1] - h_off[i]);
+    if (!decode && max_len > FQSX_RD_LDS && max_len + 128 > cfg.pe_scr_cap) {
+      if (cfg.pe_scr) dfree(c, cfg.pe_scr);
+      const u64 cap = (max_len + max_len / 4 + 128 + 63) & ~63ull;
+      if ((rc = dalloc(c, &p, (u64)T * 3 * cap, true))) return rc;
+      cfg.pe_scr = (u8 *)p;
+      cfg.pe_scr_cap = cap;
+    }
   }
   // active geometry of the local tables for this block (cleared after every phase)
   cfg.l_b.cap_mask = need_lb - 1; cfg.l_b.stride = need_lb;

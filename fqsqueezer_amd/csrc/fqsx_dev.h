@@ -225,6 +225,8 @@ struct Wk {
   u32 sc_taken;                         // scout chunks of the current epoch released so far
   u32 sc_base;                          // ring slot of the epoch's first chunk
   bool rq_early;                        // request mode: the coming suffix() call's request is posted already
+  bool rq_noscout;                      // request mode: the coming suffix() call goes without the scout waves (its sequence is a
+                                        // scratch line this wave has just written: long reverse-complement part of a second mate)
   HeadRec *rec;                         // read-head wave: where the head's output goes (null: code / push directly)
   u32 rec_idx;                          // ... and the read's index within the launch
   bool piped;                           // this wave only resolves; a second wave of the workgroup drains the coding queue
@@ -3121,9 +3123,10 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
   if (w.rq_early) w.rq_early = false;   // (prefix_sorted has posted this call's request already)
   else if (w.scout && w.sc_reqmode && i < size) {   // no read-head wave: this call is one request to the scout waves
     w.sc_read += 1;
-    w.sc_abandoned = false;
-    scout_restart(w, w.sc_read, i, w.s_let, 0, false);
+    w.sc_abandoned = w.rq_noscout;
+    if (!w.rq_noscout) scout_restart(w, w.sc_read, i, w.s_let, 0, false);
   }
+  w.rq_noscout = false;
   const u32 dbg = cfg->dbg;
   if ((dbg & FQSX_DBG_ABANDON) && w.scout && w.sc_read % 3 == 1) w.sc_abandoned = true;   // (test switch) this read without the scouts
   // A k-mer correction at position q (repair_kmers_*, or the adoption of the uncorrected k-mers) changes what stage P
@@ -4204,6 +4207,7 @@ FQ_DEV void encode_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_
   w.sc_taken = 0;
   w.sc_base = 0;
   w.rq_early = false;
+  w.rq_noscout = false;
   w.cq_head = w.cq_tail = 0;
   w.c_r_sym = 0;
   for (u32 i = 0; i < ST_N; ++i) w.st[i] = 0;

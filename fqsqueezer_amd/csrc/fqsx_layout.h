@@ -182,6 +182,8 @@ struct DevCfg {
   u8 *dout;                    // decoded block (ASCII), reads at read_off[]
   u8 *dscratch;                // [T][2][dcap] 0..4 codes of the read being decoded (+ reverse-complement line)
   u64 dcap;
+  u8 *pe_scr;                  // paired-end, mates longer than FQSX_RD_LDS: [T][3][pe_scr_cap] code line of either mate and the
+  u64 pe_scr_cap;              // reverse-complement line of an anchored second mate (what LDS holds for shorter mates); else null
   u32 *err;                    // device error word (0 = ok)
   u64 *trace;                  // -DFQSX_TIMING builds: [launch][worker][8] clock stamps of the roles (else null)
   // Sharded mode: worker w -- its coder state, RNG streams, local tables and the sub-tables it owns --
@@ -208,7 +210,7 @@ enum {
   FQSX_ERR_CTX_FULL = 4,
   FQSX_ERR_MAIL_FULL = 5,
   FQSX_ERR_PE_FULL = 6,
-  FQSX_ERR_PE_READ_TOO_LONG = 7,
+  FQSX_ERR_PE_READ_TOO_LONG = 7,  // (a mate longer than the scratch lines the host sized for the block: cannot happen)
   FQSX_ERR_DECODE = 8,
   FQSX_ERR_PIPE = 9,              // the coding queue between the two waves of a worker stalled
 };

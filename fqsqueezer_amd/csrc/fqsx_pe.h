@@ -279,7 +279,13 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
   WgShared *sm = w.sm;
   const int k = (int)cfg->bmer;
   const u64 vm = pe_value_mask(cfg);
-  if (size1 > FQSX_RD_LDS || size2 > FQSX_RD_LDS) { w.err = FQSX_ERR_PE_READ_TOO_LONG; return; }
+  // Code lines of the two mates: LDS (w.rdp as staged by the read head, sm->r2c) up to FQSX_RD_LDS bases, the worker's
+  // scratch lines in HBM beyond (the reference takes reads of up to 2^24 bases, meta.cpp:69; the suffix machinery itself
+  // reads a long sequence from its ASCII source, rd_sym)
+  const bool long1 = size1 > FQSX_RD_LDS, long2 = size2 > FQSX_RD_LDS;
+  u8 *scr = cfg->pe_scr ? cfg->pe_scr + (u64)w.tid * 3 * cfg->pe_scr_cap : nullptr;
+  if ((long1 || long2) && (!scr || size1 + 64 > cfg->pe_scr_cap || size2 + 64 > cfg->pe_scr_cap)) { w.err = FQSX_ERR_PE_READ_TOO_LONG; return; }
+  u8 *c2 = long2 ? scr + cfg->pe_scr_cap : sm->r2c;
   u64 m1[4] = {0, 0, 0, 0}, a1[3] = {0, 0, 0}, x1 = 0, a2[3] = {0, 0, 0}, x2 = 0;
   u32 mpos = 0;
   bool anchored = false;
@@ -298,30 +304,38 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
       // (a duplicate first mate returns early from the coder but sm->rd was staged before that)
       // minimizers of the first mate: 4 windows for the look-up (dna.cpp:1761-1769), 3 + 1 for the inserts (:1055-1083)
       TM_BEGIN(t_mz);
+      if (long1) {
+        FQ_SYNC_MEM();
+        for (u32 i = FQ_LANE; i < size1; i += FQ_WAVE) scr[i] = (u8)dna_code(p1[i]);
+        FQ_SYNC_MEM();
+      }
+      const u8 *c1 = long1 ? scr : w.rdp;
       {
         int mss = (int)size1 - k + 1, s1 = mss / 4, s2 = 2 * mss / 4, s3 = 3 * mss / 4;
-        m1[0] = pe_find_minimizer_w(cfg, w.rdp, 0, s1 + k - 1);
-        m1[1] = pe_find_minimizer_w(cfg, w.rdp, s1, s2 - s1 + k - 1);
-        m1[2] = pe_find_minimizer_w(cfg, w.rdp, s2, s3 - s2 + k - 1);
-        m1[3] = pe_find_minimizer_w(cfg, w.rdp, s3, (int)size1 - s3);
+        m1[0] = pe_find_minimizer_w(cfg, c1, 0, s1 + k - 1);
+        m1[1] = pe_find_minimizer_w(cfg, c1, s1, s2 - s1 + k - 1);
+        m1[2] = pe_find_minimizer_w(cfg, c1, s2, s3 - s2 + k - 1);
+        m1[3] = pe_find_minimizer_w(cfg, c1, s3, (int)size1 - s3);
         int a = mss / 3, b = 2 * mss / 3;
-        a1[0] = pe_find_minimizer_w(cfg, w.rdp, 0, a + k - 1);
-        a1[1] = pe_find_minimizer_w(cfg, w.rdp, a, b - a + k - 1);
-        a1[2] = pe_find_minimizer_w(cfg, w.rdp, b, (int)size1 - b);
+        a1[0] = pe_find_minimizer_w(cfg, c1, 0, a + k - 1);
+        a1[1] = pe_find_minimizer_w(cfg, c1, a, b - a + k - 1);
+        a1[2] = pe_find_minimizer_w(cfg, c1, b, (int)size1 - b);
         int mid1 = ((int)size1 + k) / 2;
-        x1 = (~pe_find_maximizer(cfg, w.rdp, mid1 - k + 1, (int)size1 - (mid1 - k + 1))) & vm;
+        x1 = (~pe_find_maximizer(cfg, c1, mid1 - k + 1, (int)size1 - (mid1 - k + 1))) & vm;
       }
       // second mate's codes
       FQ_SYNC();
-      for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) sm->r2c[i] = (u8)dna_code(p2[i]);
+      FQ_SYNC_MEM();
+      for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) c2[i] = (u8)dna_code(p2[i]);
+      FQ_SYNC_MEM();
       FQ_SYNC();
       {
         int mss = (int)size2 - k + 1, a = mss / 3, b = 2 * mss / 3;
-        a2[0] = pe_find_minimizer_w(cfg, sm->r2c, 0, a + k - 1);
-        a2[1] = pe_find_minimizer_w(cfg, sm->r2c, a, b - a + k - 1);
-        a2[2] = pe_find_minimizer_w(cfg, sm->r2c, b, (int)size2 - b);
+        a2[0] = pe_find_minimizer_w(cfg, c2, 0, a + k - 1);
+        a2[1] = pe_find_minimizer_w(cfg, c2, a, b - a + k - 1);
+        a2[2] = pe_find_minimizer_w(cfg, c2, b, (int)size2 - b);
         int mid2 = ((int)size2 + k) / 2;
-        x2 = (~pe_find_minimizer_w(cfg, sm->r2c, mid2 - k + 1, (int)size2 - (mid2 - k + 1))) & vm;  // sic: minimizer (dna.cpp:1087)
+        x2 = (~pe_find_minimizer_w(cfg, c2, mid2 - k + 1, (int)size2 - (mid2 - k + 1))) & vm;  // sic: minimizer (dna.cpp:1087)
       }
       TM_END_PE(w, TM_LQ, t_mz);
       TM_BEGIN(t_pf);
@@ -342,7 +356,7 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
           bool ok = e < size2 && e + 1 >= (u32)k;
           if (ok)
             for (int t = 0; t < k; ++t) {
-              u32 c = sm->r2c[e + 1 - k + t];
+              u32 c = c2[e + 1 - k + t];
               if (c == 4) ok = false;
               v = (v << 2) | (c & 3);
             }
@@ -382,23 +396,43 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
         else { MPOS_ENC(0, 255); MPOS_ENC(3, mpos >> 16); MPOS_ENC(4, (mpos >> 8) & 0xff); MPOS_ENC(5, mpos & 0xff); }
 #undef MPOS_ENC
         // CompressDirectWithMinim (dna.cpp:1559-1638): right part forwards from the anchor ...
-        FQ_SYNC();
-        for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) w.rdp[i] = sm->r2c[i];
-        FQ_SYNC();
-        pe_seed_kmers(w, w.rdp, mpos, mpos + (u32)k);
+        if (!long2) {
+          FQ_SYNC();
+          for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) w.rdp[i] = c2[i];
+          FQ_SYNC();
+        }
+        pe_seed_kmers(w, long2 ? c2 : w.rdp, mpos, mpos + (u32)k);
         run = true; j_start = (u32)k + mpos; j_hist0 = mpos;
         TM_END_PE(w, TM_SP_HIT, t_rest);
       }
     } else if (anchored) {
       // ... then the left part on the reverse complement, anchored at the same b-mer
       const u32 rsz = mpos + (u32)k;
-      FQ_SYNC();
-      for (u32 i = FQ_LANE; i < rsz; i += FQ_WAVE) {
-        u32 c = sm->r2c[rsz - 1 - i];
-        w.rdp[i] = (u8)(c == 4 ? 4 : 3 - c);
+      if (rsz <= FQSX_RD_LDS) {
+        FQ_SYNC();
+        FQ_SYNC_MEM();
+        for (u32 i = FQ_LANE; i < rsz; i += FQ_WAVE) {
+          u32 c = c2[rsz - 1 - i];
+          w.rdp[i] = (u8)(c == 4 ? 4 : 3 - c);
+        }
+        FQ_SYNC();
+        pe_seed_kmers(w, w.rdp, 0, (u32)k);
+      } else {
+        // the reverse complement as a sequence of its own in the third scratch line (ASCII: what the suffix machinery reads
+        // of a long sequence); this wave has written it, so the call goes without the scout waves
+        u8 *rline = scr + 2 * cfg->pe_scr_cap;
+        FQ_SYNC_MEM();
+        for (u32 i = FQ_LANE; i < rsz; i += FQ_WAVE) {
+          u32 c = c2[rsz - 1 - i];
+          rline[i] = c == 4 ? (u8)'N' : (u8)"TGCA"[c];
+        }
+        FQ_SYNC_MEM();
+        for (u32 i = FQ_LANE; i < (u32)k; i += FQ_WAVE) { u32 c = c2[rsz - 1 - i]; scr[i] = (u8)(c == 4 ? 4 : 3 - c); }   // (mate 1's line is free by now)
+        FQ_SYNC_MEM();
+        pe_seed_kmers(w, scr, 0, (u32)k);
+        j_p = rline;
+        w.rq_noscout = true;
       }
-      FQ_SYNC();
-      pe_seed_kmers(w, w.rdp, 0, (u32)k);
       run = true; j_size = rsz; j_start = (u32)k; j_rev = true;
     }
     if (run) suffix(w, j_p, j_size, j_orig, j_start, j_rev, j_hist0);
@@ -410,7 +444,7 @@ FQ_DEV void compress_pair(Wk &w, const u8 *p1, u32 size1, const u8 *p2, u32 size
       // update_s_letters(p2), dna.cpp:1635
       u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0;
       for (u32 i = FQ_LANE; i < size2; i += FQ_WAVE) {
-        u32 c = sm->r2c[i];
+        u32 c = c2[i];
         h0 += c == 0; h1 += c == 1; h2 += c == 2; h3 += c == 3;
       }
       h0 = wave_sum32(h0); h1 = wave_sum32(h1); h2 = wave_sum32(h2); h3 = wave_sum32(h3);

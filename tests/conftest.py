@@ -159,6 +159,15 @@ def c5_records():
             hp.Records([read_id(i, 2) for i in range(4000)], r2, synth_quals(4000, 100, 6)))
 
 
+def c20_records():
+    """240 pairs x 5000 bp: mates longer than the 4096 bases a worker stages in LDS (the reference takes up to 2^24)"""
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.synth import read_id, synth_pairs, synth_quals
+    r1, r2 = synth_pairs(240, 5000, 40000, 21, frag_min=6000, frag_max=9000)
+    return (hp.Records([read_id(i, 1) for i in range(240)], r1, synth_quals(240, 5000, 21)),
+            hp.Records([read_id(i, 2) for i in range(240)], r2, synth_quals(240, 5000, 22)))
+
+
 def check_against_fqs_pe(make_codec, recs, fqs_name):
     from fqsqueezer_amd import hostpipe as hp
     rec1, rec2 = recs

@@ -4,7 +4,7 @@ in the GPU-less container; the 64-lane paths are covered by tests/test_gpu_parit
 import numpy as np
 import pytest
 
-from conftest import EMU_LIB, c1_records, c4_records, c5_records, c7_records, check_against_digest, check_against_fqs, check_against_fqs_pe, check_decode_fqs
+from conftest import c20_records, EMU_LIB, c1_records, c4_records, c5_records, c7_records, check_against_digest, check_against_fqs, check_against_fqs_pe, check_decode_fqs
 from fqsqueezer_amd import hostpipe as hp
 from fqsqueezer_amd.codec import DnaCodec
 from oracle.pyoracle import OracleCodec
@@ -62,6 +62,14 @@ def test_emu_matches_reference_ragged(name):
 @pytest.mark.parametrize("name", ["c5_pe4k_o_t1.fqs", "c5_pe4k_o_t4.fqs", "c5_pe4k_s_t1.fqs", "c5_pe4k_s_t4.fqs"])
 def test_emu_matches_reference_paired_end(name):
     check_against_fqs_pe(emu, c5_records(), name)
+
+
+@pytest.mark.parametrize("name", ["c20_pelong_o_t2.fqs", "c20_pelong_s_t2.fqs"])
+def test_emu_paired_end_mates_longer_than_the_lds_staging(name):
+    """5000 bp mates (the reference takes up to 2^24 bases, fqs/meta.cpp:69): code lines and the reverse-complement line of an
+    anchored second mate in the worker's HBM scratch instead of LDS; encode against the reference's file, then decode it"""
+    check_against_fqs_pe(emu, c20_records(), name)
+    check_decode_fqs(emu, c20_records(), name)
 
 
 @pytest.mark.parametrize("name", ["c7_mixedlen_o_t3.fqs", "c7_mixedlen_s_t3.fqs"])

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import c1_records, c4_records, c5_records, c7_records, check_against_digest, check_against_fqs, check_against_fqs_pe, check_decode_fqs
+from conftest import c20_records, c1_records, c4_records, c5_records, c7_records, check_against_digest, check_against_fqs, check_against_fqs_pe, check_decode_fqs
 from oracle.pyoracle import OracleCodec, lib
 
 
@@ -21,6 +21,11 @@ def test_oracle_matches_reference_ragged(name):
 @pytest.mark.parametrize("name", ["c5_pe4k_o_t1.fqs", "c5_pe4k_o_t4.fqs", "c5_pe4k_s_t1.fqs", "c5_pe4k_s_t4.fqs"])
 def test_oracle_matches_reference_paired_end(name):
     check_against_fqs_pe(OracleCodec, c5_records(), name)
+
+
+@pytest.mark.parametrize("name", ["c20_pelong_o_t2.fqs", "c20_pelong_s_t2.fqs"])
+def test_oracle_matches_reference_long_paired_end_mates(name):
+    check_against_fqs_pe(OracleCodec, c20_records(), name)
 
 
 @pytest.mark.parametrize("name", ["c7_mixedlen_o_t3.fqs", "c7_mixedlen_s_t3.fqs"])

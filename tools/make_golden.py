@@ -11,6 +11,7 @@ Fixtures (data only -- inputs are re-generated deterministically by fqsqueezer_a
   c6_20k_gs300_s_t2.json    20k x 100bp, G=1Mbp, seed 6, -gs 300 (k = 12/17/21/26: 4 GiB p-mer vector, 256-way partial look-ups)
   c9_20k150_gs3100_s_t2.json  20k x 150bp, G=200kbp, seed 9, DEFAULT -gs 3100 (k = 13/18/21/27: 16 GiB p-mer vector, up to 1024-way
                             partial look-ups; the reference needs ~45 GiB and ~10 min for it)
+  c20_pelong_{o,s}_t2.fqs   240 pairs x 5000bp (fragments 6000-9000), G=40kbp, seed 21, `-p`, -gs 1 (mates beyond the LDS staging size)
   c7_mixedlen_{o,s}_t3.fqs  1500 reads of 20-31 / 60-199 / 4200-5999 bp with N runs, G=40kbp, seed 7, -gs 1
   c8_qual_{o,8,4,2}_t4.json, c8_qual_pe8_t3.json   per-block SHA-256 of the QUALITY streams (all four quality modes; PE)
   c10_full_*.fqs/.json     3000 x 100bp (G=80kbp, seed 10) with varied Illumina-style ids: complete default-mode files
@@ -108,6 +109,17 @@ def main():
                 if not os.path.exists(out):
                     subprocess.check_call([REF, "e", "-p", "-om", om, "-t", str(t), "-gs", "1", "-qm", "n", "-im", "n", "-v", "0",
                                            "-tmp", os.path.join(a.work, "tmpp_"), "-out", out, f1, f2], stdout=subprocess.DEVNULL)
+    if a.only in ("", "c20"):   # paired-end mates longer than the 4096 bases a worker stages in LDS (the reference takes up to 2^24, fqs/meta.cpp:69)
+        from fqsqueezer_amd.synth import synth_pairs
+        r1, r2 = synth_pairs(240, 5000, 40000, 21, frag_min=6000, frag_max=9000)
+        f1, f2 = os.path.join(a.work, "c20_1.fq"), os.path.join(a.work, "c20_2.fq")
+        write_fastq(f1, r1, seed=21, mate=1)
+        write_fastq(f2, r2, seed=22, mate=2)
+        for om in "os":
+            out = os.path.join(GOLD, f"c20_pelong_{om}_t2.fqs")
+            if not os.path.exists(out):
+                subprocess.check_call([REF, "e", "-p", "-om", om, "-t", "2", "-gs", "1", "-qm", "n", "-im", "n", "-v", "0",
+                                       "-tmp", os.path.join(a.work, "tmpq_"), "-out", out, f1, f2], stdout=subprocess.DEVNULL)
     if a.only in ("", "c6"):
         fq = os.path.join(a.work, "c6.fq")
         if not os.path.exists(fq):
