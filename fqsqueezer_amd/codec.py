@@ -237,13 +237,23 @@ def sort_order(bases: np.ndarray, read_off: np.ndarray, device: int = 0, lib_pat
 
 
 class IdCodec:
-    """Host-side read-id stream of the container (fqsx_id_*; header byte 7 = id mode)."""
+    """Read-id stream of the container (header byte 7 = id mode).  device = None: the host coder (fqsx_id_*, one host thread per
+    worker); device = ordinal: the GPU coder (fqsx_idg_*, one wavefront per worker) -- the same bytes."""
 
-    def __init__(self, header: bytes, lib_path: Optional[str] = None):
+    def __init__(self, header: bytes, lib_path: Optional[str] = None, device: Optional[int] = None):
         self._lib = load_library(lib_path)
         self.T = header[4]
         self._h = C.c_void_p()
-        if self._lib.fqsx_id_create(bytes(header), C.byref(self._h)):
+        self._gpu = device is not None
+        L = self._lib
+        if self._gpu:
+            L.fqsx_idg_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+            L.fqsx_idg_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+            L.fqsx_idg_destroy.argtypes = [C.c_void_p]
+            L.fqsx_idg_destroy.restype = None
+            if L.fqsx_idg_create(bytes(header), device, C.byref(self._h)):
+                raise FqsxError(f"fqsx_idg_create: {L.fqsx_last_error().decode()}")
+        elif L.fqsx_id_create(bytes(header), C.byref(self._h)):
             raise FqsxError("fqsx_id_create failed")
         self._streams = (C.c_void_p * self.T)()
         self._lens = (C.c_uint64 * self.T)()
@@ -251,15 +261,15 @@ class IdCodec:
     def encode_block(self, ids: np.ndarray, id_off: np.ndarray, paired: bool = False) -> List[bytes]:
         ids = np.ascontiguousarray(ids, dtype=np.uint8)
         id_off = np.ascontiguousarray(id_off, dtype=np.uint64)
-        rc = self._lib.fqsx_id_encode_block(self._h, ids.ctypes.data, id_off.ctypes.data, len(id_off) - 1, int(paired),
-                                            self._streams, self._lens)
+        f = self._lib.fqsx_idg_encode_block if self._gpu else self._lib.fqsx_id_encode_block
+        rc = f(self._h, ids.ctypes.data, id_off.ctypes.data, len(id_off) - 1, int(paired), self._streams, self._lens)
         if rc:
-            raise FqsxError(f"fqsx_id_encode_block: {rc}")
+            raise FqsxError(f"fqsx_id{'g' if self._gpu else ''}_encode_block: {rc}: {self._lib.fqsx_last_error().decode()}")
         return [C.string_at(self._streams[w], self._lens[w]) for w in range(self.T)]
 
     def close(self) -> None:
         if getattr(self, "_h", None):
-            self._lib.fqsx_id_destroy(self._h)
+            (self._lib.fqsx_idg_destroy if self._gpu else self._lib.fqsx_id_destroy)(self._h)
             self._h = None
 
     def __del__(self):

@@ -2351,6 +2351,212 @@ static int qual_encode_impl(fqsx_qual *q, const uint8_t *quals, const uint8_t *d
 }  // extern "C"
 
 // =======================================================================================================
+// Read-id stream on the GPU: one wavefront per worker, models in two per-worker tables in HBM
+// =======================================================================================================
+#include "fqsx_idk.h"
+
+FQ_KERNEL64 void k_id_encode(IdCfg cfg, u32 n_reads, u32 paired) {
+  FQ_SHARED IdShared sm;
+  id_encode_body(cfg, &sm, FQ_BLOCK, n_reads, paired);
+}
+// the twelve fixed models of every worker: all ones (mtf_flag 11 symbols, mtf_code[k] 2 << k, mtf_byte 256; id.cpp:84-105)
+FQ_KERNEL64 void k_id_init_fixed(IdCfg cfg) {
+  const u32 tid = FQ_BLOCK;
+  const u32 n_of[IDK_FIXED] = {11, 2, 4, 8, 16, 32, 64, 128, 256, 256, 256, 256};
+  for (u32 f = 0; f < IDK_FIXED; ++f) {
+    u64 *slot = cfg.fixed + ((u64)tid * IDK_FIXED + f) * IDK_BIG_U64;
+    for (u32 l = FQ_LANE; l < 64; l += FQ_WAVE) slot[1 + l] = 0x0001000100010001ULL;
+    if (FQ_LANE == 0) { slot[0] = 0; slot[65] = n_of[f]; }
+  }
+}
+
+struct fqsx_idg {
+  IdCfg cfg;
+  u32 T;
+  int device;
+  u64 small_cap, big_cap, out_cap, ids_cap, off_cap;
+  u8 *d_ids;
+  u64 *d_off;
+  fqsx_dna mem;   // allocation bookkeeping / stream (reuses the helpers above)
+  std::vector<u32> h_state;
+  std::vector<u64> h_lens;
+  std::vector<u8> h_out;
+};
+
+extern "C" {
+
+void fqsx_idg_destroy(fqsx_idg *q) {
+  if (!q) return;
+  fqsx_dna *c = &q->mem;
+#ifndef FQSX_EMU
+  (void)hipSetDevice(q->device);
+  (void)hipStreamSynchronize(c->stream);
+#endif
+  std::vector<void *> a = c->allocs;
+  for (void *p : a) dfree(c, p);
+#ifndef FQSX_EMU
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+#endif
+  delete q;
+}
+
+static int idg_fill_ff(fqsx_dna *c, void *p, u64 bytes) {
+#ifndef FQSX_EMU
+  HIPCHK(hipMemsetAsync(p, 0xff, bytes, c->stream));
+#else
+  (void)c;
+  memset(p, 0xff, bytes);
+#endif
+  return FQSX_OK;
+}
+
+int fqsx_idg_create(const uint8_t *h, int device, fqsx_idg **out) {
+  if (!h || !out || memcmp(h, "KCSD", 4) || h[4] == 0 || h[7] > 1) { g_err = "malformed header or id_mode none"; return FQSX_E_ARG; }
+#ifndef FQSX_EMU
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available (libfqsx has no CPU path)"; return FQSX_E_NO_DEVICE; }
+  if (device < 0 || device >= ndev) { g_err = "bad device ordinal"; return FQSX_E_ARG; }
+  HIPCHK(hipSetDevice(device));
+#endif
+  fqsx_idg *q = new fqsx_idg();
+  q->T = h[4];
+  q->device = device;
+  fqsx_dna *c = &q->mem;
+  c->T = q->T; c->device = device; c->profiling = false;
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamCreate(&c->stream));
+  HIPCHK(hipEventCreate(&c->ev0));
+  HIPCHK(hipEventCreate(&c->ev1));
+#endif
+  IdCfg &cfg = q->cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.T = q->T;
+  cfg.mode = h[7];   // 0 lossless, 1 instrument (params.h:18,92)
+  q->small_cap = 1u << 10; q->big_cap = 1u << 9;
+  q->out_cap = q->ids_cap = q->off_cap = 0;
+  q->d_ids = nullptr; q->d_off = nullptr;
+  const u64 T = q->T;
+  int rc;
+  void *p = nullptr;
+  auto fail = [&](int r) { fqsx_idg_destroy(q); return r; };
+  if ((rc = dalloc(c, &p, q->small_cap * T * 2 * sizeof(u64), false))) return fail(rc);
+  cfg.small = (u64 *)p; cfg.small_mask = q->small_cap - 1;
+  if ((rc = idg_fill_ff(c, cfg.small, q->small_cap * T * 2 * sizeof(u64)))) return fail(rc);
+  if ((rc = dalloc(c, &p, q->big_cap * T * IDK_BIG_U64 * sizeof(u64), false))) return fail(rc);
+  cfg.big = (u64 *)p; cfg.big_mask = q->big_cap - 1;
+  if ((rc = idg_fill_ff(c, cfg.big, q->big_cap * T * IDK_BIG_U64 * sizeof(u64)))) return fail(rc);
+  if ((rc = dalloc(c, &p, T * IDK_FIXED * IDK_BIG_U64 * sizeof(u64), true))) return fail(rc);
+  cfg.fixed = (u64 *)p;
+  cfg.mtf_cap = 4096;
+  if ((rc = dalloc(c, &p, T * cfg.mtf_cap * IDK_NAME, true))) return fail(rc);
+  cfg.mtf = (u8 *)p;
+  if ((rc = dalloc(c, &p, T * 4 * sizeof(u32), true))) return fail(rc);
+  cfg.state = (u32 *)p;
+  if ((rc = dalloc(c, &p, T * sizeof(u64), true))) return fail(rc);
+  cfg.lens = (u64 *)p;
+  if ((rc = dalloc(c, &p, 4 * sizeof(u32), true))) return fail(rc);
+  cfg.err = (u32 *)p;
+  LAUNCH(c, 2, k_id_init_fixed, q->T, 64, cfg);
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+  q->h_state.assign(4 * T, 0);
+  q->h_lens.assign(T, 0);
+  *out = q;
+  return FQSX_OK;
+}
+
+// ids: concatenated id lines, each INCLUDING its '\n' (read_desc_t::id_len, defs.h:70-72); id_off: n_reads + 1 offsets;
+// paired != 0: reads alternate mate 1 / mate 2.  streams[t] / lens[t]: worker t's id stream of the block (callee-owned until
+// the next call) -- byte-identical to fqsx_id_encode_block's (the host coder) and hence to the reference's.
+int fqsx_idg_encode_block(fqsx_idg *q, const uint8_t *ids, const uint64_t *off, uint32_t n_reads, int paired,
+                          const uint8_t **streams, uint64_t *lens) {
+  if (!q || !ids || !off || !streams || !lens || (paired && (n_reads & 1))) { g_err = "bad argument"; return FQSX_E_ARG; }
+  fqsx_dna *c = &q->mem;
+  IdCfg &cfg = q->cfg;
+  const u64 T = q->T;
+#ifndef FQSX_EMU
+  HIPCHK(hipSetDevice(q->device));
+#endif
+  int rc;
+  void *p = nullptr;
+  // ---- table sizes: a worker creates at most one big model per byte it codes plus nine per numeric token, and three small
+  // ones per token plus two per read; tokens end at separators, which are counted here
+  u64 max_bytes = 0, max_big = 0, max_small = 0;
+  for (u64 t = 0; t < T; ++t) {
+    u64 first = t * n_reads / T, last = (t + 1) * n_reads / T;  // reads_block.h:197-214
+    if (t) first &= ~1ull;
+    if (t + 1 < T) last &= ~1ull;
+    const u64 nb = off[last] - off[first];
+    u64 sep = 0;
+    for (u64 i = off[first]; i < off[last]; ++i) {
+      const u8 ch = ids[i];
+      sep += !((ch >= '0' && ch <= '9') || (ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z') || ch == '@');
+    }
+    max_bytes = std::max(max_bytes, nb);
+    max_big = std::max(max_big, (u64)q->h_state[4 * t + 1] + nb + 9 * sep + 2 * (last - first) + 16);
+    max_small = std::max(max_small, (u64)q->h_state[4 * t] + 3 * sep + 4 * (last - first) + 16);
+  }
+  auto regrow = [&](u64 *&tab, u64 &cap, u64 &mask, u64 need, u32 slot_u64) -> int {
+    if (need * 10 < cap * 8) return FQSX_OK;
+    const u64 ncap = pow2_at_least(need * 2);
+    int r = dalloc(c, &p, ncap * T * slot_u64 * sizeof(u64), false);
+    if (r) return r;
+    if ((r = idg_fill_ff(c, p, ncap * T * slot_u64 * sizeof(u64)))) return r;
+    LAUNCH(c, 2, k_qual_rehash, REHASH_GRID, 256, (const u64 *)tab, mask, (u64 *)p, ncap - 1, (u32)T, slot_u64);
+#ifndef FQSX_EMU
+    HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+    dfree(c, tab);
+    tab = (u64 *)p; cap = ncap; mask = ncap - 1;
+    return FQSX_OK;
+  };
+  if ((rc = regrow(cfg.small, q->small_cap, cfg.small_mask, max_small, 2))) return rc;
+  if ((rc = regrow(cfg.big, q->big_cap, cfg.big_mask, max_big, IDK_BIG_U64))) return rc;
+  const u64 need_out = (max_bytes * 2 + 4096 + 7) & ~7ull, ni = off[n_reads] + 64, no = ((u64)n_reads + 1) * sizeof(u64);
+  if (need_out > q->out_cap) {
+    dfree(c, cfg.out);
+    if ((rc = dalloc(c, &p, need_out * T, false))) return rc;
+    cfg.out = (u8 *)p; cfg.out_cap = q->out_cap = need_out;
+  }
+  if (ni > q->ids_cap) { dfree(c, q->d_ids); if ((rc = dalloc(c, &p, ni + ni / 4, false))) return rc; q->d_ids = (u8 *)p; q->ids_cap = ni + ni / 4; }
+  if (no > q->off_cap) { dfree(c, q->d_off); if ((rc = dalloc(c, &p, no + no / 4, false))) return rc; q->d_off = (u64 *)p; q->off_cap = no + no / 4; }
+  if ((rc = h2d(c, q->d_ids, ids, off[n_reads]))) return rc;
+  if ((rc = h2d(c, q->d_off, off, no))) return rc;
+  cfg.ids = q->d_ids;
+  cfg.off = q->d_off;
+  LAUNCH(c, 0, k_id_encode, q->T, 64, cfg, n_reads, (u32)(paired != 0));
+  if ((rc = d2h_sync(c, q->h_lens.data(), cfg.lens, T * sizeof(u64)))) return rc;
+  if ((rc = d2h_sync(c, q->h_state.data(), cfg.state, 4 * T * sizeof(u32)))) return rc;
+  u32 err = 0;
+  if ((rc = d2h_sync(c, &err, cfg.err, sizeof(u32)))) return rc;
+  if (err) {
+    static const char *what[] = {"", "byte outside the 128-symbol alphabet", "no instrument name", "stream overflow", "model table full",
+                                 "id, token count or instrument name beyond the kernel's staging sizes", "more than 4096 instrument names"};
+    g_err = std::string("id kernel: ") + (err < 7 ? what[err] : "error");
+    return err == IDK_ERR_BYTE || err == IDK_ERR_NO_INSTRUMENT ? FQSX_E_ARG : FQSX_E_DEVICE;
+  }
+  u64 total = 0;
+  for (u64 t = 0; t < T; ++t) {
+    if (q->h_lens[t] > cfg.out_cap) { g_err = "id stream overflow"; return FQSX_E_DEVICE; }
+    total += q->h_lens[t];
+  }
+  q->h_out.resize(total ? total : 1);
+  u64 pos = 0;
+  for (u64 t = 0; t < T; ++t) {
+    if ((rc = d2h_sync(c, q->h_out.data() + pos, cfg.out + t * cfg.out_cap, q->h_lens[t]))) return rc;
+    streams[t] = q->h_out.data() + pos;
+    lens[t] = q->h_lens[t];
+    pos += q->h_lens[t];
+  }
+  return FQSX_OK;
+}
+
+}  // extern "C"
+
+// =======================================================================================================
 // Read ordering of sorted mode: GPU radix sort + dense ranks, host replay of std::sort
 // =======================================================================================================
 #include "fqsx_sort.h"

@@ -18,17 +18,20 @@ def _gpu_groups(rec: hp.Records, device: int, lib_path: Optional[str]):
     return sort_order(bases, off, device=device, lib_path=lib_path)
 
 
-def encode_blocks(header: bytes, blocks, arrays, sizes_of, paired: bool, device: int, lib_path: Optional[str], stats: Optional[dict] = None):
+def encode_blocks(header: bytes, blocks, arrays, sizes_of, paired: bool, device: int, lib_path: Optional[str], stats: Optional[dict] = None,
+                  gpu_ids: bool = True):
     """Generator of the file's container blocks.  Per block the four coders run side by side, as the reference's worker
     codes meta, id, DNA and quality of a read in one loop (application.cpp:633-641): the DNA kernels and the quality kernel
-    on their own HIP streams (two host threads inside the C ABI, which releases the GIL), the meta and id coders on host
-    threads meanwhile."""
+    and the id kernel on their own HIP streams (host threads inside the C ABI, which releases the GIL), the meta coder on a host
+    thread meanwhile."""
     from concurrent.futures import ThreadPoolExecutor
     threads = header[4]
     stored = hp.stored_streams(header)
     dna = DnaCodec(header, device=device, lib_path=lib_path)
     meta = MetaCodec(threads, lib_path=lib_path)
-    idc = IdCodec(header, lib_path=lib_path) if hp.STREAM_ID in stored else None
+    # (the id stream comes from the GPU coder too: fqsx_idg_*, one wavefront per worker on a stream of its own; gpu_ids = False:
+    # the host coder, one host thread per worker -- the same bytes)
+    idc = IdCodec(header, lib_path=lib_path, device=device if gpu_ids else None) if hp.STREAM_ID in stored else None
     qual = QualCodec(header, device=device, lib_path=lib_path) if hp.STREAM_QUALITY in stored else None
     pool = ThreadPoolExecutor(max_workers=3)
     try:

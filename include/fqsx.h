@@ -213,6 +213,17 @@ int fqsx_id_encode_block(fqsx_id *, const uint8_t *ids, const uint64_t *id_off, 
                          const uint8_t **streams, uint64_t *lens);
 void fqsx_id_destroy(fqsx_id *);
 
+/* The read-id stream on the GPU: same arguments and the same bytes as fqsx_id_encode_block, coded by one
+ * wavefront per worker (csrc/fqsx_idk.h: tokeniser, numeric deltas, move-to-front list of instrument names, adaptive models in
+ * per-worker tables in HBM; reference fqs/id.cpp:152-184, 257-495, 734-757).  Staging limits of the kernel: id lines of at most
+ * 1024 bytes, 128 tokens, instrument names of 63 bytes, 4096 distinct instrument names per worker (beyond: an error, use the
+ * host coder).  id_mode none has no stream. */
+typedef struct fqsx_idg fqsx_idg;
+int fqsx_idg_create(const uint8_t *header17, int device, fqsx_idg **out);
+int fqsx_idg_encode_block(fqsx_idg *, const uint8_t *ids, const uint64_t *id_off, uint32_t n_reads, int paired,
+                          const uint8_t **streams, uint64_t *lens);
+void fqsx_idg_destroy(fqsx_idg *);
+
 /* Read order of `fqs e -om s` with the string work on the GPU.  Replaces preprocess_se
  * (fqs/application.cpp:349-412: 256 bins by the first four bases, N->T) plus CSortedFASTQFile::sort_reads on every
  * bin (fqs/io.h:499-528).  The GPU radix-sorts the reads by the comparator's keys and gives every read a dense
