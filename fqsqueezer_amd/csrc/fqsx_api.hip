@@ -69,6 +69,15 @@ FQ_KERNEL64 void k_compact_streams(DevCfg cfg, const u64 *lens, u8 *dst) {
   const u8 *src = cfg.out + (u64)tid * cfg.out_cap;
   for (u64 i = FQ_LANE; i < n; i += FQ_WAVE) dst[off + i] = src[i];
 }
+// the same for the quality and id coders ([T][out_cap] streams, one workgroup per worker)
+FQ_KERNEL64 void k_compact_generic(const u8 *out, u64 out_cap, const u64 *lens, u8 *dst) {
+  const u32 tid = FQ_BLOCK;
+  u64 off = 0;
+  for (u32 t = 0; t < tid; ++t) off += lens[t];
+  const u64 n = lens[tid] <= out_cap ? lens[tid] : 0;
+  const u8 *src = out + (u64)tid * out_cap;
+  for (u64 i = FQ_LANE; i < n; i += FQ_WAVE) dst[off + i] = src[i];
+}
 // ClearKmersToHT (dna.cpp:2475-2488): the workers' local tables and their fill counters, in one launch
 FQ_KERNEL64 void k_clear_local(DevCfg cfg, u64 nb_slots, u64 ns_slots) {
   if (phase_skip(cfg)) return;
@@ -697,6 +706,35 @@ int d2h_sync(fqsx_dna *c, void *h, const void *d, u64 bytes) {
 #else
 #define REHASH_GRID 1  /* the emulated kernel body already walks every slot */
 #endif
+
+// The T streams a quality / id kernel left in [T][out_cap] (lengths lens_host, already read back and checked against out_cap)
+// -> one contiguous host buffer: a compaction launch and ONE transfer instead of a transfer and a synchronisation per worker
+int collect_streams(fqsx_dna *c, u32 T, const u8 *d_out, u64 out_cap, const u64 *d_lens, const std::vector<u64> &lens_host,
+                    std::vector<u8> &h_out, const u8 **streams, u64 *lens) {
+  int rc;
+  void *p = nullptr;
+  u64 total = 0;
+  for (u32 t = 0; t < T; ++t) total += lens_host[t];
+  if (total > c->compact_cap) {
+    dfree(c, c->d_compact);
+    c->d_compact = nullptr; c->compact_cap = 0;
+    if ((rc = dalloc(c, &p, total + total / 2 + 4096, false))) return rc;
+    c->d_compact = (u8 *)p;
+    c->compact_cap = total + total / 2 + 4096;
+  }
+  h_out.resize(total ? total : 1);
+  if (total) {
+    LAUNCH(c, 2, k_compact_generic, T, 64, d_out, out_cap, d_lens, c->d_compact);
+    if ((rc = d2h_sync(c, h_out.data(), c->d_compact, total))) return rc;
+  }
+  u64 pos = 0;
+  for (u32 t = 0; t < T; ++t) {
+    streams[t] = h_out.data() + pos;
+    lens[t] = lens_host[t];
+    pos += lens_host[t];
+  }
+  return FQSX_OK;
+}
 
 u64 pow2_at_least(u64 x) {
   u64 p = 1;
@@ -2249,12 +2287,11 @@ int fqsx_qual_create(const uint8_t *h, int device, fqsx_qual **out) {
   cfg.cap_mask = q->cap - 1;
   if ((rc = dalloc(c, &p, q->T * sizeof(u32), true))) return fail(rc);
   cfg.filled = (u32 *)p;
-  if ((rc = dalloc(c, &p, q->T * sizeof(u64), true))) return fail(rc);
+  if ((rc = dalloc(c, &p, (q->T + 2) * sizeof(u64), true))) return fail(rc);   // lengths and, behind them, the error word: one transfer
   cfg.lens = (u64 *)p;
-  if ((rc = dalloc(c, &p, 16, true))) return fail(rc);
-  cfg.err = (u32 *)p;
+  cfg.err = (u32 *)(cfg.lens + q->T);
   q->h_filled.assign(q->T, 0);
-  q->h_lens.assign(q->T, 0);
+  q->h_lens.assign(q->T + 2, 0);
   *out = q;
   return FQSX_OK;
 }
@@ -2328,24 +2365,12 @@ static int qual_encode_impl(fqsx_qual *q, const uint8_t *quals, const uint8_t *d
     cfg.off = q->d_off;
   }
   LAUNCH(c, 0, k_qual_encode, T, 64, cfg, n_reads);
-  if ((rc = d2h_sync(c, q->h_lens.data(), cfg.lens, T * sizeof(u64)))) return rc;
-  u32 err = 0;
-  if ((rc = d2h_sync(c, &err, cfg.err, sizeof(u32)))) return rc;
+  if ((rc = d2h_sync(c, q->h_lens.data(), cfg.lens, ((u64)T + 1) * sizeof(u64)))) return rc;
+  const u32 err = (u32)q->h_lens[T];
   if (err) { g_err = "device error " + std::to_string(err) + " in the quality kernel"; return FQSX_E_DEVICE; }
-  u64 total = 0;
-  for (u32 t = 0; t < T; ++t) {
+  for (u32 t = 0; t < T; ++t)
     if (q->h_lens[t] > cfg.out_cap) { g_err = "quality stream overflow"; return FQSX_E_DEVICE; }
-    total += q->h_lens[t];
-  }
-  q->h_out.resize(total ? total : 1);
-  u64 pos = 0;
-  for (u32 t = 0; t < T; ++t) {
-    if ((rc = d2h_sync(c, q->h_out.data() + pos, cfg.out + (u64)t * cfg.out_cap, q->h_lens[t]))) return rc;
-    streams[t] = q->h_out.data() + pos;
-    lens[t] = q->h_lens[t];
-    pos += q->h_lens[t];
-  }
-  return FQSX_OK;
+  return collect_streams(c, T, cfg.out, cfg.out_cap, cfg.lens, q->h_lens, q->h_out, streams, lens);
 }
 
 }  // extern "C"
@@ -2452,18 +2477,16 @@ int fqsx_idg_create(const uint8_t *h, int device, fqsx_idg **out) {
   cfg.mtf_cap = 4096;
   if ((rc = dalloc(c, &p, T * cfg.mtf_cap * IDK_NAME, true))) return fail(rc);
   cfg.mtf = (u8 *)p;
-  if ((rc = dalloc(c, &p, T * 4 * sizeof(u32), true))) return fail(rc);
-  cfg.state = (u32 *)p;
-  if ((rc = dalloc(c, &p, T * sizeof(u64), true))) return fail(rc);
+  if ((rc = dalloc(c, &p, (T + 2 + 2 * T) * sizeof(u64), true))) return fail(rc);   // lengths, error word, per-worker state: one transfer
   cfg.lens = (u64 *)p;
-  if ((rc = dalloc(c, &p, 4 * sizeof(u32), true))) return fail(rc);
-  cfg.err = (u32 *)p;
+  cfg.err = (u32 *)(cfg.lens + T);
+  cfg.state = (u32 *)(cfg.lens + T + 2);
   LAUNCH(c, 2, k_id_init_fixed, q->T, 64, cfg);
 #ifndef FQSX_EMU
   HIPCHK(hipStreamSynchronize(c->stream));
 #endif
   q->h_state.assign(4 * T, 0);
-  q->h_lens.assign(T, 0);
+  q->h_lens.assign(T + 2 + 2 * T, 0);
   *out = q;
   return FQSX_OK;
 }
@@ -2528,30 +2551,18 @@ int fqsx_idg_encode_block(fqsx_idg *q, const uint8_t *ids, const uint64_t *off, 
   cfg.ids = q->d_ids;
   cfg.off = q->d_off;
   LAUNCH(c, 0, k_id_encode, q->T, 64, cfg, n_reads, (u32)(paired != 0));
-  if ((rc = d2h_sync(c, q->h_lens.data(), cfg.lens, T * sizeof(u64)))) return rc;
-  if ((rc = d2h_sync(c, q->h_state.data(), cfg.state, 4 * T * sizeof(u32)))) return rc;
-  u32 err = 0;
-  if ((rc = d2h_sync(c, &err, cfg.err, sizeof(u32)))) return rc;
+  if ((rc = d2h_sync(c, q->h_lens.data(), cfg.lens, (T + 2 + 2 * T) * sizeof(u64)))) return rc;
+  memcpy(q->h_state.data(), q->h_lens.data() + T + 2, 4 * T * sizeof(u32));
+  const u32 err = (u32)q->h_lens[T];
   if (err) {
     static const char *what[] = {"", "byte outside the 128-symbol alphabet", "no instrument name", "stream overflow", "model table full",
                                  "id, token count or instrument name beyond the kernel's staging sizes", "more than 4096 instrument names"};
     g_err = std::string("id kernel: ") + (err < 7 ? what[err] : "error");
     return err == IDK_ERR_BYTE || err == IDK_ERR_NO_INSTRUMENT ? FQSX_E_ARG : FQSX_E_DEVICE;
   }
-  u64 total = 0;
-  for (u64 t = 0; t < T; ++t) {
+  for (u64 t = 0; t < T; ++t)
     if (q->h_lens[t] > cfg.out_cap) { g_err = "id stream overflow"; return FQSX_E_DEVICE; }
-    total += q->h_lens[t];
-  }
-  q->h_out.resize(total ? total : 1);
-  u64 pos = 0;
-  for (u64 t = 0; t < T; ++t) {
-    if ((rc = d2h_sync(c, q->h_out.data() + pos, cfg.out + t * cfg.out_cap, q->h_lens[t]))) return rc;
-    streams[t] = q->h_out.data() + pos;
-    lens[t] = q->h_lens[t];
-    pos += q->h_lens[t];
-  }
-  return FQSX_OK;
+  return collect_streams(c, (u32)T, cfg.out, cfg.out_cap, cfg.lens, q->h_lens, q->h_out, streams, lens);
 }
 
 }  // extern "C"

@@ -198,15 +198,33 @@ def measure(n_reads: int = 300_000, read_len: int = 150, T: int = 64, device: in
         out[tag] = row
         out[tag + "_msym_s"], out[tag + "_bits_per_symbol"], out[tag + "_pcie_inclusive_msym_s"] = row["value"], row["bits_per_symbol"], row["pcie_inclusive_msym_s"]
 
+    # ---- read-id coder (k_id_encode, row N4): lossless ids of the generator ("@SRR000001.<i> <i>/1"), GPU kernel vs the host coder
+    # (one host thread per worker) on the same blocks
+    from fqsqueezer_amd.codec import IdCodec
+    hi = hp.make_header(T, "se_sorted", gs, "none", "lossless")
+    ib = [hp.id_arrays(rec, idx) for idx in hp.form_blocks(rec, "se_sorted")]
+    id_bytes = sum(int(o[-1]) for (_, o) in ib)
+    row = {}
+    for tag2, devarg in (("gpu", device), ("host_threads", None)):
+        c = IdCodec(hi, device=devarg)
+        t0 = time.perf_counter()
+        nbytes = sum(sum(len(x) for x in c.encode_block(a, o, False)) for (a, o) in ib)
+        dt = time.perf_counter() - t0
+        c.close()
+        row[tag2] = {"value": round(n_reads / dt / 1e6, 3), "unit": "Mids/s", "id_mbytes_s": round(id_bytes / dt / 1e6, 2), "stream_bytes": nbytes}
+    row["identical_streams"] = row["gpu"]["stream_bytes"] == row["host_threads"]["stream_bytes"]
+    row["note"] = "host buffers in, streams out (the upload is inside); the DNA path codes 0.67 Mreads/s of 150 bp at 100 Mbases/s, so either id coder runs beside it"
+    out["id_lossless"] = row
+
     # ---- full mode end to end (BASELINE configs[2]'s modes: -p -om s -qm 8, default -im i): the DNA and the quality kernels on
-    # two HIP streams, the meta and id coders on host threads (fqsfile.encode_blocks), host buffers in, container blocks out
+    # two HIP streams, the id kernel on a third, the meta coder on a host thread (fqsfile.encode_blocks), host buffers in, container blocks out
     from fqsqueezer_amd.fqsfile import compress_records_pe
     t0 = time.perf_counter()
     hdr_f, blks = compress_records_pe(rec1, rec2, T, "s", gs, device=device, quality_mode="illumina_8", id_mode="instrument", as_blocks=True)
     n_out = sum(len(ch) for ch in hp.fqs_chunks(hdr_f, blks))
     dt = time.perf_counter() - t0
     out["full_mode_pe_q8"] = {"value": round(2 * n_pairs * read_len / dt / 1e6, 3), "unit": "Mbases/s", "file_bytes": n_out,
-                              "note": "whole file from host buffers, GPU sort pre-pass included: 4 streams per block, DNA + quality kernels concurrently, id / meta on host threads"}
+                              "note": "whole file from host buffers, GPU sort pre-pass included: 4 streams per block, DNA + quality + id kernels concurrently, meta on a host thread"}
     if have_ref:
         out["full_mode_pe_q8"]["cpu"] = ref_run(["e", "-p", "-om", "s", "-t", "8", "-gs", str(gs), "-qm", "8", "-v", "0", "-tmp", tmp, "-out", os.path.join(td, "f.fqs"), f1, f2],
                                                 2 * npc * read_len, "Mbases/s", f"`fqs-1.1 e -p -om s -qm 8 -t 8` (default -im i), {npc} pairs")
