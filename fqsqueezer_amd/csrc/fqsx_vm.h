@@ -16,6 +16,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <sys/un.h>
 #include <unistd.h>
 #include <cerrno>
@@ -144,6 +145,13 @@ struct FdMesh {
   uint64_t word = 0;
   std::vector<int> peer;   // [world] connected socket to rank q (-1 for this rank)
 };
+// a rank that has died must make its peers fail, not wait forever: every socket operation of the mesh gives up after two minutes
+inline void mesh_timeouts(int fd) {
+  timeval tv;
+  tv.tv_sec = 120; tv.tv_usec = 0;
+  (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+  (void)setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+}
 inline void mesh_name(uint64_t word, sockaddr_un *a, socklen_t *len) {
   memset(a, 0, sizeof(*a));
   a->sun_family = AF_UNIX;
@@ -167,6 +175,7 @@ inline int mesh_listen(FdMesh &m, uint32_t rank, uint32_t world, std::string &er
   }
   if (ur >= 0) close(ur);
   if (listen(m.listener, 256)) { err = errno_str("listen"); return 1; }
+  mesh_timeouts(m.listener);   // (accept() honours SO_RCVTIMEO)
   return 0;
 }
 inline int write_all(int fd, const void *p, size_t n) {
@@ -187,6 +196,7 @@ inline int mesh_connect(FdMesh &m, const uint64_t *words, std::string &err) {
     sockaddr_un a;
     socklen_t len;
     mesh_name(words[q], &a, &len);
+    mesh_timeouts(s);
     if (connect(s, (sockaddr *)&a, len)) { err = errno_str("connect to a rank of another node? (the partitioned mode is one node)"); close(s); return 1; }
     const uint32_t me = m.rank;
     if (write_all(s, &me, sizeof(me))) { err = errno_str("send"); close(s); return 1; }
@@ -194,7 +204,8 @@ inline int mesh_connect(FdMesh &m, const uint64_t *words, std::string &err) {
   }
   for (uint32_t i = m.rank + 1; i < m.world; ++i) {
     int s = accept4(m.listener, nullptr, nullptr, SOCK_CLOEXEC);
-    if (s < 0) { err = errno_str("accept"); return 1; }
+    if (s < 0) { err = errno_str("accept (a rank of the world did not connect)"); return 1; }
+    mesh_timeouts(s);
     uint32_t q = 0;
     if (read_all(s, &q, sizeof(q)) || q <= m.rank || q >= m.world || m.peer[q] >= 0) { err = "unexpected peer on the descriptor socket"; close(s); return 1; }
     m.peer[q] = s;
