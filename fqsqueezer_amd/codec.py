@@ -17,7 +17,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_PKG, "libfqsx.so")
 
 STAT_NAMES = ["gprobe", "gslot", "lprobe", "lslot", "gins", "gins_slot", "siv_words", "ctx_slots",
-              "coded", "lins", "mail", "bases"]
+              "coded", "lins", "mail", "bases", "siv_saved"]
 
 
 class FqsxError(RuntimeError):

@@ -900,7 +900,10 @@ FQ_DEV u64 siv_count_equal(Wk &w, u64 lo, u64 hi, u64 flag) {
   if (start >= hi) return 0;
   const u64 b0 = (start + FQSX_SIV_BLK - 1) >> FQSX_SIV_BLK_LOG, b1 = hi >> FQSX_SIV_BLK_LOG;   // whole blocks inside [start, hi): b0 .. b1-1
   if (b0 + 2 > b1) return siv_count_sweep(w, start, hi, flag);   // (a short range: the sweep alone)
-  return siv_count_sweep(w, start, b0 << FQSX_SIV_BLK_LOG, flag) + siv_count_blocks(w, b0, b1, flag) + siv_count_sweep(w, b1 << FQSX_SIV_BLK_LOG, hi, flag);
+  const u64 read_before = w.st[ST_SIV_WORDS];
+  const u64 r = siv_count_sweep(w, start, b0 << FQSX_SIV_BLK_LOG, flag) + siv_count_blocks(w, b0, b1, flag) + siv_count_sweep(w, b1 << FQSX_SIV_BLK_LOG, hi, flag);
+  w.st[ST_SIV_SAVED] += (((hi - 1) >> 5) - (start >> 5) + 1) - (w.st[ST_SIV_WORDS] - read_before);
+  return r;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -125,6 +125,9 @@ enum {
   ST_LINS,         // local inserts
   ST_MAIL,         // mailbox entries pushed
   ST_BASES,        // input bases consumed
+  ST_SIV_SAVED,    // siv words the reference's rank loop sweeps (dna.cpp:600-605: the whole range between the previous and the current
+                   // p-mer) minus the words the kernel read for the same rank (end blocks + count index): ST_SIV_WORDS + this = the
+                   // algorithmic figure of SURVEY 8d
   ST_N
 };
 // section timers (only maintained by -DFQSX_TIMING builds)

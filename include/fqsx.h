@@ -97,6 +97,8 @@ int fqsx_dna_decode_block(fqsx_dna *, const uint8_t *const *streams, const uint6
  * [0] global probes [1] global slots read [2] local probes [3] local slots read
  * [4] global inserts [5] slots read by them [6] siv words touched [7] context slots read
  * [8] symbols range-coded [9] local inserts [10] mailbox entries [11] input bases
+ * [12] siv words of the reference's rank sweeps (fqs/dna.cpp:600-605) that the count index spared the kernels ([6] + [12] = the
+ *      words the algorithm sweeps)
  * [16..63] in-kernel section timers / event counts (10 ns ticks, only in -DFQSX_TIMING diagnostic builds) */
 int fqsx_dna_stats(fqsx_dna *, uint64_t out[64]);
 

@@ -33,7 +33,7 @@ def dna_bytes(st: dict, pairs: int = 0) -> float:
     """SURVEY.md 8(d): B = sum_probes(24 + 4 slots) + sum_global_inserts(24 + 4 slots + 4) + 8 siv_words + 24 ctx_slots + 80 coded;
     paired-end adds the pair table: 8 finds + 14 inserts of a 16-byte item behind a 24-byte descriptor per pair."""
     probes, slots = st["gprobe"] + st["lprobe"], st["gslot"] + st["lslot"]
-    return (24.0 * probes + 4.0 * slots + 28.0 * st["gins"] + 4.0 * st["gins_slot"] + 8.0 * st["siv_words"]
+    return (24.0 * probes + 4.0 * slots + 28.0 * st["gins"] + 4.0 * st["gins_slot"] + 8.0 * (st["siv_words"] + st.get("siv_saved", 0))
             + 24.0 * st["ctx_slots"] + 80.0 * st["coded"] + 22.0 * 40.0 * pairs)
 
 
