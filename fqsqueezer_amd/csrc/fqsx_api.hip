@@ -182,12 +182,17 @@ FQ_KERNEL64 void k_part_scatter(DevCfg cfg, u32 seg1, u32 *demand) {
   part_scatter_body(cfg, kind, blk, cursor, ld, gm, demand ? doff : nullptr);
 }
 // paired-end insert phase: per-owner demand, then the inserts
-FQ_KERNEL64 void k_pe_demand(DevCfg cfg, u32 *demand) {
+// seg1 != 0 (paired-end encoding on one GPU): nothing is read back inside a block -- the kernel applies the host's growth
+// rule to the pair table itself and posts the phase (err[1] = seg1, see phase_skip) if owner FQ_BLOCK's sub-table would pass it
+FQ_KERNEL64 void k_pe_demand(DevCfg cfg, u32 *demand, u32 seg1) {
   FQ_SHARED InsShared sm;
+  if (seg1 && phase_skip(cfg)) return;
   pe_insert_body(cfg, &sm, FQ_BLOCK, true, demand);
+  if (seg1 && FQ_LANE == 0 && ((u64)cfg.g_pe.filled[FQ_BLOCK] + demand[FQ_BLOCK]) * 2 > cfg.g_pe.cap_mask + 1) cfg.err[1] = seg1;
 }
 FQ_KERNEL64 void k_pe_insert(DevCfg cfg) {
   FQ_SHARED InsShared sm;
+  if (phase_skip(cfg)) return;
   pe_insert_body(cfg, &sm, FQ_BLOCK, false, nullptr);
 }
 FQ_KERNEL void k_rehash_ptab(PTab o, PTab n, u32 n_sub) {
@@ -1167,15 +1172,36 @@ int grow_for_demand(fqsx_dna *c) {
   return FQSX_OK;
 }
 // The device stopped the block's queue before the inserts of segment `seg` (phase_skip): grow, then take up from there
+int pe_insert_and_clear(fqsx_dna *c);
 int block_recover(fqsx_dna *c, u32 seg) {
   const u32 T = c->T;
   int rc;
   if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, (4 * T + 1) * sizeof(u32)))) return rc;
-  const u64 before = c->gs_cap + c->gb_cap;
+  const u64 before = c->gs_cap + c->gb_cap + c->gpe_cap;
   if ((rc = grow_for_demand(c))) return rc;
-  if (c->gs_cap + c->gb_cap == before) { g_err = "phase " + std::to_string(seg) + " posted for growth, but no table needs it"; return FQSX_E_DEVICE; }
   if ((rc = dzero(c, c->cfg.err + 1, sizeof(u32)))) return rc;
+  if (c->paired) {   // the pair table's demand again (the queued count stopped at the posted word), growth, then the phase's inserts
+    LAUNCH(c, 2, k_pe_demand, T, 64, c->cfg, c->d_demand + 4 * T + 1, 0u);
+    std::vector<u32> dem(T), fil(T);
+    if ((rc = d2h_sync(c, dem.data(), c->d_demand + 4 * T + 1, T * sizeof(u32)))) return rc;
+    if ((rc = d2h_sync(c, fil.data(), c->cfg.g_pe.filled, T * sizeof(u32)))) return rc;
+    u64 need = 0;
+    for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)fil[o] + dem[o]);
+    if (need * 2 > c->gpe_cap && (rc = grow_gpe(c, pow2_at_least(need * 2 + 2)))) return rc;
+  }
+  if (c->gs_cap + c->gb_cap + c->gpe_cap == before) { g_err = "phase " + std::to_string(seg) + " posted for growth, but no table needs it"; return FQSX_E_DEVICE; }
+  if (c->paired && (rc = pe_insert_and_clear(c))) return rc;
   return insert_and_clear(c);
+}
+// paired-end: the pair-table inserts of a phase and the clearing of the workers' local pair tables
+int pe_insert_and_clear(fqsx_dna *c) {
+  const u32 T = c->T;
+  DevCfg &cfg = c->cfg;
+  int rc;
+  LAUNCH(c, 2, k_pe_insert, T, 64, cfg);
+  if ((rc = dzero(c, cfg.l_pe.key, c->cur_need_lpe * T * sizeof(u64)))) return rc;
+  if ((rc = dzero(c, cfg.l_pe.val, c->cur_need_lpe * T * sizeof(u64)))) return rc;
+  return dzero(c, cfg.l_pe.filled, T * sizeof(u32));
 }
 
 // One synchronisation segment on one GPU: encode launch, mailbox partition, growth decision, insert phase, clear
@@ -1191,9 +1217,13 @@ int block_segment(fqsx_dna *c, u32 seg) {
     const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
     LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
     LAUNCH(c, 2, k_part_scan, 3 * T, 64, cfg);
-    if (!c->paired && !decode) {
-      // single-end encoding: nothing is read back inside a block -- the growth check is the device's (phase_skip)
+    if (!decode) {
+      // encoding: nothing is read back inside a block -- the growth checks are the device's (phase_skip)
       LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, seg + 1, c->d_demand);   // (group offsets, demand words and growth check included)
+      if (c->paired) {
+        LAUNCH(c, 2, k_pe_demand, T, 64, cfg, c->d_demand + 4 * T + 1, seg + 1);   // (per-owner demand of the pair table + its growth check)
+        if ((rc = pe_insert_and_clear(c))) return rc;
+      }
       return insert_and_clear(c);
     }
     LAUNCH(c, 2, k_part_dstoff, 3, 64, cfg, c->d_demand, 0u);
@@ -1207,16 +1237,13 @@ int block_segment(fqsx_dna *c, u32 seg) {
     }
     if ((rc = grow_for_demand(c))) return rc;
     if (c->paired) {  // pair table: size for the exact per-owner demand, then insert
-      LAUNCH(c, 2, k_pe_demand, T, 64, cfg, c->d_demand);
+      LAUNCH(c, 2, k_pe_demand, T, 64, cfg, c->d_demand, 0u);
       if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, T * sizeof(u32)))) return rc;
       if ((rc = d2h_sync(c, c->h_filled.data(), cfg.g_pe.filled, T * sizeof(u32)))) return rc;
       u64 need = 0;
       for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_filled[o] + c->h_demand[o]);
       if (need * 2 > c->gpe_cap && (rc = grow_gpe(c, pow2_at_least(need * 2 + 2)))) return rc;
-      LAUNCH(c, 2, k_pe_insert, T, 64, cfg);
-      if ((rc = dzero(c, cfg.l_pe.key, need_lpe * T * sizeof(u64)))) return rc;
-      if ((rc = dzero(c, cfg.l_pe.val, need_lpe * T * sizeof(u64)))) return rc;
-      if ((rc = dzero(c, cfg.l_pe.filled, T * sizeof(u32)))) return rc;
+      if ((rc = pe_insert_and_clear(c))) return rc;
     }
     LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
     if ((rc = clear_local_tables(c))) return rc;
@@ -1398,6 +1425,7 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   c->pe_cap = 0;
   if (c->paired) {  // ht_pe_mers (application.cpp:89) and ht_pe_mers_local (dna.cpp:105-107)
     c->gpe_cap = pow2_at_least(std::max<u64>(1024, (1ull << 20) / T));
+    if (const char *e = getenv("FQSX_PTAB_INIT")) c->gpe_cap = pow2_at_least(std::max<u64>(64, strtoull(e, nullptr, 10)));   // (tests: growth from a tiny pair table)
     if ((rc = ptab_alloc(c, cfg.g_pe, T, c->gpe_cap, true))) return rc;
     c->lpe_cap = 1024;
     if ((rc = ptab_alloc(c, cfg.l_pe, T, c->lpe_cap, true))) return rc;
@@ -1422,7 +1450,7 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   if ((rc = dalloc(c, &p, (u64)FQSX_TRACE_LAUNCHES * T * FQSX_TRACE_W * sizeof(u64), true))) return rc;
   cfg.trace = (u64 *)p;
 #endif
-  if ((rc = dalloc(c, &p, (4 * (u64)T + 1) * sizeof(u32), true))) return rc;
+  if ((rc = dalloc(c, &p, (5 * (u64)T + 2) * sizeof(u32), true))) return rc;   // [0 .. 4T]: k-mer tables (k_part_dstoff); [4T+1 ..): pair table
   c->d_demand = (u32 *)p;
   if ((rc = dalloc(c, &p, ((u64)T + 64) * sizeof(u64), true))) return rc;
   c->d_lens = (u64 *)p;
@@ -1879,7 +1907,7 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   // ---- paired-end: every rank applies every source's triples to its replica of the pair table
   if (c->paired) {
     if (G > 1 && PM) LAUNCH(c, 2, k_shard_pe_unpack, T, 64, cfg, (const u64 *)c->d_gathered, W, off_pe, (const u32 *)(c->d_cglob + 3ull * T * T));
-    LAUNCH(c, 2, k_pe_demand, T, 64, cfg, c->d_demand);
+    LAUNCH(c, 2, k_pe_demand, T, 64, cfg, c->d_demand, 0u);
     if ((rc = d2h_sync(c, c->h_demand.data(), c->d_demand, T * sizeof(u32)))) return rc;
     if ((rc = d2h_sync(c, c->h_filled.data(), cfg.g_pe.filled, T * sizeof(u32)))) return rc;
     u64 need = 0;

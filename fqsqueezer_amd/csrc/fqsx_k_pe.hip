@@ -7,7 +7,7 @@
 #ifndef FQSX_EMU
 template <int MODE> FQ_DEV void encode_pe_kernel_body(const EncArgs &a) {
   if (worker_elsewhere(a)) return;
-  if (wg_handoff_init(a, false)) return;   // a device error stops the block's remaining launches (the host reads the word per phase)
+  if (wg_handoff_init(a, true)) return;   // a device error or a phase posted for growth stops the block's remaining launches (phase_skip)
   switch (FQ_WAVE_ID) {
     case 1: role_scout_req<2>(fq_kernarg(), 0u); break;
     case 2: role_resolve<MODE>(fq_kernarg()); break;
@@ -27,6 +27,7 @@ int fqsx_launch_encode_pe(hipStream_t s, const EncArgs &a) {
 }
 #else
 static void fqsx_emu_encode_pe(const EncArgs &a) {
+  if (a.cfg.err[0] | a.cfg.err[1]) return;
   for (u32 b = 0; b < a.cfg.T; ++b) {
     fq_emu_block = b;
     if (!shard_mine(a.cfg, b)) {   // sharded run: a worker that lives on another rank only reports empty lists here

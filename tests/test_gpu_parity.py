@@ -55,6 +55,18 @@ def test_hip_matches_reference_paired_end(name):
     check_against_fqs_pe(gpu, c5_records(), name)
 
 
+@pytest.mark.parametrize("name", ["c5_pe4k_o_t4.fqs", "c5_pe4k_s_t4.fqs"])
+def test_hip_paired_end_growth_posted_by_the_device_is_recovered(name, monkeypatch):
+    """Paired-end encoding reads nothing back inside a block either: the partition kernel checks the k-mer tables' growth rule,
+    the demand kernel the pair table's; a posted phase stops the block's queue and the host grows and resumes at that phase's
+    inserts (pair table and k-mer tables).  From 256-slot k-mer sub-tables and 64-slot pair sub-tables both happen in most blocks."""
+    monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    monkeypatch.setenv("FQSX_PTAB_INIT", "64")
+    codec = check_against_fqs_pe(gpu, c5_records(), name)
+    cap = codec.capacity()
+    assert cap["growths"] >= 8 and cap["pair_slots"] > 64 * 4, cap
+
+
 @pytest.mark.parametrize("name", ["c20_pelong_o_t2.fqs", "c20_pelong_s_t2.fqs"])
 def test_hip_paired_end_mates_longer_than_the_lds_staging(name):
     """5000 bp mates (the reference takes up to 2^24 bases, fqs/meta.cpp:69): code lines and the reverse-complement line of an
