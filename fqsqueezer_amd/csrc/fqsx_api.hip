@@ -190,6 +190,50 @@ FQ_KERNEL64 void k_pe_demand(DevCfg cfg, u32 *demand, u32 seg1) {
   pe_insert_body(cfg, &sm, FQ_BLOCK, true, demand);
   if (seg1 && FQ_LANE == 0 && ((u64)cfg.g_pe.filled[FQ_BLOCK] + demand[FQ_BLOCK]) * 2 > cfg.g_pe.cap_mask + 1) cfg.err[1] = seg1;
 }
+// the bucketed form of the phase (fqsx_pe.h): count, offsets + growth check, scatter, per-owner inserts
+FQ_KERNEL void k_pe_bucket_count(DevCfg cfg) {
+  if (phase_skip(cfg)) return;
+#ifndef FQSX_EMU
+  const u32 total = cfg.T * cfg.pe_cap, stride = gridDim.x * blockDim.x;
+  for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) pe_bucket_count_body(cfg, g);
+#else
+  for (u32 g = 0; g < cfg.T * cfg.pe_cap; ++g) pe_bucket_count_body(cfg, g);
+#endif
+}
+FQ_KERNEL64 void k_pe_bucket_offsets(DevCfg cfg, u32 seg1) {   // one wave
+  if (phase_skip(cfg)) return;
+  u32 run = 0;
+  bool over = false;
+  for (u32 base = 0; base < cfg.T; base += FQ_WAVE) {
+    const u32 o = base + FQ_LANE;
+    const u32 v = o < cfg.T ? cfg.pe_bkt_n[o] : 0u;
+    const u32 ex = wave_excl_scan32(v) + run;
+    if (o < cfg.T) {
+      cfg.pe_bkt_n[cfg.T + o] = ex;
+      cfg.pe_bkt_cur[o] = 0;
+      over |= ((u64)cfg.g_pe.filled[o] + v) * 2 > cfg.g_pe.cap_mask + 1;   // the host's growth rule: at most half full after the inserts
+    }
+    run += wave_sum32(v);
+  }
+  if (FQ_LANE == 0) cfg.pe_bkt_n[2 * cfg.T] = run;
+  if (wave_any(over) && FQ_LANE == 0) cfg.err[1] = seg1;
+}
+FQ_KERNEL void k_pe_bucket_scatter(DevCfg cfg) {
+  if (phase_skip(cfg)) return;
+#ifndef FQSX_EMU
+  const u32 total = cfg.T * cfg.pe_cap, stride = gridDim.x * blockDim.x;
+  for (u32 g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) pe_bucket_scatter_body(cfg, g);
+#else
+  for (u32 g = 0; g < cfg.T * cfg.pe_cap; ++g) pe_bucket_scatter_body(cfg, g);
+#endif
+}
+FQ_KERNEL64 void k_pe_insert_buckets(DevCfg cfg) {   // grid = T (owner); also leaves the counters zero for the next phase
+  FQ_SHARED InsShared sm;
+  if (phase_skip(cfg)) return;
+  pe_insert_bucket_body(cfg, &sm, FQ_BLOCK);
+  FQ_SYNC_MEM();
+  if (FQ_LANE == 0) cfg.pe_bkt_n[FQ_BLOCK] = 0;
+}
 FQ_KERNEL64 void k_pe_insert(DevCfg cfg) {
   FQ_SHARED InsShared sm;
   if (phase_skip(cfg)) return;
@@ -1067,6 +1111,9 @@ int block_prepare(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u64 *h
       if ((rc = dalloc(c, &p, (u64)T * c->pe_cap * 3 * sizeof(u64), false))) return rc;
       cfg.pe_list = (u64 *)p;
       cfg.pe_cap = c->pe_cap;
+      if (cfg.pe_bkt) dfree(c, cfg.pe_bkt);
+      if ((rc = dalloc(c, &p, (u64)T * c->pe_cap * 3 * sizeof(u64), false))) return rc;
+      cfg.pe_bkt = (u64 *)p;
     }
     need_lpe = pow2_at_least(2 * 14 * seg_pairs + 64);
     if (need_lpe > c->lpe_cap) {
@@ -1173,6 +1220,7 @@ int grow_for_demand(fqsx_dna *c) {
 }
 // The device stopped the block's queue before the inserts of segment `seg` (phase_skip): grow, then take up from there
 int pe_insert_and_clear(fqsx_dna *c);
+int pe_clear_local(fqsx_dna *c);
 int block_recover(fqsx_dna *c, u32 seg) {
   const u32 T = c->T;
   int rc;
@@ -1181,6 +1229,7 @@ int block_recover(fqsx_dna *c, u32 seg) {
   if ((rc = grow_for_demand(c))) return rc;
   if ((rc = dzero(c, c->cfg.err + 1, sizeof(u32)))) return rc;
   if (c->paired) {   // the pair table's demand again (the queued count stopped at the posted word), growth, then the phase's inserts
+    if ((rc = dzero(c, c->cfg.pe_bkt_n, T * sizeof(u32)))) return rc;   // (the per-owner counts of the stopped pass: the next phase counts from zero)
     LAUNCH(c, 2, k_pe_demand, T, 64, c->cfg, c->d_demand + 4 * T + 1, 0u);
     std::vector<u32> dem(T), fil(T);
     if ((rc = d2h_sync(c, dem.data(), c->d_demand + 4 * T + 1, T * sizeof(u32)))) return rc;
@@ -1194,14 +1243,17 @@ int block_recover(fqsx_dna *c, u32 seg) {
   return insert_and_clear(c);
 }
 // paired-end: the pair-table inserts of a phase and the clearing of the workers' local pair tables
-int pe_insert_and_clear(fqsx_dna *c) {
+int pe_clear_local(fqsx_dna *c) {
   const u32 T = c->T;
   DevCfg &cfg = c->cfg;
   int rc;
-  LAUNCH(c, 2, k_pe_insert, T, 64, cfg);
   if ((rc = dzero(c, cfg.l_pe.key, c->cur_need_lpe * T * sizeof(u64)))) return rc;
   if ((rc = dzero(c, cfg.l_pe.val, c->cur_need_lpe * T * sizeof(u64)))) return rc;
   return dzero(c, cfg.l_pe.filled, T * sizeof(u32));
+}
+int pe_insert_and_clear(fqsx_dna *c) {
+  LAUNCH(c, 2, k_pe_insert, c->T, 64, c->cfg);
+  return pe_clear_local(c);
 }
 
 // One synchronisation segment on one GPU: encode launch, mailbox partition, growth decision, insert phase, clear
@@ -1220,9 +1272,17 @@ int block_segment(fqsx_dna *c, u32 seg) {
     if (!decode) {
       // encoding: nothing is read back inside a block -- the growth checks are the device's (phase_skip)
       LAUNCH(c, 2, k_part_scatter, part_grid, 64, cfg, seg + 1, c->d_demand);   // (group offsets, demand words and growth check included)
-      if (c->paired) {
-        LAUNCH(c, 2, k_pe_demand, T, 64, cfg, c->d_demand + 4 * T + 1, seg + 1);   // (per-owner demand of the pair table + its growth check)
-        if ((rc = pe_insert_and_clear(c))) return rc;
+      if (c->paired) {   // pair table: triples grouped by owner (count, offsets + growth check, scatter), then every owner's own group
+#ifndef FQSX_EMU
+        const u32 bgrid = (u32)std::min<u64>(1024, ((u64)T * cfg.pe_cap + 255) / 256);
+#else
+        const u32 bgrid = 1;   // (the emulated kernel body already walks every triple)
+#endif
+        LAUNCH(c, 2, k_pe_bucket_count, bgrid, 256, cfg);
+        LAUNCH(c, 2, k_pe_bucket_offsets, 1, 64, cfg, seg + 1);
+        LAUNCH(c, 2, k_pe_bucket_scatter, bgrid, 256, cfg);
+        LAUNCH(c, 2, k_pe_insert_buckets, T, 64, cfg);
+        if ((rc = pe_clear_local(c))) return rc;
       }
       return insert_and_clear(c);
     }
@@ -1431,6 +1491,9 @@ int create_impl(fqsx_dna *c, const u8 *h) {
     if ((rc = ptab_alloc(c, cfg.l_pe, T, c->lpe_cap, true))) return rc;
     if ((rc = dalloc(c, &p, (u64)T * sizeof(u32), true))) return rc;
     cfg.pe_n = (u32 *)p;
+    if ((rc = dalloc(c, &p, (3 * (u64)T + 1) * sizeof(u32), true))) return rc;   // per-owner counts (kept zero between phases), offsets, cursors
+    cfg.pe_bkt_n = (u32 *)p;
+    cfg.pe_bkt_cur = cfg.pe_bkt_n + 2 * T + 1;
   }
   {  // group order of the partitioned mailboxes: by owner (one GPU)
     u8 ident[256];

@@ -175,6 +175,9 @@ struct DevCfg {
   u64 *pe_list;                // [T][pe_cap][3] (key, value, weight) triples pushed by each source
   u32 *pe_n;                   // [T]
   u32 pe_cap;                  // triples per source
+  u64 *pe_bkt;                 // [T * pe_cap][3] the phase's triples grouped by owner (k_pe_bucket_*; any order inside a group: inserts commute)
+  u32 *pe_bkt_n;               // [2T + 1] triples per owner, then the groups' offsets (exclusive scan, [T] = total)
+  u32 *pe_bkt_cur;             // [T] scatter cursors
   const u8 *bases;             // block input: concatenated ASCII reads
   const u64 *read_off;         // n_reads+1
   u8 *out;                     // [T][out_cap] DNA streams of the block

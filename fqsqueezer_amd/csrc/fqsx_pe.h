@@ -537,6 +537,45 @@ FQ_DEV void pe_apply_batch(const DevCfg &cfg, SM *sm, u32 tid, u32 n, u32 &err) 
   FQ_SYNC_MEM();
 }
 
+// ---- the same insert phase in four steps that spread the scan over the chip (paired-end encoding on one GPU): every triple is
+// looked at by ONE thread, which finds its owner (count -> offsets -> scatter into per-owner groups); owner `tid` then applies
+// its own group only.  With T owners each scanning all T sources the scan was T times the work and most of the phase's time.
+// Grouping is by atomic cursors, so the order inside a group varies from run to run -- the inserts commute.
+FQ_DEV bool pe_triple_owner(const DevCfg &cfg, u32 g, u32 &owner, u64 &key, u64 &value, u64 &cnt) {   // g = source * pe_cap + entry
+  const u32 src = g / cfg.pe_cap, e = g - src * cfg.pe_cap;
+  if (src >= cfg.T || e >= cfg.pe_n[src]) return false;
+  const u64 vm = (1ull << (2 * cfg.bmer)) - 1ull;
+  const u64 *t = cfg.pe_list + ((u64)src * cfg.pe_cap + e) * 3;
+  key = t[0]; value = t[1]; cnt = t[2];
+  if (key == vm || value == vm) return false;   // ht_kmer.cpp:126-127
+  owner = pe_owner(&cfg, murmur64(key));
+  return true;
+}
+FQ_DEV void pe_bucket_count_body(const DevCfg &cfg, u32 g) {
+  u32 owner = 0; u64 k, v, c;
+  if (pe_triple_owner(cfg, g, owner, k, v, c)) atomic_add32(&cfg.pe_bkt_n[owner], 1u);
+}
+FQ_DEV void pe_bucket_scatter_body(const DevCfg &cfg, u32 g) {
+  u32 owner = 0; u64 k, v, c;
+  if (!pe_triple_owner(cfg, g, owner, k, v, c)) return;
+  const u32 at = cfg.pe_bkt_n[cfg.T + owner] + atomic_add32(&cfg.pe_bkt_cur[owner], 1u);
+  u64 *d = cfg.pe_bkt + 3 * (u64)at;
+  d[0] = k; d[1] = v; d[2] = c;
+}
+template <class SM>
+FQ_DEV void pe_insert_bucket_body(const DevCfg &cfg, SM *sm, u32 tid) {
+  const u32 lo = cfg.pe_bkt_n[cfg.T + tid], hi = cfg.pe_bkt_n[cfg.T + tid + 1];
+  u32 err = 0;
+  for (u32 base = lo; base < hi && !err; base += FQ_WAVE) {
+    const u32 e = base + FQ_LANE, n = hi - base < FQ_WAVE ? hi - base : FQ_WAVE;
+    FQ_SYNC();
+    if (e < hi) { const u64 *t = cfg.pe_bkt + 3 * (u64)e; sm->pe_bk[0][FQ_LANE] = t[0]; sm->pe_bk[1][FQ_LANE] = t[1]; sm->pe_bk[2][FQ_LANE] = t[2]; }
+    FQ_SYNC();
+    pe_apply_batch(cfg, sm, tid, n, err);
+  }
+  if (err) *cfg.err = err;
+}
+
 // count_only: number of triples owner `tid` will insert (upper bound of new slots) -> demand[tid]
 template <class SM>
 FQ_DEV void pe_insert_body(const DevCfg &cfg, SM *sm, u32 tid, bool count_only, u32 *demand) {

@@ -70,6 +70,7 @@ FQ_DEV bool spin_expired(u32 &spins) {
   return (u32)((now - first) & 0xfffffu) > FQSX_WAIT_LIMIT_S * 95u;
 }
 FQ_DEV void atomic_add64(u64 *p, u64 v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
+FQ_DEV u32 atomic_add32(u32 *p, u32 v) { return atomicAdd(p, v); }   // returns the old value
 
 FQ_DEV u32 wave_sum32(u32 v) {
 #pragma unroll
@@ -149,6 +150,7 @@ FQ_DEV void lds_store_rel(u32 *p, u32 v) { *p = v; }
 FQ_DEV void fq_sleep() {}
 FQ_DEV bool spin_expired(u32 &spins) { return ++spins > (1u << 20); }
 FQ_DEV void atomic_add64(u64 *p, u64 v) { *p += v; }
+FQ_DEV u32 atomic_add32(u32 *p, u32 v) { const u32 o = *p; *p = o + v; return o; }
 static thread_local u32 fq_emu_block = 0, fq_emu_nblocks = 1;
 FQ_DEV u32 wave_sum32(u32 v) { return v; }
 FQ_DEV u64 wave_sum64(u64 v) { return v; }

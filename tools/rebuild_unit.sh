@@ -1,6 +1,6 @@
 #!/bin/bash
 # Recompile ONE translation unit of libfqsx.so from the working tree and relink (the other objects are reused as they are:
-# only valid when the edit does not touch what those units include).  usage: tools/rebuild_unit.sh fqsx_api.hip [out.so]
+# only valid when the edit does not touch what those units include: a change of fqsx_layout.h / fqsx_dev.h needs the full build).  usage: tools/rebuild_unit.sh fqsx_api.hip [out.so]
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 U=${1:-fqsx_api.hip}; OUT=${2:-$R/fqsqueezer_amd/libfqsx.so}
