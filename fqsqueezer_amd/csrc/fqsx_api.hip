@@ -916,13 +916,25 @@ int vtab_alloc(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 cbi
 int grow_global(fqsx_dna *c, KTab &t, u64 &cap_field, u64 new_cap) {
   KTab n = t;
   int rc;
-  if (c->part) {
+  fqsx_dna::VmTab &v = &t == &c->cfg.g_s ? c->vm_s : c->vm_b;
+  // A table of one GPU that reaches 2 GiB (FQSX_CHUNK_AUTO_KB: another size, 0 = never) becomes a chunked table at that growth
+  // by itself: from then on its growths never hold the old and the new table side by side (fqsx_dna_use_chunked_tables does
+  // it from the start).
+  const char *auto_env = getenv("FQSX_CHUNK_AUTO_KB");
+  const u64 auto_bytes = (auto_env ? strtoull(auto_env, nullptr, 10) : (2048ull << 10)) << 10;
+  bool chunked = c->part || v.live;
+  if (!chunked && c->shard_world == 1 && auto_bytes && new_cap * c->T * sizeof(u64) >= auto_bytes) {
+    if (!c->vm_gran) VMCHK(fqsx_vm::granularity(c->device, &c->vm_gran, e_));
+    chunked = c->vm_gran >= sizeof(u64) && !(c->vm_gran & (c->vm_gran - 1));
+  }
+  if (chunked) {
     // Chunked tables (partitioned over the ranks, or one GPU's capacity mode).  Every rank takes the same decision in the
     // same phase (the demand follows from the all-reduced counts and the exchanged occupancies), so the descriptor exchange
     // is collective; each rank re-inserts its own sub-tables, and the phase's all-gather orders that before anybody's next
     // look-up.  Sub-table by sub-table -- new chunk, re-insert, old chunk back to the device -- so that the old and the new
     // table are never alive side by side: the peak is the new table plus ONE old sub-table.
-    fqsx_dna::VmTab &v = &t == &c->cfg.g_s ? c->vm_s : c->vm_b, nv;
+    fqsx_dna::VmTab nv;
+    const bool old_chunked = v.live;   // (false once: the growth at which a plain table turns into a chunked one)
     if ((rc = vtab_reserve(c, n, nv, new_cap, t.k, t.cbits))) return rc;
     for (u32 o = c->shard_rank; o < c->T; o += c->shard_world) {
       if ((rc = vtab_create_own(c, nv, o))) return rc;
@@ -930,10 +942,10 @@ int grow_global(fqsx_dna *c, KTab &t, u64 &cap_field, u64 new_cap) {
 #ifndef FQSX_EMU
       HIPCHK(hipStreamSynchronize(c->stream));
 #endif
-      vtab_drop(c, v, o);
+      if (old_chunked) vtab_drop(c, v, o);
     }
     if ((rc = vtab_exchange(c, nv))) return rc;
-    vtab_free(c, v);
+    if (old_chunked) vtab_free(c, v); else dfree(c, t.slots);
     v = nv;
   } else {
     if ((rc = ktab_alloc(c, n, c->T, new_cap, t.k, t.cbits, false))) return rc;
@@ -2225,7 +2237,7 @@ int fqsx_dna_capacity(fqsx_dna *c, uint64_t out[16]) {
     out[11] = c->gpe_cap * T;
   }
   out[12] = sizeof(u64);   // bytes per global-table slot
-  out[13] = c->part ? c->vm_own_bytes : (c->gs_cap + c->gb_cap) * T * sizeof(u64);   // s- + b-mer table memory this rank holds
+  out[13] = c->vm_own_bytes + (c->vm_s.live ? 0 : c->gs_cap * T * sizeof(u64)) + (c->vm_b.live ? 0 : c->gb_cap * T * sizeof(u64));   // s- + b-mer table memory this rank holds
   return FQSX_OK;
 }
 

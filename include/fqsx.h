@@ -114,7 +114,8 @@ int fqsx_dna_capacity(fqsx_dna *, uint64_t out[16]);
  * fqs/ht_kmer.h:88-112): before the first block, switch the s- and b-mer tables to one chunk of physical memory per
  * sub-table inside one reserved address range (HIP virtual-memory API).  The kernels see the same layout; a growth then
  * re-inserts sub-table by sub-table and returns each old chunk before the next new one is made, so the peak is the new table
- * plus one old sub-table instead of old + new side by side.  Also chosen by the environment variable FQSX_CHUNKED_TABLES=1. */
+ * plus one old sub-table instead of old + new side by side.  Also chosen by the environment variable FQSX_CHUNKED_TABLES=1; and a
+ * table that reaches 2 GiB (FQSX_CHUNK_AUTO_KB: another size in KiB, 0 = never) turns into a chunked table at that growth by itself. */
 int fqsx_dna_use_chunked_tables(fqsx_dna *);
 
 /* Sharded mode (reference: the T x T mailboxes of fqs/application.h:56-59 and their owner-side

@@ -54,6 +54,16 @@ def test_chunked_tables_grow_sub_table_by_sub_table(name, monkeypatch):
     assert cap["device_bytes_peak"] - cap["device_bytes"] < (plain["device_bytes_peak"] - plain["device_bytes"]) // 2, (cap, plain)
 
 
+def test_tables_turn_into_chunked_tables_at_a_size_by_themselves(monkeypatch):
+    """a table of one GPU that reaches FQSX_CHUNK_AUTO_KB (default 2 GiB) continues as a chunked table from that growth on"""
+    monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    monkeypatch.setenv("FQSX_CHUNK_AUTO_KB", "64")
+    codec = check_against_fqs(emu, c1_records(), "c1_10k_s_t4.fqs")
+    cap = codec.capacity()
+    assert cap["growths"] >= 6 and cap["table_bytes_held"] == 8 * (cap["smer_slots"] + cap["bmer_slots"])
+    assert cap["device_bytes_peak"] - cap["device_bytes"] < 8 * cap["bmer_slots"] // 4, cap   # (the last growths went sub-table by sub-table)
+
+
 @pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
 def test_emu_matches_reference_ragged(name):
     check_against_fqs(emu, c4_records(), name)

@@ -45,6 +45,14 @@ def test_hip_chunked_tables_grow_sub_table_by_sub_table(name, monkeypatch):
     assert (plain["smers"], plain["bmers"], plain["growths"]) == (cap["smers"], cap["bmers"], cap["growths"])
 
 
+def test_hip_tables_turn_into_chunked_tables_at_a_size_by_themselves(monkeypatch):
+    """a table of one GPU that reaches FQSX_CHUNK_AUTO_KB (default 2 GiB: the c19 test passes it) continues as a chunked table"""
+    monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    monkeypatch.setenv("FQSX_CHUNK_AUTO_KB", "64")
+    cap = check_against_fqs(gpu, c1_records(), "c1_10k_s_t4.fqs").capacity()
+    assert cap["growths"] >= 6 and cap["table_bytes_held"] == 8 * (cap["smer_slots"] + cap["bmer_slots"])
+
+
 @pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
 def test_hip_matches_reference_ragged(name):
     check_against_fqs(gpu, c4_records(), name)
