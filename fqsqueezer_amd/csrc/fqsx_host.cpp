@@ -1,6 +1,7 @@
 // fqsx_host.cpp -- host-side (CPU) plumbing that travels with the DNA path: the read-length
 // ("meta") stream every .fqs block carries (reference fqs/meta.cpp:31-73, application.cpp:633), the read-id
-// stream (fqs/id.cpp, SURVEY.md §8f row N4: string tokeniser + delta coder, host work by design) and the
+// stream (fqs/id.cpp, SURVEY.md §8f row N4: string tokeniser + delta coder; the host twin of the GPU coder csrc/fqsx_idk.h,
+// which the tests compare it with byte for byte) and the
 // per-bin read order of sorted mode.  None of it is on the hot path; it exists so that a complete container
 // can be written around the GPU DNA / quality streams and handed to the reference decoder.
 #include "../../include/fqsx.h"
