@@ -99,3 +99,68 @@ def test_partitioned_tables_world_of_one_over_rccl():
         one.close()
     finally:
         os.environ.pop("FQSX_GTAB_INIT", None)
+
+
+# ---- configs[3]-shaped input (c19: 10 M x 150 bp, G = 300 Mbp, -gs 300, T = 64) with the k-mer tables partitioned over two ranks:
+# every block's digest against the REFERENCE's (tests/golden/c19_10M150_gs300_s_t64.json), tables of several GB in chunks of tens
+# of MB, half of them on either rank.  Both ranks share the box's one GPU (collectives staged through the host).
+C19_WORKER = r'''
+import faulthandler, hashlib, json, os, sys
+faulthandler.enable()
+sys.path.insert(0, os.environ["FQSX_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.codec import sort_order
+from fqsqueezer_amd.sharded import NativeShardedDnaCodec
+from fqsqueezer_amd.synth import read_id, synth_reads
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+d = json.load(open(os.path.join(os.environ["FQSX_ROOT"], "tests", "golden", "c19_10M150_gs300_s_t64.json")))
+limit = int(os.environ.get("FQSX_FULLSIZE_BLOCKS", "0")) or d["n_blocks"]
+n = d["reads"]
+reads = synth_reads(n, d["len"], d["genome"], d["seed"])
+rec = hp.Records([read_id(i) for i in range(n)], reads, reads)
+groups = sort_order(rec.seq.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(d["len"]))
+blks = hp.form_blocks(rec, "se_sorted", groups=groups)
+assert len(blks) == d["n_blocks"]
+header = bytes.fromhex(d["header"])
+T = header[4]
+sh = NativeShardedDnaCodec(header, rank, world, device=0, transport="staged", partition=True)
+for g, (idx, ref) in enumerate(zip(blks[:limit], d["blocks"])):
+    bases, off = hp.block_arrays(rec, idx)
+    mine = sh.encode_block(bases, off, g)
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    if rank == 0:
+        streams = {}
+        for p in parts:
+            streams.update(p)
+        h = hashlib.sha256()
+        for w in range(T):
+            h.update(streams[w])
+        assert sum(len(streams[w]) for w in range(T)) == ref["bytes"] and h.hexdigest() == ref["sha256"], f"block {g} differs from the reference"
+cap = sh.codec.capacity()
+lst = [None] * world
+dist.all_gather_object(lst, (cap["table_bytes_held"], 8 * (cap["smer_slots"] + cap["bmer_slots"]), cap["device_bytes_peak"], sh.traffic))
+if rank == 0:
+    held, whole = [x[0] for x in lst], lst[0][1]
+    assert sum(held) == whole and max(held) * 2 == whole, (held, whole)
+    print("PARTITIONED_C19_OK", limit, "blocks;", "table bytes per rank", held, "of", whole, "peak device bytes per rank", [x[2] for x in lst], lst[0][3])
+sh.close()
+dist.destroy_process_group()
+'''
+
+
+def test_partitioned_tables_c19_two_ranks_against_the_reference(tmp_path):
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", "c19_10M150_gs300_s_t64.json")):
+        pytest.skip("c19 golden has not been generated (tools/make_golden.py)")
+    script = tmp_path / "w.py"
+    script.write_text(C19_WORKER)
+    env = dict(os.environ, FQSX_ROOT=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29563", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1100)
+    i = r.stderr.find("Fatal Python error")
+    assert r.returncode == 0, (r.stdout[-1500:] + (r.stderr[max(0, i - 500):i + 2500] if i >= 0 else r.stderr[-3000:]))
+    assert "PARTITIONED_C19_OK" in r.stdout
+    print(r.stdout[r.stdout.find("PARTITIONED_C19_OK"):][:600])
