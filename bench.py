@@ -247,9 +247,22 @@ def main() -> None:
             return r
 
         part, free = conc_pass(True), conc_pass(False)
+        # the same with one PROCESS per file (tools/gpu_multi_proc_part.py: own HIP queues and runtime locks per file; the threads
+        # above share this process's), on CU partitions as well
+        procs = None
+        if a.reads == 1_000_000 and a.len == 150 and a.genome == 7_500_000 and a.gs == 8 and a.threads == 64 and a.concurrent <= 4:
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_multi_proc_part.py"), str(a.concurrent), "1"],
+                                   capture_output=True, text=True, timeout=600)
+                procs = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
+                if "value" in procs:
+                    procs["speedup_over_one_file"] = round(procs["value"] / value, 3)
+            except Exception as e:   # noqa: BLE001 -- extra information only
+                procs = {"error": str(e)[:300]}
         conc = {"instances": a.concurrent, "value": part["value"], "unit": "Mbases/s", "identical_output": part["identical_output"] and free["identical_output"],
                 "steady_state_value": part.get("steady_state_value"), "speedup_over_one_file": round(part["value"] / value, 3),
-                "unpartitioned": free,
+                "unpartitioned": free, "one_process_per_file": procs,
                 "note": "independent compressions of the workload file running concurrently on one GPU as threads of this process, each codec on "
                         "its own partition of the compute units (fqsx_dna_create_on_partition: CU-masked stream; one file occupies T of the 256 CUs); "
                         "`unpartitioned` = the same with plain streams (the files' kernels queue behind each other for CUs); aggregate rates"}
