@@ -117,7 +117,7 @@ dist.destroy_process_group()
 # and looks the others' up through the mapping; the tables start at 64 slots per sub-table so that they grow several times
 @pytest.mark.parametrize("world,T,mode,port,partition", [(2, 5, "se_sorted", 29533, 0), (3, 4, "se_original", 29534, 0), (2, 4, "pe_sorted", 29535, 0),
                                                          (3, 5, "pe_original", 29536, 0), (2, 5, "se_sorted", 29537, 1), (3, 7, "se_original", 29538, 1),
-                                                         (3, 4, "pe_sorted", 29539, 1)])
+                                                         (3, 4, "pe_sorted", 29539, 1), (2, 6, "pe_original", 29540, 1)])
 def test_native_sharded_driver_streams_identical_to_one_process_run(tmp_path, built, world, T, mode, port, partition):
     script = tmp_path / "w.py"
     script.write_text(NATIVE_WORKER)
