@@ -115,7 +115,7 @@ from fqsqueezer_amd.sharded import NativeShardedDnaCodec
 from fqsqueezer_amd.synth import read_id, synth_reads
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-d = json.load(open(os.path.join(os.environ["FQSX_ROOT"], "tests", "golden", "c19_10M150_gs300_s_t64.json")))
+d = json.load(open(os.path.join(os.environ["FQSX_ROOT"], "tests", "golden", os.environ["FQSX_GOLDEN"])))
 limit = int(os.environ.get("FQSX_FULLSIZE_BLOCKS", "0")) or d["n_blocks"]
 n = d["reads"]
 reads = synth_reads(n, d["len"], d["genome"], d["seed"])
@@ -144,21 +144,23 @@ lst = [None] * world
 dist.all_gather_object(lst, (cap["table_bytes_held"], 8 * (cap["smer_slots"] + cap["bmer_slots"]), cap["device_bytes_peak"], sh.traffic))
 if rank == 0:
     held, whole = [x[0] for x in lst], lst[0][1]
-    assert sum(held) == whole and max(held) * 2 == whole, (held, whole)
-    print("PARTITIONED_C19_OK", limit, "blocks;", "table bytes per rank", held, "of", whole, "peak device bytes per rank", [x[2] for x in lst], lst[0][3])
+    assert sum(held) == whole and max(held) * world == whole, (held, whole)
+    print("PARTITIONED_C19_OK", os.environ["FQSX_GOLDEN"], limit, "blocks;", "table bytes per rank", held, "of", whole, "peak device bytes per rank", [x[2] for x in lst], lst[0][3])
 sh.close()
 dist.destroy_process_group()
 '''
 
 
-def test_partitioned_tables_c19_two_ranks_against_the_reference(tmp_path):
-    if not os.path.exists(os.path.join(ROOT, "tests", "golden", "c19_10M150_gs300_s_t64.json")):
-        pytest.skip("c19 golden has not been generated (tools/make_golden.py)")
+# c17 = the reference's DEFAULT geometry (-gs 3100: k = 13 / 18 / 21 / 27, 16 GiB p-mer vector per rank) on 1 M reads, T = 8, over four ranks
+@pytest.mark.parametrize("golden,world,port", [("c19_10M150_gs300_s_t64.json", 2, 29563), ("c17_1M150_gs3100_s_t8.json", 4, 29564)])
+def test_partitioned_tables_c19_two_ranks_against_the_reference(tmp_path, golden, world, port):
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", golden)):
+        pytest.skip(f"{golden} has not been generated (tools/make_golden.py)")
     script = tmp_path / "w.py"
     script.write_text(C19_WORKER)
-    env = dict(os.environ, FQSX_ROOT=ROOT)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29563", str(script)]
+    env = dict(os.environ, FQSX_ROOT=ROOT, FQSX_GOLDEN=golden)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1100)
     i = r.stderr.find("Fatal Python error")
     assert r.returncode == 0, (r.stdout[-1500:] + (r.stderr[max(0, i - 500):i + 2500] if i >= 0 else r.stderr[-3000:]))
