@@ -320,22 +320,22 @@ FQ_KERNEL void k_rehash_ctx(const u64 *o, u64 ocap_mask, u64 *n, u64 ncap_mask, 
 // ---- sharded mode: what is exchanged between the GPUs of a node ---------------------------------
 // C[kind][s][o] = entries source s pushed for owner o in this phase (after k_part_count, before k_part_scan turns the
 // tile counts into offsets); rows of workers that live elsewhere stay zero, so a sum over the ranks gives the matrix
-FQ_KERNEL64 void k_shard_counts(DevCfg cfg) {   // grid = 3 * T: (kind, source)
-  const u32 T = cfg.T, kind = FQ_BLOCK / T, s = FQ_BLOCK % T;
+FQ_KERNEL64 void k_shard_counts(DevCfg cfg, u32 *dst) {   // grid = 3 * T + 1: (kind, source), then the tail
+  const u32 T = cfg.T;
+  if (FQ_BLOCK == 3 * T) {   // tail of the count matrix: [3 T^2 + s] = paired-end triples source s pushed in this phase (own sources, else 0)
+    for (u32 s = FQ_LANE; s < T; s += FQ_WAVE) dst[3ull * T * T + s] = (cfg.pe_n && shard_mine(cfg, s)) ? cfg.pe_n[s] : 0u;
+    return;
+  }
+  const u32 kind = FQ_BLOCK / T, s = FQ_BLOCK % T;
   const Mail &m = cfg.mail[kind];
   for (u32 o = FQ_LANE; o < T; o += FQ_WAVE) {
     u32 n = 0;
     if (shard_mine(cfg, s))
       for (u32 t = 0; t < m.n_tiles; ++t) n += m.tile_hist[((u64)s * m.n_tiles + t) * T + cfg.vmap[o]];
-    cfg.shard_cnt[((u64)kind * T + s) * T + o] = n;
+    dst[((u64)kind * T + s) * T + o] = n;
   }
 }
 // ---- native sharded driver (fqsx_shard_encode_block): the words that ride along with the collectives ------------
-// tail of the count matrix: [3 T^2 + s] = paired-end triples source s pushed in this phase (own sources, else 0)
-FQ_KERNEL64 void k_shard_counts_tail(DevCfg cfg) {
-  const u32 T = cfg.T;
-  for (u32 s = FQ_LANE; s < T; s += FQ_WAVE) cfg.shard_cnt[3ull * T * T + s] = (cfg.pe_n && shard_mine(cfg, s)) ? cfg.pe_n[s] : 0u;
-}
 // after the all-reduce of the counts: out[0/1] = table demand of the coming insert phase (occupied + incoming slots of the
 // fullest s- / b-mer sub-table: every rank holds a replica of every sub-table, so every rank computes the same numbers),
 // out[2] = the device error word
@@ -415,9 +415,18 @@ FQ_KERNEL64 void k_shard_fill_unpack(DevCfg cfg, const u64 *gathered, u64 stride
 // Received entries -> this rank's owners' groups in (owner, source, push) order (the order InsertKmersToHT drains
 // its column in).  recv = the chunks of ranks 0..G-1 one after the other; the chunk of rank q holds, for every owner
 // of this rank in ascending order, the entries of q's sources in ascending order.  C = the summed count matrix.
+FQ_DEV void shard_merge_body(const DevCfg &cfg, u32 kind, u32 o, const u64 *recv, const u32 *C, u32 *col, u32 *pre);
 FQ_KERNEL64 void k_shard_merge(DevCfg cfg, u32 kind, const u64 *recv, const u32 *C) {   // grid = T (owner)
   FQ_SHARED u32 col[256], pre[256];
-  const u32 T = cfg.T, G = cfg.shard_world, me = cfg.shard_rank, o = FQ_BLOCK;
+  shard_merge_body(cfg, kind, FQ_BLOCK, recv, C, col, pre);
+}
+FQ_KERNEL64 void k_shard_merge3(DevCfg cfg, const u64 *recv0, const u64 *recv1, const u64 *recv2, const u32 *C) {   // grid = 3 T: (kind, owner)
+  FQ_SHARED u32 col[256], pre[256];
+  const u32 kind = FQ_BLOCK / cfg.T;
+  shard_merge_body(cfg, kind, FQ_BLOCK % cfg.T, kind == 0 ? recv0 : kind == 1 ? recv1 : recv2, C, col, pre);
+}
+FQ_DEV void shard_merge_body(const DevCfg &cfg, u32 kind, u32 o, const u64 *recv, const u32 *C, u32 *col, u32 *pre) {
+  const u32 T = cfg.T, G = cfg.shard_world, me = cfg.shard_rank;
   const Mail &m = cfg.mail[kind];
   const u32 *Ck = C + (u64)kind * T * T;
   const u32 n_own = (T - me + G - 1) / G;   // owners of this rank: me, me + G, ...
@@ -853,7 +862,14 @@ void vtab_free(fqsx_dna *c, fqsx_dna::VmTab &v) {
 // the address range of a table of T sub-tables with `cap` slots each; nothing mapped yet
 int vtab_reserve(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 cbits) {
   const u32 T = c->T;
-  const u64 stride = std::max<u64>(cap, c->vm_gran / sizeof(u64));   // (both powers of two: a sub-table is whole chunks)
+#ifndef FQSX_EMU
+  // a chunk is at least 2 MiB (and 2 MiB-aligned, below): with 4 KiB-granular chunks the 1 M-read file ran 7 % slower than on
+  // hipMalloc'ed tables (blocks 0-69: 10 %) -- page-table fragments of the size of the chunk
+  const u64 min_chunk = std::max<u64>(c->vm_gran, 2ull << 20);
+#else
+  const u64 min_chunk = c->vm_gran;
+#endif
+  const u64 stride = std::max<u64>(cap, min_chunk / sizeof(u64));   // (both powers of two: a sub-table is whole chunks)
   v = fqsx_dna::VmTab();
   v.chunk_bytes = stride * sizeof(u64);
   v.va_bytes = v.chunk_bytes * T;
@@ -932,17 +948,26 @@ int grow_global(fqsx_dna *c, KTab &t, u64 &cap_field, u64 new_cap) {
     // same phase (the demand follows from the all-reduced counts and the exchanged occupancies), so the descriptor exchange
     // is collective; each rank re-inserts its own sub-tables, and the phase's all-gather orders that before anybody's next
     // look-up.  Sub-table by sub-table -- new chunk, re-insert, old chunk back to the device -- so that the old and the new
-    // table are never alive side by side: the peak is the new table plus ONE old sub-table.
+    // table are never alive side by side: the peak is the new table plus one step's old sub-tables.
     fqsx_dna::VmTab nv;
     const bool old_chunked = v.live;   // (false once: the growth at which a plain table turns into a chunked one)
     if ((rc = vtab_reserve(c, n, nv, new_cap, t.k, t.cbits))) return rc;
-    for (u32 o = c->shard_rank; o < c->T; o += c->shard_world) {
-      if ((rc = vtab_create_own(c, nv, o))) return rc;
-      LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, 1u, o, 1u);
+    // (several sub-tables per step while they are small -- at least 256 MB of new chunks per step, all of them for a small
+    // table: a step costs a memory-create / map / synchronise / unmap round of about a millisecond)
+    const u32 G = c->shard_world, n_own = (c->T - c->shard_rank + G - 1) / G;
+    const char *step_env = getenv("FQSX_CHUNK_STEP_KB");   // (tests: 1 = one sub-table per step whatever its size)
+    const u64 step_bytes = (step_env ? strtoull(step_env, nullptr, 10) : (256ull << 10)) << 10;
+    const u32 per_step = (u32)std::max<u64>(1, std::min<u64>(n_own, step_bytes / nv.chunk_bytes));
+    for (u32 j0 = 0; j0 < n_own; j0 += per_step) {
+      const u32 nb = std::min(per_step, n_own - j0), first = c->shard_rank + j0 * G;
+      for (u32 j = 0; j < nb; ++j)
+        if ((rc = vtab_create_own(c, nv, first + j * G))) return rc;
+      LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, nb, first, G);
 #ifndef FQSX_EMU
       HIPCHK(hipStreamSynchronize(c->stream));
 #endif
-      if (old_chunked) vtab_drop(c, v, o);
+      if (old_chunked)
+        for (u32 j = 0; j < nb; ++j) vtab_drop(c, v, first + j * G);
     }
     if ((rc = vtab_exchange(c, nv))) return rc;
     if (old_chunked) vtab_free(c, v); else dfree(c, t.slots);
@@ -1764,7 +1789,7 @@ int fqsx_shard_encode(fqsx_dna *c, uint32_t seg, uint32_t *counts /*[codec] [3][
   if ((rc = launch_segment(c, false, c->cur_n_reads, c->cur_S, seg))) return rc;
   const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
   LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
-  LAUNCH(c, 2, k_shard_counts, 3 * T, 64, cfg);
+  LAUNCH(c, 2, k_shard_counts, 3 * T + 1, 64, cfg, cfg.shard_cnt);
   if ((rc = d2d(c, counts, cfg.shard_cnt, 3ull * T * T * sizeof(u32)))) return rc;
   u32 err = 0;
   if ((rc = d2h_sync(c, &err, cfg.err, sizeof(u32)))) return rc;
@@ -1904,9 +1929,7 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   if ((rc = launch_segment(c, false, c->cur_n_reads, c->cur_S, seg))) return rc;
   const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
   LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
-  LAUNCH(c, 2, k_shard_counts, 3 * T, 64, cfg);
-  LAUNCH(c, 2, k_shard_counts_tail, 1, 64, cfg);
-  if ((rc = d2d(c, c->d_cglob, cfg.shard_cnt, NC * sizeof(u32)))) return rc;
+  LAUNCH(c, 2, k_shard_counts, 3 * T + 1, 64, cfg, c->d_cglob);   // (straight into the buffer the all-reduce runs on)
   COMMCHK(c->comm.allreduce_sum_u32(c->comm.ctx, c->d_cglob, NC), "all-reduce of the mailbox counts");   // collective 1
   LAUNCH(c, 2, k_shard_need, 1, 64, cfg, (const u32 *)c->d_cglob, c->d_small + 2);
   // ---- the phase's one host round trip: every transfer size, the table demand, the error word
@@ -1943,7 +1966,7 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
     recv[k] = c->d_xrecv[k];
   }
   COMMCHK(c->comm.alltoallv_u64(c->comm.ctx, 3, send, sc.data(), recv, rcnt.data()), "all-to-all of the mailboxes");   // collective 2
-  for (u32 k = 0; k < 3; ++k) LAUNCH(c, 2, k_shard_merge, T, 64, cfg, k, (const u64 *)c->d_xrecv[k], (const u32 *)c->d_cglob);
+  LAUNCH(c, 2, k_shard_merge3, 3 * T, 64, cfg, (const u64 *)c->d_xrecv[0], (const u64 *)c->d_xrecv[1], (const u64 *)c->d_xrecv[2], (const u32 *)c->d_cglob);
   // ---- growth (every rank sees the same demand: the replicas are exact), insert phase of own owners
   if (small[0] * 2 > c->gs_cap && (rc = grow_global(c, cfg.g_s, c->gs_cap, pow2_at_least(small[0] * 2 + 2)))) return rc;
   if (small[1] * 2 > c->gb_cap && (rc = grow_global(c, cfg.g_b, c->gb_cap, pow2_at_least(small[1] * 2 + 2)))) return rc;
@@ -1956,6 +1979,7 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   for (u32 k = 0; k < 3; ++k)
     for (u32 q = 0; q < G; ++q) {
       if (c->part && k != MAIL_P) continue;
+      if (G == 1 && !c->shard_apply_own) continue;   // (nobody to hand the items to)
       for (u32 f = 0; f < G; ++f) n_items[(u64)k * G + q] += vol[((u64)k * G + f) * G + q];
       M[k] = std::max(M[k], n_items[(u64)k * G + q]);
     }

@@ -42,6 +42,7 @@ def test_chunked_tables_grow_sub_table_by_sub_table(name, monkeypatch):
     (memfd + mmap in this build, hipMemCreate + hipMemMap on the GPU); a growth re-inserts sub-table by sub-table and returns
     each old chunk before the next new one exists.  Streams stay the reference's; the peak stays below old + new."""
     monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    monkeypatch.setenv("FQSX_CHUNK_STEP_KB", "1")      # (one sub-table per growth step although the tables are small)
     monkeypatch.setenv("FQSX_CHUNKED_TABLES", "1")
     codec = check_against_fqs(emu, c1_records(), name)
     cap = codec.capacity()
@@ -57,6 +58,7 @@ def test_chunked_tables_grow_sub_table_by_sub_table(name, monkeypatch):
 def test_tables_turn_into_chunked_tables_at_a_size_by_themselves(monkeypatch):
     """a table of one GPU that reaches FQSX_CHUNK_AUTO_KB (default 2 GiB) continues as a chunked table from that growth on"""
     monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    monkeypatch.setenv("FQSX_CHUNK_STEP_KB", "1")
     monkeypatch.setenv("FQSX_CHUNK_AUTO_KB", "64")
     codec = check_against_fqs(emu, c1_records(), "c1_10k_s_t4.fqs")
     cap = codec.capacity()

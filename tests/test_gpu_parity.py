@@ -39,6 +39,7 @@ def test_hip_chunked_tables_grow_sub_table_by_sub_table(name, monkeypatch):
     growths re-insert sub-table by sub-table and give each old chunk back at once.  Same streams, same table contents."""
     from fqsqueezer_amd.codec import DnaCodec
     monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    monkeypatch.setenv("FQSX_CHUNK_STEP_KB", "1")      # (one sub-table per growth step although the tables are small)
     codec = check_against_fqs(lambda h: DnaCodec(h, device=0, chunked_tables=True), c1_records(), name)
     cap, plain = codec.capacity(), check_against_fqs(gpu, c1_records(), name).capacity()
     assert cap["growths"] >= 4 and cap["table_bytes_held"] == 8 * (cap["smer_slots"] + cap["bmer_slots"])
@@ -48,6 +49,7 @@ def test_hip_chunked_tables_grow_sub_table_by_sub_table(name, monkeypatch):
 def test_hip_tables_turn_into_chunked_tables_at_a_size_by_themselves(monkeypatch):
     """a table of one GPU that reaches FQSX_CHUNK_AUTO_KB (default 2 GiB: the c19 test passes it) continues as a chunked table"""
     monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    monkeypatch.setenv("FQSX_CHUNK_STEP_KB", "1")
     monkeypatch.setenv("FQSX_CHUNK_AUTO_KB", "64")
     cap = check_against_fqs(gpu, c1_records(), "c1_10k_s_t4.fqs").capacity()
     assert cap["growths"] >= 6 and cap["table_bytes_held"] == 8 * (cap["smer_slots"] + cap["bmer_slots"])
