@@ -42,7 +42,7 @@ def test_hip_chunked_tables_grow_sub_table_by_sub_table(name, monkeypatch):
     monkeypatch.setenv("FQSX_CHUNK_STEP_KB", "1")      # (one sub-table per growth step although the tables are small)
     codec = check_against_fqs(lambda h: DnaCodec(h, device=0, chunked_tables=True), c1_records(), name)
     cap, plain = codec.capacity(), check_against_fqs(gpu, c1_records(), name).capacity()
-    assert cap["growths"] >= 4 and cap["table_bytes_held"] == 8 * (cap["smer_slots"] + cap["bmer_slots"])
+    assert cap["growths"] >= 4 and cap["table_bytes_held"] >= 8 * (cap["smer_slots"] + cap["bmer_slots"])   # (a chunk is at least 2 MiB)
     assert (plain["smers"], plain["bmers"], plain["growths"]) == (cap["smers"], cap["bmers"], cap["growths"])
 
 
@@ -52,7 +52,7 @@ def test_hip_tables_turn_into_chunked_tables_at_a_size_by_themselves(monkeypatch
     monkeypatch.setenv("FQSX_CHUNK_STEP_KB", "1")
     monkeypatch.setenv("FQSX_CHUNK_AUTO_KB", "64")
     cap = check_against_fqs(gpu, c1_records(), "c1_10k_s_t4.fqs").capacity()
-    assert cap["growths"] >= 6 and cap["table_bytes_held"] == 8 * (cap["smer_slots"] + cap["bmer_slots"])
+    assert cap["growths"] >= 6 and cap["table_bytes_held"] >= 8 * (cap["smer_slots"] + cap["bmer_slots"])
 
 
 @pytest.mark.parametrize("name", ["c4_ragged_o_t3.fqs", "c4_ragged_s_t3.fqs"])
