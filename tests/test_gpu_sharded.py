@@ -166,3 +166,69 @@ def test_partitioned_tables_c19_two_ranks_against_the_reference(tmp_path, golden
     assert r.returncode == 0, (r.stdout[-1500:] + (r.stderr[max(0, i - 500):i + 2500] if i >= 0 else r.stderr[-3000:]))
     assert "PARTITIONED_C19_OK" in r.stdout
     print(r.stdout[r.stdout.find("PARTITIONED_C19_OK"):][:600])
+
+
+# ---- BASELINE configs[2] at its full size (c18: 5 M pairs x 150 bp, -p -om s, T = 8) over two ranks with partitioned tables: the
+# DNA stream digests of every block against the reference's.  Minutes (eight workers): run with FQSX_SLOW=1.
+C18_WORKER = r'''
+import faulthandler, hashlib, json, os, sys
+faulthandler.enable()
+sys.path.insert(0, os.environ["FQSX_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.codec import sort_order
+from fqsqueezer_amd.sharded import NativeShardedDnaCodec
+from fqsqueezer_amd.synth import read_id, synth_pairs, synth_quals
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+d = json.load(open(os.path.join(os.environ["FQSX_ROOT"], "tests", "golden", "c18_pe5M_s_q8_t8.json")))
+limit = int(os.environ.get("FQSX_FULLSIZE_BLOCKS", "0")) or d["n_blocks"]
+n, L, seed = d["pairs"], d["len"], d["seed"]
+r1, r2 = synth_pairs(n, L, d["genome"], seed)
+rec1 = hp.Records([read_id(i, 1) for i in range(n)], r1, synth_quals(n, L, seed))       # (ids and qualities decide the block boundaries)
+rec2 = hp.Records([read_id(i, 2) for i in range(n)], r2, synth_quals(n, L, seed + 1))
+groups = sort_order(r1.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+blks = hp.form_blocks_pe(rec1, rec2, "pe_sorted", groups=groups)
+assert len(blks) == d["n_blocks"]
+print(f"rank {rank}: input ready", flush=True)
+header = hp.make_header(d["threads"], "pe_sorted", d["gs"])
+T = header[4]
+sh = NativeShardedDnaCodec(header, rank, world, device=0, transport="staged", partition=True)
+for g, (idx, ref) in enumerate(zip(blks[:limit], d["blocks"])):
+    bases, off = hp.block_arrays_pe(rec1, rec2, idx)
+    assert len(off) - 1 == ref["n_reads"]
+    mine = sh.encode_block(bases, off, g)
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    if rank == 0:
+        streams = {}
+        for p in parts:
+            streams.update(p)
+        h = hashlib.sha256()
+        for w in range(T):
+            h.update(streams[w])
+        assert h.hexdigest() == ref["2"], f"block {g}: DNA streams differ from the reference"
+        if g % 16 == 15:
+            print(f"block {g} ok", flush=True)
+cap = sh.codec.capacity()
+if rank == 0:
+    print("PARTITIONED_C18_OK", limit, "blocks;", {k: cap[k] for k in ("smers", "bmers", "pairs", "table_bytes_held", "device_bytes_peak", "growths")}, sh.traffic)
+sh.close()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.skipif(os.environ.get("FQSX_SLOW") != "1", reason="5 M pairs on eight workers over two ranks: minutes; set FQSX_SLOW=1")
+def test_partitioned_tables_c18_paired_end_full_size_against_the_reference(tmp_path):
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", "c18_pe5M_s_q8_t8.json")):
+        pytest.skip("c18 golden has not been generated (tools/make_golden.py)")
+    script = tmp_path / "w.py"
+    script.write_text(C18_WORKER)
+    env = dict(os.environ, FQSX_ROOT=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29565", str(script)]
+    r = subprocess.run(cmd, env=env, text=True, timeout=1150, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    i = r.stderr.find("Fatal Python error")
+    assert r.returncode == 0, (r.stdout[-1500:] + (r.stderr[max(0, i - 500):i + 2500] if i >= 0 else r.stderr[-3000:]))
+    assert "PARTITIONED_C18_OK" in r.stdout
+    print(r.stdout[r.stdout.find("PARTITIONED_C18_OK"):][:700])
