@@ -59,6 +59,9 @@ FQ_KERNEL64 void k_insert_phase(DevCfg cfg, u64 nb_slots, u64 ns_slots) {
     return;
   }
   insert_phase_body(cfg, &sm, FQ_BLOCK / 3, FQ_BLOCK % 3);
+  // partitioned tables: this owner's slots are read by other GPUs in the next launch -- out of this XCD's L2 into HBM
+  // before the kernel ends (the phase's collective then orders the end of this kernel before anybody's next look-up)
+  if (cfg.sys_scope) fq_release_system();
 }
 // gathers the T streams of the block into one contiguous buffer (one D2H transfer per block)
 FQ_KERNEL64 void k_compact_streams(DevCfg cfg, const u64 *lens, u8 *dst) {
@@ -261,16 +264,18 @@ FQ_KERNEL void k_rehash_ptab(PTab o, PTab n, u32 n_sub) {
 // re-insert every occupied slot of `o` into the (empty, larger) table `n`; layout-free, so parallel
 // n zero words at p (the chunks of a chunked table are cleared by a kernel of the codec's own stream, so that the order
 // against the re-insert kernel that follows does not hang on how the runtime treats a memset into a mapped range)
-FQ_KERNEL void k_zero_words(u64 *p, u64 n) {
+// sys: the words are a sub-table other GPUs will map (system-scope release at the end, see DevCfg.sys_scope)
+FQ_KERNEL void k_zero_words(u64 *p, u64 n, u32 sys) {
 #ifndef FQSX_EMU
   const u64 gstride = (u64)gridDim.x * blockDim.x;
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) p[i] = 0;
 #else
   for (u64 i = 0; i < n; ++i) p[i] = 0;
 #endif
+  if (sys) fq_release_system();
 }
 // (sub-tables first, first + step, ...: all of them on one GPU; a rank's own ones when the tables are partitioned)
-FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub, u32 first, u32 step) {
+FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub, u32 first, u32 step, u32 sys) {
   const u64 ocap = o.cap_mask + 1;
   const u64 total = ocap * n_sub;
 #ifndef FQSX_EMU
@@ -289,6 +294,7 @@ FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub, u32 first, u32 step) {
       p = (p + 1) & n.cap_mask;
     }
   }
+  if (sys) fq_release_system();   // (the new chunks are mapped by the other ranks next: k_zero_words)
 }
 FQ_KERNEL void k_rehash_ctx(const u64 *o, u64 ocap_mask, u64 *n, u64 ncap_mask, u32 T) {
   const u64 ocap = ocap_mask + 1, total = ocap * T;
@@ -320,10 +326,13 @@ FQ_KERNEL void k_rehash_ctx(const u64 *o, u64 ocap_mask, u64 *n, u64 ncap_mask, 
 // ---- sharded mode: what is exchanged between the GPUs of a node ---------------------------------
 // C[kind][s][o] = entries source s pushed for owner o in this phase (after k_part_count, before k_part_scan turns the
 // tile counts into offsets); rows of workers that live elsewhere stay zero, so a sum over the ranks gives the matrix
-FQ_KERNEL64 void k_shard_counts(DevCfg cfg, u32 *dst) {   // grid = 3 * T + 1: (kind, source), then the tail
+// status: what this rank's host has to report (a failure of its own since the last vote); [3 T^2 + T] = (status | device error
+// word) != 0, so that after the all-reduce every rank knows whether ANY rank is in trouble and all leave the phase together
+FQ_KERNEL64 void k_shard_counts(DevCfg cfg, u32 *dst, u32 status) {   // grid = 3 * T + 1: (kind, source), then the tail
   const u32 T = cfg.T;
   if (FQ_BLOCK == 3 * T) {   // tail of the count matrix: [3 T^2 + s] = paired-end triples source s pushed in this phase (own sources, else 0)
     for (u32 s = FQ_LANE; s < T; s += FQ_WAVE) dst[3ull * T * T + s] = (cfg.pe_n && shard_mine(cfg, s)) ? cfg.pe_n[s] : 0u;
+    if (FQ_LANE == 0) dst[3ull * T * T + T] = (status | cfg.err[0]) != 0 ? 1u : 0u;
     return;
   }
   const u32 kind = FQ_BLOCK / T, s = FQ_BLOCK % T;
@@ -629,6 +638,7 @@ struct fqsx_dna {
   // partitioned tables (fqsx_shard_partition_tables): this rank holds the physical memory of its owners' sub-tables of
   // g_s / g_b and maps the other ranks' next to them (fqsx_vm.h)
   bool part;
+  bool part_fallback;   // fqsx_shard_partition_tables found GPUs without peer access: the world keeps replicas
   u64 vm_gran;
   fqsx_vm::FdMesh mesh;
   struct VmTab {
@@ -893,7 +903,7 @@ int vtab_create_own(fqsx_dna *c, fqsx_dna::VmTab &v, u32 o) {
   VMCHK(fqsx_vm::map(c->device, v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, v.h[o], e_));
   v.mapped[o] = 1;
   const u64 words = v.chunk_bytes / sizeof(u64);   // (a peer reads the chunk only after a collective that follows on this stream)
-  LAUNCH(c, 2, k_zero_words, (u32)std::min<u64>(REHASH_GRID, (words + 255) / 256), 256, (u64 *)(v.va + (u64)o * v.chunk_bytes), words);
+  LAUNCH(c, 2, k_zero_words, (u32)std::min<u64>(REHASH_GRID, (words + 255) / 256), 256, (u64 *)(v.va + (u64)o * v.chunk_bytes), words, c->cfg.sys_scope);
   return FQSX_OK;
 }
 // Collective: every rank hands the descriptors of its own chunks to every other rank and maps what it receives
@@ -962,7 +972,7 @@ int grow_global(fqsx_dna *c, KTab &t, u64 &cap_field, u64 new_cap) {
       const u32 nb = std::min(per_step, n_own - j0), first = c->shard_rank + j0 * G;
       for (u32 j = 0; j < nb; ++j)
         if ((rc = vtab_create_own(c, nv, first + j * G))) return rc;
-      LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, nb, first, G);
+      LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, nb, first, G, c->cfg.sys_scope);
 #ifndef FQSX_EMU
       HIPCHK(hipStreamSynchronize(c->stream));
 #endif
@@ -974,7 +984,7 @@ int grow_global(fqsx_dna *c, KTab &t, u64 &cap_field, u64 new_cap) {
     v = nv;
   } else {
     if ((rc = ktab_alloc(c, n, c->T, new_cap, t.k, t.cbits, false))) return rc;
-    LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, c->T, 0u, 1u);
+    LAUNCH(c, 2, k_rehash_ktab, REHASH_GRID, 256, t, n, c->T, 0u, 1u, 0u);
 #ifndef FQSX_EMU
     HIPCHK(hipStreamSynchronize(c->stream));
 #endif
@@ -1619,7 +1629,7 @@ int fqsx_dna_create_on_partition(const uint8_t *h, int device, uint32_t part, ui
   for (int k = 0; k < 3; ++k) { c->d_xrecv[k] = nullptr; c->xrecv_cap[k] = 0; }
   c->d_items = c->d_gathered = c->d_small = nullptr; c->items_cap = c->gathered_cap = 0;
   c->sh_phases = c->sh_collectives = c->sh_a2a_words = c->sh_gather_words = 0;
-  c->part = false; c->vm_gran = 0; c->vm_own_bytes = 0;
+  c->part = false; c->part_fallback = false; c->vm_gran = 0; c->vm_own_bytes = 0;
   c->dev_bytes = c->dev_bytes_peak = 0; c->n_growths = 0;
   c->h_pin = nullptr; c->d_end = nullptr; c->filled_valid = false;
   c->d_vmap = nullptr; c->d_xbuf = nullptr; c->xbuf_cap = 0; c->d_cglob = nullptr;
@@ -1751,13 +1761,13 @@ int fqsx_shard_config(fqsx_dna *c, uint32_t rank, uint32_t world) {
   void *p = nullptr;
   if ((rc = h2d(c, c->d_vmap, vm, 256))) return rc;
   if (!c->cfg.shard_cnt) {
-    if ((rc = dalloc(c, &p, (3ull * T * T + T) * sizeof(u32), true))) return rc;   // (+ T: paired-end triples per source)
+    if ((rc = dalloc(c, &p, (3ull * T * T + T + 1) * sizeof(u32), true))) return rc;   // (+ T: paired-end triples per source, + 1: status word)
     c->cfg.shard_cnt = (u32 *)p;
-    if ((rc = dalloc(c, &p, (3ull * T * T + T) * sizeof(u32), true))) return rc;
+    if ((rc = dalloc(c, &p, (3ull * T * T + T + 1) * sizeof(u32), true))) return rc;
     c->d_cglob = (u32 *)p;
     if ((rc = dalloc(c, &p, 8 * sizeof(u64), true))) return rc;
     c->d_small = (u64 *)p;
-    c->h_cglob.assign(3ull * T * T + T, 0);
+    c->h_cglob.assign(3ull * T * T + T + 1, 0);
   }
 #ifndef FQSX_EMU
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1769,6 +1779,9 @@ int fqsx_shard_begin_block(fqsx_dna *c, const uint8_t *bases /*[codec]*/, const 
                            uint32_t n_reads, uint32_t generation, uint32_t *n_segments) {
   if (!c || !bases || !off || !h_off || !n_segments) { g_err = "null argument"; return FQSX_E_ARG; }
   if (c->part) { g_err = "partitioned tables are driven through fqsx_shard_encode_block"; return FQSX_E_ARG; }
+  // the step-wise driver exchanges the three k-mer mailboxes only: the pair-table triples of a paired-end file travel with
+  // the native loop's all-gather (shard_phase_native), nowhere else -- a world of several ranks would leave the pair table empty
+  if (c->paired && c->shard_world > 1) { g_err = "paired-end files are sharded through fqsx_shard_attach + fqsx_shard_encode_block (the step-wise fqsx_shard_* driver does not exchange the pair-table triples)"; return FQSX_E_ARG; }
 #ifndef FQSX_EMU
   HIPCHK(hipSetDevice(c->device));
 #endif
@@ -1789,7 +1802,7 @@ int fqsx_shard_encode(fqsx_dna *c, uint32_t seg, uint32_t *counts /*[codec] [3][
   if ((rc = launch_segment(c, false, c->cur_n_reads, c->cur_S, seg))) return rc;
   const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
   LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
-  LAUNCH(c, 2, k_shard_counts, 3 * T + 1, 64, cfg, cfg.shard_cnt);
+  LAUNCH(c, 2, k_shard_counts, 3 * T + 1, 64, cfg, cfg.shard_cnt, 0u);
   if ((rc = d2d(c, counts, cfg.shard_cnt, 3ull * T * T * sizeof(u32)))) return rc;
   u32 err = 0;
   if ((rc = d2h_sync(c, &err, cfg.err, sizeof(u32)))) return rc;
@@ -1918,18 +1931,46 @@ int xbuf_fit(fqsx_dna *c, u64 *&buf, u64 &cap, u64 words) {
   cap = ncap;
   return FQSX_OK;
 }
-#define COMMCHK(x, what) do { if ((x) != 0) { if (g_err.empty() || g_err.find(what) == std::string::npos) g_err = std::string(what) + " failed"; return FQSX_E_HIP; } } while (0)
+// A collective that fails is not something the ranks can agree on any more: the transport is told to give up (RCCL:
+// ncclCommAbort, so that this rank's part of a pending collective does not keep the others' kernels spinning) and the call fails.
+#define COMMCHK(x, what) do { if ((x) != 0) { if (g_err.empty() || g_err.find(what) == std::string::npos) g_err = std::string(what) + " failed"; if (c->comm.abort) c->comm.abort(c->comm.ctx); return FQSX_E_HIP; } } while (0)
+
+// All ranks leave a phase together or not at all: RCCL has no timeout, so a rank that returned between two collectives would
+// leave the others waiting in the next one for ever.  What a rank can fail on by itself -- the device error word of its encode
+// launch, a device allocation, a table growth -- is therefore put to a vote before anybody moves on:
+//   * the all-reduced count matrix carries one status word (k_shard_counts): encode errors are known to all after collective 1;
+//   * buffers and tables are sized from numbers every rank holds alike (the summed matrix, the replicated / exchanged
+//     occupancies), so "does anybody allocate or grow in this phase" has the same answer everywhere; in such a phase -- a few
+//     per file -- the ranks allocate and grow first and then all-reduce one word before the mailboxes travel.
+// fail: this rank's own verdict (0 = fine).  Returns 0 if every rank is fine, this rank's error code or FQSX_E_PEER otherwise.
+int shard_vote(fqsx_dna *c, int fail, const char *what) {
+  const u64 NC = 3ull * c->T * c->T + c->T + 1;
+  u32 *word = c->d_cglob + NC - 1;   // (the status word of the count matrix: read by the host already)
+  u32 v = fail ? 1u : 0u;
+  const std::string mine = g_err;
+  int rc;
+  if ((rc = h2d(c, word, &v, sizeof(v)))) return rc;
+#ifndef FQSX_EMU
+  HIPCHK(hipStreamSynchronize(c->stream));   // (v is a stack variable)
+#endif
+  COMMCHK(c->comm.allreduce_sum_u32(c->comm.ctx, word, 1), "all-reduce of the phase's status vote");
+  if ((rc = d2h_sync(c, &v, word, sizeof(v)))) return rc;
+  c->sh_collectives += 1;
+  if (fail) { g_err = mine; return fail; }
+  if (v) { g_err = std::string("another rank of the world failed in ") + what + " (this rank was fine): the phase is given up on every rank"; return FQSX_E_PEER; }
+  return FQSX_OK;
+}
 
 int shard_phase_native(fqsx_dna *c, u32 seg) {
   const u32 T = c->T, G = c->shard_world, me = c->shard_rank;
   DevCfg &cfg = c->cfg;
-  const u64 NC = 3ull * T * T + T;
+  const u64 NC = 3ull * T * T + T + 1;   // counts, paired-end triples per source, status word
   int rc;
   // ---- encode own workers, count what they pushed for whom
   if ((rc = launch_segment(c, false, c->cur_n_reads, c->cur_S, seg))) return rc;
   const u32 part_grid = T * (cfg.mail[0].n_tiles + cfg.mail[1].n_tiles + cfg.mail[2].n_tiles);
   LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
-  LAUNCH(c, 2, k_shard_counts, 3 * T + 1, 64, cfg, c->d_cglob);   // (straight into the buffer the all-reduce runs on)
+  LAUNCH(c, 2, k_shard_counts, 3 * T + 1, 64, cfg, c->d_cglob, 0u);   // (straight into the buffer the all-reduce runs on)
   COMMCHK(c->comm.allreduce_sum_u32(c->comm.ctx, c->d_cglob, NC), "all-reduce of the mailbox counts");   // collective 1
   LAUNCH(c, 2, k_shard_need, 1, 64, cfg, (const u32 *)c->d_cglob, c->d_small + 2);
   // ---- the phase's one host round trip: every transfer size, the table demand, the error word
@@ -1940,8 +1981,12 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   memcpy(c->h_cglob.data(), c->d_cglob, NC * sizeof(u32));
 #endif
   if ((rc = d2h_sync(c, small, c->d_small + 2, sizeof(small)))) return rc;
-  if (small[2]) { g_err = "device error " + std::to_string(small[2]) + " in encode kernel"; return FQSX_E_DEVICE; }
   const u32 *C = c->h_cglob.data();
+  if (C[NC - 1]) {   // a device error somewhere in the world: every rank sees the same word and leaves here
+    if (small[2]) { g_err = "device error " + std::to_string(small[2]) + " in encode kernel"; return FQSX_E_DEVICE; }
+    g_err = "device error in the encode kernel of another rank of the world (this rank was fine): the phase is given up on every rank";
+    return FQSX_E_PEER;
+  }
   std::vector<u64> vol(3ull * G * G, 0);   // [kind][from rank][to rank]
   for (u32 k = 0; k < 3; ++k)
     for (u32 s = 0; s < T; ++s)
@@ -1953,26 +1998,18 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   std::vector<u64> sc(3ull * G), rcnt(3ull * G);
   const u64 *send[3];
   u64 *recv[3];
+  u64 recv_need[3] = {0, 0, 0};   // the largest rank's incoming entries: every rank sizes its buffer for that (same capacity everywhere)
   for (u32 k = 0; k < 3; ++k) {
-    u64 n_in = 0;
     for (u32 q = 0; q < G; ++q) {
       sc[(u64)k * G + q] = vol[((u64)k * G + me) * G + q];
       rcnt[(u64)k * G + q] = vol[((u64)k * G + q) * G + me];
-      n_in += rcnt[(u64)k * G + q];
       if (q != me) c->sh_a2a_words += sc[(u64)k * G + q];
+      u64 n_in = 0;
+      for (u32 f = 0; f < G; ++f) n_in += vol[((u64)k * G + f) * G + q];
+      recv_need[k] = std::max(recv_need[k], n_in + 1);
     }
-    if ((rc = xbuf_fit(c, c->d_xrecv[k], c->xrecv_cap[k], n_in + 1))) return rc;
-    send[k] = cfg.mail[k].sorted;
-    recv[k] = c->d_xrecv[k];
   }
-  COMMCHK(c->comm.alltoallv_u64(c->comm.ctx, 3, send, sc.data(), recv, rcnt.data()), "all-to-all of the mailboxes");   // collective 2
-  LAUNCH(c, 2, k_shard_merge3, 3 * T, 64, cfg, (const u64 *)c->d_xrecv[0], (const u64 *)c->d_xrecv[1], (const u64 *)c->d_xrecv[2], (const u32 *)c->d_cglob);
-  // ---- growth (every rank sees the same demand: the replicas are exact), insert phase of own owners
-  if (small[0] * 2 > c->gs_cap && (rc = grow_global(c, cfg.g_s, c->gs_cap, pow2_at_least(small[0] * 2 + 2)))) return rc;
-  if (small[1] * 2 > c->gb_cap && (rc = grow_global(c, cfg.g_b, c->gb_cap, pow2_at_least(small[1] * 2 + 2)))) return rc;
-  if ((rc = d2d(c, c->d_small, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
-  LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
-  // ---- one all-gather: the applied items of every kind (padded to the largest rank's), the p-mer statistics, the triples
+  // ---- the all-gather's layout: the applied items of every kind (padded to the largest rank's), the p-mer statistics, the triples
   // (partitioned tables: no s-/b-mer items -- the look-ups read the owner's memory -- but the owners' occupancy counters)
   u64 M[3] = {0, 0, 0}, PM = 0;
   std::vector<u64> n_items(3ull * G, 0), pe_tot(G, 0);
@@ -1988,8 +2025,34 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   if (c->paired)
     for (u32 s = 0; s < T; ++s) { pe_tot[s % G] += C[3ull * T * T + s]; PM = std::max(PM, pe_tot[s % G]); }
   const u64 off_k[3] = {0, M[0], M[0] + M[1]}, off_siv = M[0] + M[1] + M[2], off_fill = off_siv + 2, off_pe = off_fill + FW, W = off_pe + 3 * PM;
-  if ((rc = xbuf_fit(c, c->d_items, c->items_cap, W))) return rc;
-  if ((rc = xbuf_fit(c, c->d_gathered, c->gathered_cap, W * G))) return rc;
+  // ---- allocations and growths of this phase, if any (every rank answers alike: see shard_vote), then the vote
+  const bool grow_s = small[0] * 2 > c->gs_cap, grow_b = small[1] * 2 > c->gb_cap;
+  // (tests: FQSX_TEST_FAIL="rank,phase" -- that rank reports a failed allocation in that phase, which every rank then treats as
+  // an allocating one: all of them must come back with an error, none may be left waiting in a collective)
+  int inj_rank = -1, inj_phase = -1;
+  if (const char *e = getenv("FQSX_TEST_FAIL")) (void)sscanf(e, "%d,%d", &inj_rank, &inj_phase);
+  const bool injected = inj_phase >= 0 && (u64)inj_phase == c->sh_phases;
+  if (injected || grow_s || grow_b || W > c->items_cap || W * G > c->gathered_cap || recv_need[0] > c->xrecv_cap[0] || recv_need[1] > c->xrecv_cap[1] ||
+      recv_need[2] > c->xrecv_cap[2]) {
+    int fail = 0;
+    if (injected && (u32)inj_rank == me) { fail = FQSX_E_NOMEM; g_err = "injected allocation failure (FQSX_TEST_FAIL)"; }
+    for (u32 k = 0; k < 3 && !fail; ++k) fail = xbuf_fit(c, c->d_xrecv[k], c->xrecv_cap[k], recv_need[k]);
+    if (!fail) fail = xbuf_fit(c, c->d_items, c->items_cap, W);
+    if (!fail) fail = xbuf_fit(c, c->d_gathered, c->gathered_cap, W * G);
+    // growth: every rank sees the same demand (the replicas are exact / the occupancies are exchanged); nobody looks a k-mer
+    // up between collective 1 and the end of the phase, so the tables can be rebuilt here as well as before the inserts
+    if (!fail && grow_s) fail = grow_global(c, cfg.g_s, c->gs_cap, pow2_at_least(small[0] * 2 + 2));
+    if (!fail && grow_b) fail = grow_global(c, cfg.g_b, c->gb_cap, pow2_at_least(small[1] * 2 + 2));
+    if (fail && c->part) fqsx_vm::mesh_close(c->mesh);   // (ranks waiting for this rank's descriptors fail instead of timing out)
+    if ((rc = shard_vote(c, fail, "the allocations / table growth of a phase"))) return rc;
+  }
+  for (u32 k = 0; k < 3; ++k) { send[k] = cfg.mail[k].sorted; recv[k] = c->d_xrecv[k]; }
+  COMMCHK(c->comm.alltoallv_u64(c->comm.ctx, 3, send, sc.data(), recv, rcnt.data()), "all-to-all of the mailboxes");   // collective 2
+  LAUNCH(c, 2, k_shard_merge3, 3 * T, 64, cfg, (const u64 *)c->d_xrecv[0], (const u64 *)c->d_xrecv[1], (const u64 *)c->d_xrecv[2], (const u32 *)c->d_cglob);
+  // ---- insert phase of own owners
+  if ((rc = d2d(c, c->d_small, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
+  LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
+  // ---- one all-gather
   for (u32 k = 0; k < 3; ++k)
     if (n_items[(u64)k * G + me]) LAUNCH(c, 2, k_shard_collect, REHASH_GRID, 256, cfg, k, c->d_items + off_k[k]);
   LAUNCH(c, 2, k_shard_siv_delta, 1, 64, cfg, (const u64 *)c->d_small, c->d_items + off_siv);
@@ -2011,7 +2074,10 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
     if ((rc = d2h_sync(c, c->h_filled.data(), cfg.g_pe.filled, T * sizeof(u32)))) return rc;
     u64 need = 0;
     for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_filled[o] + c->h_demand[o]);
-    if (need * 2 > c->gpe_cap && (rc = grow_gpe(c, pow2_at_least(need * 2 + 2)))) return rc;
+    if (need * 2 > c->gpe_cap) {   // (the replicas of the pair table are exact: every rank grows in the same phase, and votes on it)
+      const int fail = grow_gpe(c, pow2_at_least(need * 2 + 2));
+      if ((rc = shard_vote(c, fail, "the growth of the pair table"))) return rc;
+    }
     LAUNCH(c, 2, k_pe_insert, T, 64, cfg);
     if ((rc = dzero(c, cfg.l_pe.key, c->cur_need_lpe * T * sizeof(u64)))) return rc;
     if ((rc = dzero(c, cfg.l_pe.val, c->cur_need_lpe * T * sizeof(u64)))) return rc;
@@ -2041,6 +2107,9 @@ int tables_to_chunks(fqsx_dna *c) {
   VMCHK(fqsx_vm::granularity(c->device, &c->vm_gran, e_));
   if (c->vm_gran < sizeof(u64) || (c->vm_gran & (c->vm_gran - 1))) { g_err = "unexpected allocation granularity"; return FQSX_E_HIP; }
   c->part = true;
+  // sub-tables on other GPUs: the writers end with a system-scope release, the readers start behind a system-scope acquire
+  // (FQSX_SYS_SCOPE=1: the same fences in a world of one rank -- what they cost, measured on one GPU)
+  c->cfg.sys_scope = (c->shard_world > 1 || (getenv("FQSX_SYS_SCOPE") && atoi(getenv("FQSX_SYS_SCOPE")))) ? 1u : 0u;
   dfree(c, c->cfg.g_s.slots);
   dfree(c, c->cfg.g_b.slots);
   c->cfg.g_s.slots = c->cfg.g_b.slots = nullptr;
@@ -2077,6 +2146,47 @@ int fqsx_shard_partition_tables(fqsx_dna *c) {
 #endif
   const u32 G = c->shard_world, me = c->shard_rank;
   int rc;
+  c->part_fallback = false;
+#ifndef FQSX_EMU
+  // ---- can every GPU of the world load from every other one's memory?  The PCI bus ids are all-gathered (device ordinals are
+  // per process), every rank asks the runtime about its peers, and one all-reduced word makes the answer the same everywhere:
+  // if any pair cannot, ALL ranks keep table replicas (the mode fqsx_shard_attach leaves the codec in) -- slower to update,
+  // G times the table memory, same streams -- and say so.
+  if (G > 1) {
+    u64 mine[2] = {0, 0};
+    char bus[16] = {0};
+    HIPCHK(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), c->device));
+    memcpy(mine, bus, sizeof(mine));
+    std::vector<u64> all(2ull * G, 0);
+    if ((rc = xbuf_fit(c, c->d_items, c->items_cap, 2))) return rc;
+    if ((rc = xbuf_fit(c, c->d_gathered, c->gathered_cap, 2ull * G))) return rc;
+    if ((rc = h2d(c, c->d_items, mine, sizeof(mine)))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    COMMCHK(c->comm.allgather_u64(c->comm.ctx, c->d_items, 2, c->d_gathered), "all-gather of the ranks' PCI bus ids");
+    if ((rc = d2h_sync(c, all.data(), c->d_gathered, all.size() * sizeof(u64)))) return rc;
+    std::string why;
+    for (u32 q = 0; q < G && why.empty(); ++q) {
+      if (q == me) continue;
+      char pb[17] = {0};
+      memcpy(pb, &all[2ull * q], 16);
+      int pd = -1, can = 0;
+      if (hipDeviceGetByPCIBusId(&pd, pb) != hipSuccess) { (void)hipGetLastError(); why = std::string("the GPU of rank ") + std::to_string(q) + " (" + pb + ") is not visible to rank " + std::to_string(me); }
+      else if (pd != c->device && (hipDeviceCanAccessPeer(&can, c->device, pd) != hipSuccess || !can)) { (void)hipGetLastError(); why = std::string("rank ") + std::to_string(me) + " (" + bus + ") has no peer access to the GPU of rank " + std::to_string(q) + " (" + pb + ")"; }
+    }
+    u32 v = why.empty() ? 0u : 1u;
+    u32 *word = c->d_cglob;
+    if ((rc = h2d(c, word, &v, sizeof(v)))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    COMMCHK(c->comm.allreduce_sum_u32(c->comm.ctx, word, 1), "all-reduce of the peer-access check");
+    if ((rc = d2h_sync(c, &v, word, sizeof(v)))) return rc;
+    if (v) {
+      c->part_fallback = true;
+      g_err = "partitioned tables need peer access between all GPUs of the world: " + (why.empty() ? std::string("another rank cannot reach a peer") : why) +
+              "; every rank keeps table replicas instead (fqsx_shard_is_partitioned() == 0)";
+      return FQSX_OK;
+    }
+  }
+#endif
   // ---- the descriptor mesh: listen, exchange the names through the transport, connect
   VMCHK(fqsx_vm::mesh_listen(c->mesh, me, G, e_));
   std::vector<u64> words(G, 0);
@@ -2108,6 +2218,8 @@ int fqsx_shard_encode_block(fqsx_dna *c, const uint8_t *bases, const uint64_t *o
   return block_finish(c, h_off, streams, lens, nullptr);
 }
 
+int fqsx_shard_is_partitioned(fqsx_dna *c) { return c && c->part && !c->part_fallback ? 1 : 0; }
+
 int fqsx_shard_traffic(fqsx_dna *c, uint64_t out[4]) {
   if (!c || !out) return FQSX_E_ARG;
   out[0] = c->sh_phases; out[1] = c->sh_collectives; out[2] = c->sh_a2a_words; out[3] = c->sh_gather_words;
@@ -2122,6 +2234,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -2137,14 +2250,14 @@ bool rccl_load() {
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) { g_err = std::string("librccl not found: ") + dlerror(); return false; }
 #define RSYM(field, name) do { *(void **)&g_rccl.field = dlsym(h, name); if (!g_rccl.field) { g_err = std::string("librccl lacks ") + name; return false; } } while (0)
-  RSYM(GetUniqueId, "ncclGetUniqueId"); RSYM(CommInitRank, "ncclCommInitRank"); RSYM(CommDestroy, "ncclCommDestroy");
+  RSYM(GetUniqueId, "ncclGetUniqueId"); RSYM(CommInitRank, "ncclCommInitRank"); RSYM(CommDestroy, "ncclCommDestroy"); RSYM(CommAbort, "ncclCommAbort");
   RSYM(AllReduce, "ncclAllReduce"); RSYM(AllGather, "ncclAllGather"); RSYM(Send, "ncclSend"); RSYM(Recv, "ncclRecv");
   RSYM(GroupStart, "ncclGroupStart"); RSYM(GroupEnd, "ncclGroupEnd"); RSYM(GetErrorString, "ncclGetErrorString");
 #undef RSYM
   g_rccl.lib = h;
   return true;
 }
-struct RcclCtx { ncclComm_t comm; hipStream_t stream; u32 world; };
+struct RcclCtx { ncclComm_t comm; hipStream_t stream; u32 world; bool aborted; };
 #define NCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { g_err = std::string(#x) + ": " + g_rccl.GetErrorString(r_); return 1; } } while (0)
 int rccl_allreduce(void *ctx, uint32_t *buf, uint64_t n) {
   RcclCtx *x = (RcclCtx *)ctx;
@@ -2170,6 +2283,10 @@ int rccl_allgather(void *ctx, const uint64_t *send, uint64_t n, uint64_t *recv) 
   RcclCtx *x = (RcclCtx *)ctx;
   NCHK(g_rccl.AllGather(send, recv, n, ncclUint64, x->comm, x->stream));
   return 0;
+}
+void rccl_abort(void *ctx) {
+  RcclCtx *x = (RcclCtx *)ctx;
+  if (x && !x->aborted) { x->aborted = true; (void)g_rccl.CommAbort(x->comm); }
 }
 }  // namespace
 #endif
@@ -2199,12 +2316,14 @@ int fqsx_rccl_comm_create(fqsx_dna *c, const uint8_t id[128], uint32_t rank, uin
   RcclCtx *x = new RcclCtx();
   x->stream = c->stream;
   x->world = world;
+  x->aborted = false;
   ncclResult_t r = g_rccl.CommInitRank(&x->comm, (int)world, u, (int)rank);
   if (r != ncclSuccess) { g_err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); delete x; return FQSX_E_HIP; }
   out->ctx = x;
   out->allreduce_sum_u32 = rccl_allreduce;
   out->alltoallv_u64 = rccl_alltoallv;
   out->allgather_u64 = rccl_allgather;
+  out->abort = rccl_abort;
   return FQSX_OK;
 #else
   (void)c; (void)id; (void)rank; (void)world; (void)out;
@@ -2216,7 +2335,7 @@ void fqsx_rccl_comm_destroy(fqsx_comm *m) {
 #ifndef FQSX_EMU
   if (!m || !m->ctx) return;
   RcclCtx *x = (RcclCtx *)m->ctx;
-  if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(x->comm);
+  if (g_rccl.CommDestroy && !x->aborted) (void)g_rccl.CommDestroy(x->comm);
   delete x;
   m->ctx = nullptr;
 #else

@@ -5,6 +5,7 @@
 // (one wave per workgroup: no roles to separate, the body is inlined into the kernel, which gets the whole register file)
 template <int MODE> FQ_DEV void decode_kernel_body(const EncArgs &a) {
   if (a.cfg.err[0]) return;   // (one wave per workgroup: the test is the workgroup's) a device error stops the block's remaining launches
+  if (a.cfg.sys_scope) fq_acquire_system();   // partitioned tables: see wg_handoff_init
   encode_segment_body<MODE, true, false>(a.cfg, fq_wg(), FQ_BLOCK, a.n_reads, a.S, a.seg, a.pad);
 }
 

@@ -195,6 +195,10 @@ struct DevCfg {
   // Sharded mode: worker w -- its coder state, RNG streams, local tables and the sub-tables it owns --
   // lives on rank w % shard_world; every rank holds a read-only replica of all sub-tables.  shard_world == 1: one GPU.
   u32 shard_rank, shard_world;
+  u32 sys_scope;               // the s- / b-mer tables are partitioned over more than one rank: sub-tables of other GPUs are read
+                               // through peer mappings, so the kernels that write own sub-tables end with a system-scope release and
+                               // the kernels that look k-mers up start behind a system-scope acquire (fqsx_plat.h)
+  u32 pad_sys_;
   const u8 *vmap;              // [256] owner -> position of its group in the partitioned mailbox: identity, or rank-major
                                // (all owners of rank 0, then rank 1, ...) so that what goes to one rank is contiguous
   u32 *shard_cnt;              // [3][T][T] entries source s pushed for owner o in this phase (own sources; else 0)

@@ -69,6 +69,14 @@ FQ_DEV bool spin_expired(u32 &spins) {
   spins = first << 12;
   return (u32)((now - first) & 0xfffffu) > FQSX_WAIT_LIMIT_S * 95u;
 }
+// System-scope fences of the partitioned sharded mode (DevCfg.sys_scope): an owner's table writes have to reach its HBM
+// before another GPU loads them over xGMI, and a reader must not serve such a load from a line of the other GPU's memory
+// it cached in an earlier launch.  Per-XCD L2s are write-back and not coherent with anything outside their XCD
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): release = buffer_wbl2 sc0 sc1 +
+// s_waitcnt vmcnt(0) (writes the XCD L2's dirty lines back), acquire = buffer_inv sc0 sc1 (drops the CU's L1 and the
+// non-local lines of the XCD's L2).  Once per wave / workgroup and launch, never per element.
+FQ_DEV void fq_release_system() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
+FQ_DEV void fq_acquire_system() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); }
 FQ_DEV void atomic_add64(u64 *p, u64 v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
 FQ_DEV u32 atomic_add32(u32 *p, u32 v) { return atomicAdd(p, v); }   // returns the old value
 
@@ -148,6 +156,8 @@ FQ_DEV double ema_update(double avg, double level) { return __dadd_rn(__dmul_rn(
 FQ_DEV u32 lds_load_acq(const u32 *p) { return *p; }
 FQ_DEV void lds_store_rel(u32 *p, u32 v) { *p = v; }
 FQ_DEV void fq_sleep() {}
+FQ_DEV void fq_release_system() {}
+FQ_DEV void fq_acquire_system() {}
 FQ_DEV bool spin_expired(u32 &spins) { return ++spins > (1u << 20); }
 FQ_DEV void atomic_add64(u64 *p, u64 v) { *p += v; }
 FQ_DEV u32 atomic_add32(u32 *p, u32 v) { const u32 o = *p; *p = o + v; return o; }

@@ -63,6 +63,9 @@ FQ_DEV bool wg_handoff_init(const EncArgs &a, bool honour_posted) {
     for (u32 x = 1; x <= FQSX_SCR; ++x) sm->sb[x].h_pub = 0;
     sm->rq_tail = 0; sm->rq_head = 0; sm->rq_done = 0;
   }
+  // partitioned tables: other GPUs' sub-tables have changed since this CU / XCD last cached lines of them (one wave's
+  // acquire serves the workgroup: every wave's loads go through the same L1 and L2, and all of them wait at the barrier)
+  if (a.cfg.sys_scope && FQ_WAVE_ID == 0) fq_acquire_system();
   FQ_WG_BARRIER();
   return sm->wg_stop != 0;
 }

@@ -37,6 +37,9 @@ from .codec import DnaCodec, FqsxError
 class ShardedDnaCodec:
     def __init__(self, header: bytes, rank: int, world: int, device: int = 0, lib_path: Optional[str] = None,
                  tensor_device: Optional[torch.device] = None, group=None, apply_own: bool = False):
+        if header[5] >= 2 and world > 1:   # dna_mode 2 / 3 (the library refuses the same in fqsx_shard_begin_block)
+            raise ValueError("the step-wise sharded driver does not exchange the pair-table triples: shard a paired-end file with "
+                             "NativeShardedDnaCodec (fqsx_shard_attach + fqsx_shard_encode_block)")
         self.codec = DnaCodec(header, device=device, lib_path=lib_path)
         self._lib, self._h, self.T = self.codec._lib, self.codec._h, self.codec.T
         self.rank, self.world, self.group = rank, world, group
@@ -149,7 +152,8 @@ class _Comm(C.Structure):
     _AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
     _A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64))
     _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
-    _fields_ = [("ctx", C.c_void_p), ("allreduce_sum_u32", _AR), ("alltoallv_u64", _A2A), ("allgather_u64", _AG)]
+    _AB = C.CFUNCTYPE(None, C.c_void_p)
+    _fields_ = [("ctx", C.c_void_p), ("allreduce_sum_u32", _AR), ("alltoallv_u64", _A2A), ("allgather_u64", _AG), ("abort", _AB)]
 
 
 def _host_tensor(addr: int, n: int, ctype, dtype) -> torch.Tensor:
@@ -278,10 +282,18 @@ class NativeShardedDnaCodec:
         else:
             self._comm = comm if comm is not None else _torch_comm(world, group)
         self._ck(L.fqsx_shard_attach(self._h, rank, world, C.byref(self._comm)), "fqsx_shard_attach")
-        self.partitioned = partition
+        self.partitioned = False
+        self.partition_note = ""
         if partition:   # (collective) each rank keeps 1/world of the k-mer tables and maps the rest from its peers
             L.fqsx_shard_partition_tables.argtypes = [C.c_void_p]
+            L.fqsx_shard_is_partitioned.argtypes = [C.c_void_p]
             self._ck(L.fqsx_shard_partition_tables(self._h), "fqsx_shard_partition_tables")
+            self.partitioned = bool(L.fqsx_shard_is_partitioned(self._h))
+            if not self.partitioned:   # GPUs without peer access: the whole world stays with replicas (same streams)
+                self.partition_note = self._lib.fqsx_last_error().decode()
+                if rank == 0:
+                    import warnings
+                    warnings.warn("fqsx: " + self.partition_note)
         self.own_workers = list(range(rank, self.T, world))
         self._streams = (C.c_void_p * self.T)()
         self._lens = (C.c_uint64 * self.T)()

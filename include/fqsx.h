@@ -44,6 +44,9 @@ typedef struct fqsx_comm {
                        uint64_t *const *recv, const uint64_t *recv_counts);
   /* every rank contributes n 64-bit words; recv = [world][n] */
   int (*allgather_u64)(void *ctx, const uint64_t *send, uint64_t n, uint64_t *recv);
+  /* optional (may be null): give the transport up after a failed collective, so that this rank's part of whatever is still
+   * pending does not keep the other ranks waiting (RCCL: ncclCommAbort) */
+  void (*abort)(void *ctx);
 } fqsx_comm;
 
 enum {
@@ -52,7 +55,8 @@ enum {
   FQSX_E_NO_DEVICE = -2,  /* no HIP device (the library has no CPU fallback) */
   FQSX_E_HIP = -3,        /* HIP runtime error, see fqsx_last_error() */
   FQSX_E_NOMEM = -4,      /* device allocation failed */
-  FQSX_E_DEVICE = -5      /* device-side error word set (table/stream overflow) */
+  FQSX_E_DEVICE = -5,     /* device-side error word set (table/stream overflow) */
+  FQSX_E_PEER = -6        /* sharded mode: another rank of the world failed; every rank has left the phase (this one was fine) */
 };
 
 /* header17: the 17 parameter bytes of the .fqs file being written
@@ -120,12 +124,16 @@ int fqsx_dna_use_chunked_tables(fqsx_dna *);
 
 /* Sharded mode (reference: the T x T mailboxes of fqs/application.h:56-59 and their owner-side
  * application, fqs/dna.cpp:825-847, :2393-2472): logical worker w -- coder state, RNG streams, local tables and the
- * sub-tables it owns -- lives on rank w % world; every rank keeps a replica of all sub-tables for the look-ups.
- * One synchronisation phase = encode -> [all-reduce of the per-(source, owner) counts] -> pack -> [all-to-all of the three
- * mailboxes] -> merge -> [all-reduce(max) of the table demand] -> insert -> [all-gather of the applied items] -> apply ->
- * [all-reduce of the p-mer statistics] -> end_phase; the bracketed collectives are the caller's (RCCL over xGMI through
- * torch.distributed in fqsqueezer_amd/sharded.py).  The streams are bit-identical to the one-GPU run's.
- * Pointers marked [codec] are in the codec's memory space (device memory). */
+ * sub-tables it owns -- lives on rank w % world; every rank keeps a replica of all sub-tables for the look-ups (or maps the
+ * other ranks' sub-tables: fqsx_shard_partition_tables below).  The product path is the phase loop inside the library
+ * (fqsx_shard_attach + fqsx_shard_encode_block, further down).
+ * The step-wise form below is the round-2 bring-up driver, kept for single-end worlds and for callers that want to run the
+ * collectives themselves: one synchronisation phase = encode -> [all-reduce of the per-(source, owner) counts] -> pack ->
+ * [all-to-all of the three mailboxes] -> merge -> [all-reduce(max) of the two demand words fqsx_shard_merge returns] -> insert
+ * -> [all-gather of the applied items] -> apply -> [all-reduce of the p-mer statistics] -> end_phase; the bracketed collectives
+ * are the caller's (fqsqueezer_amd/sharded.py: ShardedDnaCodec over torch.distributed).  It does not exchange the pair-table
+ * triples: fqsx_shard_begin_block refuses a paired-end codec in a world of more than one rank (FQSX_E_ARG).
+ * The streams are bit-identical to the one-GPU run's.  Pointers marked [codec] are in the codec's memory space (device memory). */
 int fqsx_shard_config(fqsx_dna *, uint32_t rank, uint32_t world);
 int fqsx_shard_begin_block(fqsx_dna *, const uint8_t *bases /*[codec]*/, const uint64_t *read_off /*[codec]*/, const uint64_t *h_read_off,
                            uint32_t n_reads, uint32_t generation, uint32_t *n_segments);
@@ -157,8 +165,15 @@ int fqsx_shard_traffic(fqsx_dna *, uint64_t out[4]);
  * (insert phase); the phase's collectives order them before the next look-ups.  The all-gather of a phase then carries no
  * k-mer items, only the owners' occupancy counters, the p-mer items and statistics and the paired-end triples (the p-mer
  * vector and the pair table stay replicated).  Streams are bit-identical to the one-GPU run's.
+ * Memory order: the kernels that write own sub-tables (insert phase, growth) end with a system-scope release and the encode /
+ * decode kernels start behind a system-scope acquire (csrc/fqsx_plat.h), so that an owner's writes are in its HBM before the
+ * phase's last collective and no GPU serves a foreign look-up from a line it cached in an earlier launch.
+ * Peer access: the ranks all-gather their GPUs' PCI bus ids and ask hipDeviceCanAccessPeer; if any pair of the world cannot
+ * reach each other ALL ranks stay with table replicas -- the call still returns FQSX_OK, fqsx_last_error() says why and
+ * fqsx_shard_is_partitioned() returns 0.
  * fqsx_dna_capacity()[13] = bytes of k-mer table memory this rank holds. */
 int fqsx_shard_partition_tables(fqsx_dna *);
+int fqsx_shard_is_partitioned(fqsx_dna *);
 /* RCCL transport on the codec's own stream (collectives and kernels are ordered by the stream; librccl is loaded on first
  * use).  Rank 0 calls fqsx_rccl_unique_id and hands the 128 bytes to the other ranks by any means (a file, a TCP store). */
 int fqsx_rccl_unique_id(uint8_t id[128]);

@@ -262,7 +262,8 @@ def test_native_sharded_driver_on_the_gpu_over_rccl():
             mine, ref = sh.encode_block(bases, off, g), one.encode_block(bases, off, g)
             assert [mine[w] for w in range(16)] == ref, f"block {g}"
         tr = sh.traffic
-        assert tr["phases"] >= 60 and tr["collectives"] == 3 * tr["phases"]
+        votes = tr["collectives"] - 3 * tr["phases"]   # (one status vote per phase in which buffers or tables grow)
+        assert tr["phases"] >= 60 and 0 <= votes <= tr["phases"] // 2, tr
         sh.close()
         rec1, rec2 = c5_records()
         header = hp.make_header(8, "pe_sorted", 1)
