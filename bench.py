@@ -9,8 +9,14 @@ DNA path over the whole file: fresh codec state, every reads block encoded in fi
 per-worker range-coder streams copied back to the host.  Inputs (base bytes + read offsets of
 every block) are resident in HBM before the timed region starts.
 
-N > 1 (torch.distributed.run): every rank compresses its own independent file (seed 2+rank)
-on its own GPU -- weak scaling, no data-path collective (see DESIGN.md "Multi-GPU").
+N > 1 (torch.distributed.run, one rank per GPU): ONE file sharded over the N GPUs with partitioned k-mer tables -- the layout
+BASELINE.json's north_star and configs[3] name: logical worker w lives on rank w % N, the mailboxes travel in one RCCL
+all-to-all per synchronisation phase, every rank holds 1/N of the s-/b-mer tables and reads the rest over xGMI through peer
+mappings (fqsx_shard_attach + fqsx_shard_partition_tables + fqsx_shard_encode_block).  Strong scaling: `value` = the file's
+bases / wall time.  The file is configs[3]-shaped (150 bp SE sorted at the reference's default geometry -gs 3100, k = 13/18/21/27,
+16 GiB p-mer vector per rank): 2 M reads of a 50 Mbp genome unless --reads / --genome say otherwise.  `--replicas` gives the
+other multi-GPU mode instead (N independent files, one per GPU, no collective: weak scaling); its rate also rides along in
+the sharded line as `replicas`.
 
 Prints ONE JSON line (rank 0).
 """
@@ -46,10 +52,10 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=1_000_000)
+    ap.add_argument("--reads", type=int, default=None, help="default: 1 M (one GPU / replicas), 2 M (one file sharded over N > 1 GPUs)")
     ap.add_argument("--len", type=int, default=150)
-    ap.add_argument("--genome", type=int, default=7_500_000)
-    ap.add_argument("--gs", type=int, default=8)
+    ap.add_argument("--genome", type=int, default=None, help="default: 7.5 Mbp (one GPU / replicas), 50 Mbp (sharded)")
+    ap.add_argument("--gs", type=int, default=None, help="default: 8 (one GPU / replicas), 3100 = the reference's default geometry (sharded)")
     ap.add_argument("--threads", type=int, default=64, help="logical workers T (header byte, <=255)")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -63,13 +69,29 @@ def main() -> None:
                     help="with --sharded: the k-mer tables partitioned over the ranks (each GPU holds 1/N of them, look-ups of the "
                          "rest over xGMI through peer mappings; fqsx_shard_partition_tables) instead of a replica on every rank")
     ap.add_argument("--sharded", action="store_true",
-                    help="ONE file sharded over the N GPUs (workers w %% N on rank w, RCCL all-to-all of the mailboxes, "
-                         "replica refresh; fqsqueezer_amd/sharded.py) instead of N independent files: strong scaling")
+                    help="ONE file sharded over the N GPUs (workers w %% N on rank w, RCCL all-to-all of the mailboxes; "
+                         "fqsqueezer_amd/sharded.py): strong scaling.  The default for N > 1, with --partition")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: N independent files, one per GPU (weak scaling) instead of one sharded file")
+    ap.add_argument("--no-partition", action="store_true", help="sharded: table replicas on every rank instead of partitioned tables")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not a.replicas:   # the driver's `--gpus N` line: the north star's layout
+        a.sharded = True
+        a.partition = not a.no_partition
+    if a.sharded and world > 1:
+        a.reads = a.reads or 2_000_000; a.genome = a.genome or 50_000_000; a.gs = a.gs or 3100
+    else:
+        a.reads = a.reads or 1_000_000; a.genome = a.genome or 7_500_000; a.gs = a.gs or 8
+    emu = os.environ.get("FQSX_BENCH_EMU")   # tests only: the launcher path of the sharded line on CPUs (gloo + the emulated kernels)
+    if emu:
+        if not a.sharded:
+            raise SystemExit("FQSX_BENCH_EMU only rehearses the sharded multi-rank line (tests/test_multirank_cpu.py)")
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        return sharded_main(a, rank, local_rank, world, emu_lib=emu)
 
     import torch
     import torch.distributed as dist
@@ -298,7 +320,7 @@ def main() -> None:
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2+rank), -om s -gs {a.gs} -qm n -im n",
-                   "workers_T": a.threads, "blocks": len(blocks), "per_gpu": "one independent file per GPU"},
+                   "workers_T": a.threads, "blocks": len(blocks), "per_gpu": "one independent file per GPU" + (" (--replicas)" if world > 1 else "")},
         "bits_per_base": round(8.0 * dna_bytes / n_bases, 5), "steady_state": steady, "pcie_inclusive_mbases_s": pcie, "workers_255": t255, "concurrent_files": conc,
         "capacity": cap_line, "other_rows": rows, "roofline": roofline, "cpu_baseline": cpu,
     }
@@ -308,65 +330,153 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def sharded_main(a, rank, local_rank, world):
-    """--sharded: ONE file (seed 2) over the N GPUs, strong scaling: workers w % N on rank w, per-phase RCCL all-to-all
-    of the mailboxes + replica refresh (fqsqueezer_amd/sharded.py).  The blocks are handed over as host buffers (the
-    sharded entry point uploads them), so `value` includes that copy.  Streams are bit-identical to the one-GPU run's."""
+def sharded_main(a, rank, local_rank, world, emu_lib=None):
+    """ONE file (seed 2) over the N GPUs, strong scaling: logical worker w on rank w % N, per synchronisation phase an all-reduce of
+    the count matrix, the three mailboxes in one grouped all-to-all and one all-gather (RCCL on the codec's stream, inside
+    libfqsx.so: fqsx_shard_encode_block); with --partition (the default for N > 1) every rank holds 1/N of the k-mer tables and
+    reads the rest through peer mappings.  The blocks are resident in HBM on every rank before the timed region.  Streams are
+    bit-identical to the one-GPU run's (tests/test_sharded_cpu.py, tests/test_gpu_sharded.py).  emu_lib: tests only (see main)."""
     import torch
     import torch.distributed as dist
     from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.codec import DnaCodec
     from fqsqueezer_amd.sharded import NativeShardedDnaCodec
     from fqsqueezer_amd.synth import read_id, synth_reads
+    gpu = emu_lib is None
     reads = synth_reads(a.reads, a.len, a.genome, 2)
     rec = hp.Records([read_id(i) for i in range(a.reads)], reads, reads)
     header = hp.make_header(a.threads, "se_sorted", a.gs)
-    dev_blocks = []   # the blocks resident in HBM before the timed region, as in the unsharded bench
-    for idx in hp.form_blocks(rec, "se_sorted"):
+    groups = None
+    if gpu and a.reads > 2_000_000:   # large files: the sorted order from the GPU pre-pass (fqsx_sort_order)
+        from fqsqueezer_amd.codec import sort_order
+        groups = sort_order(reads.reshape(-1), np.arange(a.reads + 1, dtype=np.uint64) * np.uint64(a.len), device=local_rank)
+    dev_blocks = []   # the blocks resident in the codec's memory space (HBM) before the timed region, as in the unsharded bench
+    for idx in hp.form_blocks(rec, "se_sorted", groups=groups):
         bases, off = hp.block_arrays(rec, idx)
-        dev_blocks.append((torch.from_numpy(np.ascontiguousarray(bases)).cuda(), torch.from_numpy(off.view(np.int64)).cuda(), off))
+        t_b, t_o = torch.from_numpy(np.ascontiguousarray(bases)), torch.from_numpy(off.view(np.int64))
+        dev_blocks.append((t_b.cuda(), t_o.cuda(), off) if gpu else (t_b, t_o, off))
     n_bases = int(a.reads) * int(a.len)
-    traffic = {}
+    traffic, cap, info = {}, {}, {}
+    comm = [None]   # the process's RCCL communicator: made with the first codec, rebound to every later one (ncclCommInitRank takes seconds)
 
-    def one_step():
-        # native driver: the phase loop, RCCL calls included, inside libfqsx.so (fqsx_shard_encode_block); the RCCL id travels
-        # through torch.distributed's object broadcast
-        ids = [NativeShardedDnaCodec.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        c = NativeShardedDnaCodec(header, rank, world, device=local_rank, transport="rccl", id_bytes=ids[0], partition=a.partition)
+    def sync():
+        dist.barrier()
+        if gpu:
+            torch.cuda.synchronize()
+
+    def one_step(profile=False):
+        if not gpu:
+            c = NativeShardedDnaCodec(header, rank, world, lib_path=emu_lib, transport="torch", partition=a.partition)
+        elif comm[0] is None:
+            ids = [NativeShardedDnaCodec.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            c = NativeShardedDnaCodec(header, rank, world, device=local_rank, transport="rccl", id_bytes=ids[0], partition=a.partition)
+            comm[0] = c.detach_comm()
+            info.update(c.rccl_info())
+        else:
+            c = NativeShardedDnaCodec(header, rank, world, device=local_rank, transport="rccl", comm=comm[0], partition=a.partition)
+        if profile:
+            c.codec.set_profiling(True)
         nb = 0
         for g, (d_b, d_o, off) in enumerate(dev_blocks):
             nb += c.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g)
         traffic.update(c.traffic)
-        traffic["table_bytes_held_rank0"] = c.codec.capacity()["table_bytes_held"]
+        cap.update(c.codec.capacity())
+        info["partitioned"] = bool(c.partitioned)
+        info["partition_note"] = c.partition_note
+        res = (nb, c.codec.stats() if profile else None, c.codec.kernel_times() if profile else None)
         c.close()
-        return nb
+        return res
 
     for _ in range(a.warmup):
         one_step()
-    dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     mine = 0
     for _ in range(a.steps):
-        mine = one_step()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        mine, _, _ = one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    dd = "cuda" if gpu else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dd)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    tot = torch.tensor([mine], dtype=torch.int64, device="cuda")
+    elapsed = float(t.item())
+    tot = torch.tensor([mine], dtype=torch.int64, device=dd)
     dist.all_reduce(tot)
+    held = [None] * world
+    dist.all_gather_object(held, {"rank": rank, "table_bytes_held": int(cap.get("table_bytes_held", 0)), "device_bytes_peak": int(cap.get("device_bytes_peak", 0)),
+                                  "ranks_seen": info.get("ranks_seen")})
+    value = n_bases * a.steps / elapsed / 1e6
+
+    # ---- kernel-level pass (HIP events around every launch of this rank's stream; untimed): the dominant kernel's roofline on rank 0
+    roofline = None
+    if gpu:
+        _, st, kt = one_step(profile=True)
+        sync()
+        if rank == 0:
+            alg = algorithmic_bytes(st)
+            ins_bytes = 28.0 * st["gins"] + 4.0 * st["gins_slot"]
+            enc_s = kt["encode_ms"] / 1e3
+            read_bytes = alg - ins_bytes - 8.0 * st.get("siv_saved", 0)
+            roofline = {"bound": "hbm", "achieved": round((alg - ins_bytes) / max(enc_s, 1e-9) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round((alg - ins_bytes) / max(enc_s, 1e-9) / 1e9 / 8000.0, 6), "traffic": None, "kernel": "k_encode_se_sorted",
+                        "launches": kt["encode_launches"], "avg_launch_ms": round(kt["encode_ms"] / max(1, kt["encode_launches"]), 4),
+                        "algorithmic_bytes_per_launch": round((alg - ins_bytes) / max(1, kt["encode_launches"]), 1),
+                        "frac_of_bytes_the_kernel_reads": round(read_bytes / max(enc_s, 1e-9) / 1e9 / 8000.0, 6),
+                        "note": f"rank 0's launches only: its {len(range(0, a.threads, world))} of the {a.threads} workers (one workgroup each), SURVEY 8d bytes of "
+                                "those workers / rank 0's encode-kernel time (HIP events on the codec's stream); look-ups of the other ranks' "
+                                "sub-tables are xGMI loads, not HBM reads of this GPU"}
+
+    # ---- the other multi-GPU mode beside it: N independent 1 M-read files, one per GPU (weak scaling, no collective)
+    replicas = None
+    if gpu and world > 1:
+        r_reads = synth_reads(1_000_000, a.len, 7_500_000, 2 + rank)
+        r_rec = hp.Records([read_id(i) for i in range(len(r_reads))], r_reads, r_reads)
+        r_header = hp.make_header(a.threads, "se_sorted", 8)
+        r_blocks = []
+        for idx in hp.form_blocks(r_rec, "se_sorted"):
+            bases, off = hp.block_arrays(r_rec, idx)
+            r_blocks.append((torch.from_numpy(np.ascontiguousarray(bases)).cuda(), torch.from_numpy(off.view(np.int64)).cuda(), off))
+
+        def r_step():
+            c = DnaCodec(r_header, device=local_rank)
+            for g, (d_b, d_o, off) in enumerate(r_blocks):
+                c.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g, collect=False)
+            c.close()
+
+        r_step()
+        sync()
+        t1 = time.perf_counter()
+        r_step()
+        sync()
+        tr = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        replicas = {"value": round(world * 150.0 / float(tr.item()), 4), "unit": "Mbases/s", "scaling": "weak",
+                    "workload": "1000000x150bp SE, G=7500000 (seed 2+rank), -om s -gs 8, one independent file per GPU, no data-path collective; one timed pass"}
+
     if rank == 0:
-        elapsed = float(t.item())
-        print(json.dumps({
-            "metric": "Mbases/s compressed (DNA stream, SE sorted)", "value": round(n_bases * a.steps / elapsed / 1e6, 4), "unit": "Mbases/s",
+        line = {
+            "metric": "Mbases/s compressed (DNA stream, SE sorted)", "value": round(value, 4), "unit": "Mbases/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2), -om s -gs {a.gs} -qm n -im n", "workers_T": a.threads,
-                       "blocks": len(dev_blocks), "per_gpu": f"one file sharded over {world} GPU(s): workers w % {world}, RCCL all-to-all of the mailboxes per phase"
-                                  + (", k-mer tables partitioned over the ranks (peer-mapped look-ups)" if a.partition else ", table replicas on every rank")},
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic" if gpu else "synthetic (EMULATION BUILD on CPUs: a test of the launcher path, not a measurement)",
+            "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2), -om s -gs {a.gs} -qm n -im n: ONE file sharded over {world} GPU(s)",
+                       "workers_T": a.threads, "blocks": len(dev_blocks),
+                       "per_gpu": f"workers w % {world} == rank ({len(range(0, a.threads, world))} workgroups on rank 0); per phase: all-reduce of the count matrix, "
+                                  "one grouped all-to-all of the three mailboxes, one all-gather (RCCL over xGMI, inside libfqsx.so)"
+                                  + ("; s-/b-mer tables partitioned over the ranks (1/N each, the rest read through peer mappings)" if info.get("partitioned")
+                                     else "; table replicas on every rank" + (" (asked for partitioned tables: " + info.get("partition_note", "") + ")" if a.partition else ""))},
             "bits_per_base": round(8.0 * int(tot.item()) / n_bases, 5),
-            "exchange_rank0_per_file": traffic, "roofline": None, "cpu_baseline": None}), flush=True)
+            "partitioned_tables": bool(info.get("partitioned")), "ranks_seen": info.get("ranks_seen"),
+            "per_rank": held, "exchange_rank0_per_file": traffic, "replicas": replicas,
+            "roofline": roofline, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
     dist.barrier()
+    if gpu and comm[0] is not None:
+        from fqsqueezer_amd.sharded import _Comm  # noqa: F401
+        import ctypes as C
+        from fqsqueezer_amd.codec import load_library
+        load_library().fqsx_rccl_comm_destroy(C.byref(comm[0]))
     dist.destroy_process_group()
 
 

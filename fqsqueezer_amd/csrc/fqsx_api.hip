@@ -2235,6 +2235,8 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -2250,7 +2252,7 @@ bool rccl_load() {
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) { g_err = std::string("librccl not found: ") + dlerror(); return false; }
 #define RSYM(field, name) do { *(void **)&g_rccl.field = dlsym(h, name); if (!g_rccl.field) { g_err = std::string("librccl lacks ") + name; return false; } } while (0)
-  RSYM(GetUniqueId, "ncclGetUniqueId"); RSYM(CommInitRank, "ncclCommInitRank"); RSYM(CommDestroy, "ncclCommDestroy"); RSYM(CommAbort, "ncclCommAbort");
+  RSYM(GetUniqueId, "ncclGetUniqueId"); RSYM(CommInitRank, "ncclCommInitRank"); RSYM(CommDestroy, "ncclCommDestroy"); RSYM(CommAbort, "ncclCommAbort"); RSYM(CommCount, "ncclCommCount"); RSYM(CommUserRank, "ncclCommUserRank");
   RSYM(AllReduce, "ncclAllReduce"); RSYM(AllGather, "ncclAllGather"); RSYM(Send, "ncclSend"); RSYM(Recv, "ncclRecv");
   RSYM(GroupStart, "ncclGroupStart"); RSYM(GroupEnd, "ncclGroupEnd"); RSYM(GetErrorString, "ncclGetErrorString");
 #undef RSYM
@@ -2327,6 +2329,34 @@ int fqsx_rccl_comm_create(fqsx_dna *c, const uint8_t id[128], uint32_t rank, uin
   return FQSX_OK;
 #else
   (void)c; (void)id; (void)rank; (void)world; (void)out;
+  g_err = "the emulation build has no RCCL transport";
+  return FQSX_E_NO_DEVICE;
+#endif
+}
+// the communicator of one codec for the next one (a file per codec, one communicator per process: ncclCommInitRank takes
+// seconds): from now on the collectives run on `c`'s stream
+int fqsx_rccl_comm_rebind(fqsx_comm *m, fqsx_dna *c) {
+#ifndef FQSX_EMU
+  if (!m || !m->ctx || !c) { g_err = "bad argument"; return FQSX_E_ARG; }
+  ((RcclCtx *)m->ctx)->stream = c->stream;
+  return FQSX_OK;
+#else
+  (void)m; (void)c;
+  g_err = "the emulation build has no RCCL transport";
+  return FQSX_E_NO_DEVICE;
+#endif
+}
+// out[0] = ranks of the communicator as RCCL counts them, out[1] = this process's rank in it
+int fqsx_rccl_comm_info(fqsx_comm *m, uint32_t out[2]) {
+#ifndef FQSX_EMU
+  if (!m || !m->ctx || !out) { g_err = "bad argument"; return FQSX_E_ARG; }
+  RcclCtx *x = (RcclCtx *)m->ctx;
+  int n = 0, r = 0;
+  if (g_rccl.CommCount(x->comm, &n) != ncclSuccess || g_rccl.CommUserRank(x->comm, &r) != ncclSuccess) { g_err = "ncclCommCount / ncclCommUserRank failed"; return FQSX_E_HIP; }
+  out[0] = (u32)n; out[1] = (u32)r;
+  return FQSX_OK;
+#else
+  (void)m; (void)out;
   g_err = "the emulation build has no RCCL transport";
   return FQSX_E_NO_DEVICE;
 #endif

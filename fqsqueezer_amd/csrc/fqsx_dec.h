@@ -13,6 +13,7 @@
 // lane (read-only: the table cannot change in between, the wave is the worker's only writer), and the level search then
 // walks the cached answers.  Same decisions, same stores, same creations / clones as find_leveled.
 FQ_DEV u32 dec_level_get(WgShared *sm, u32 l, Slot4 &s, const u64 *lev, u64 rs) {
+  const u32 ls = 1;   // (the decoder's level keys are a plain array: LEVKEY)
   const u32 idx = sm->fr_idx[l];
   if (idx == FQSX_NIL) return FQSX_NIL;
   s.q0 = LEVKEY(l); s.q1 = sm->fr_q1[l]; s.q2 = sm->fr_q2[l]; s.q3 = sm->fr_q3[l];
@@ -20,6 +21,7 @@ FQ_DEV u32 dec_level_get(WgShared *sm, u32 l, Slot4 &s, const u64 *lev, u64 rs) 
 }
 FQ_DEV u32 find_leveled_dec(Wk &w, u32 tag, const u64 *lev, u64 rs, int n_levels, double &avg, u64 tpl_q2, u64 tpl_q3, u32 tpl_total, Slot4 &s) {
   WgShared *sm = w.sm;
+  const u32 ls = 1;
   FQ_SYNC();
   for (u32 l = FQ_LANE; l < (u32)n_levels; l += FQ_WAVE) {
     u32 vis = 0;

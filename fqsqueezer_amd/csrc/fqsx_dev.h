@@ -26,7 +26,9 @@ struct SpecBuf {
   u64 sp_sdir[6][FQSX_SPEC];   // rolled k-mers after insert_zero: pm, sm, bm, pm_u, sm_u, bm_u
   u64 sp_src[6][FQSX_SPEC];
   u8 sp_scur[6][FQSX_SPEC];
-  u64 sp_key[FQSX_SPEC][10];   // context keys of the position's symbol: 7 code levels (r_sym field left 0) or 10 letter levels
+  u64 sp_key[10][FQSX_SPEC];   // context keys of the position's symbol: 7 code levels (r_sym field left 0) or 10 letter levels; level-major,
+                               // so that the lanes of a wave (one position each) touch consecutive 8-byte words: [position][level] rows of
+                               // 80 bytes put 64 lanes on 16 LDS banks (4-way conflicts on every key store, copy and load)
   u8 sp_kind[FQSX_SPEC];       // how the position's symbol is coded: SK_* (set by stage P for settled positions, else by stage C)
   u64 sp_cq[FQSX_SPEC];        // SK_RANK_PENDING: the four counts, 16 bits each
   u8 sp_lvz[FQSX_SPEC];        // SK_RANK_PENDING: level | cor_zone << 4
@@ -73,12 +75,14 @@ struct HeadRec {
   u32 kcur[3];
 };
 struct WgShared {
-  HeadRec hd[2];
+  HeadRec hd[FQSX_HD];         // (round 4: three -- with two, the wave that resolves the reads waited a quarter of its time for the first
+                               // chunk of the next read: the read head could only start a read once the read before the previous one was
+                               // finished, and the scouts' stage P of the read's first chunk starts behind the head)
   u32 hd_ready, hd_taken;      // read heads finished / consumed (free-running counts within the launch)
   u32 hd_early;                // read heads whose part for the scout waves (codes, k-mers after the prefix) is in place
   alignas(8) u32 mt[4][624];   // MT19937 states of cinc_b, cinc_s, cinc_lb, cinc_ls
   u32 mt_idx[4];
-  alignas(8) u8 rd[2][FQSX_RD_LDS];       // 2-bit codes (0..4) of the current read (two buffers: the head wave stages the next read)
+  alignas(8) u8 rd[FQSX_HD][FQSX_RD_LDS]; // 2-bit codes (0..4) of the current read (one buffer per head record: the head wave stages the next reads)
   u64 bk_key[256];             // probe batch: normalised k-mers
   u32 bk_res[256][4];          // probe batch: counts
   u8 bk_dir[256];              // probe batch: orientation
@@ -129,7 +133,7 @@ struct WgShared {
   // position (SK_RANK / SK_LETTER) or as a finished (freq, cum, total) triple of a small direct-indexed model
   // (SK_RAW: key[0] = freq | cum << 32, key[1] = total).  Filled by the wave that resolves the reads, drained by
   // the coder (the same wave in the single-wave build, the workgroup's second wave in the encode kernel).
-  u64 cq_key[FQSX_CQ][10];
+  u64 cq_key[10][FQSX_CQ];     // (level-major like sp_key: the models wave reads one entry per lane)
   u8 cq_kind[FQSX_CQ];         // SK_* | SK_RESET
   u8 cq_rsym[FQSX_CQ];
   u32 cq_tail, cq_head, cq_done;   // entries published / consumed (free-running); producer finished
@@ -1048,8 +1052,8 @@ FQ_DEV void rc_encode(Wk &w, u32 freq, u32 cum, u32 tot) {
   const u32 e = w.cq_tail & (FQSX_CQ - 1);
   FQ_SYNC();
   if (FQ_LANE == 0) {
-    sm->cq_key[e][0] = (u64)freq | ((u64)cum << 32);
-    sm->cq_key[e][1] = tot;
+    sm->cq_key[0][e] = (u64)freq | ((u64)cum << 32);
+    sm->cq_key[1][e] = tot;
     sm->cq_kind[e] = SK_RAW;
     sm->cq_rsym[e] = 5;
   }
@@ -1189,8 +1193,9 @@ FQ_DEV u32 letters_thr(u32 i) { return 1u << ((0x2EEDCB987650ULL >> (4 * i)) & 1
 // search with lazy clone-on-threshold; returns slot index (model + already incremented counter in s)
 // `lev` points to the level keys in LDS; `rs` is added to the keys of levels >= 2 (the r_sym field the
 // speculation stage left open)
-#define LEVKEY(l) (lev[l] + ((l) >= 2 ? rs : 0))
-FQ_DEV u32 find_leveled(Wk &w, u32 tag, const u64 *lev, u64 rs, int n_levels, double &avg, u64 tpl_q2, u64 tpl_q3, u32 tpl_total, Slot4 &s) {
+// ls: distance (in keys) between two levels' keys of one symbol: 1 for a plain array, FQSX_CQ inside the coding queue
+#define LEVKEY(l) (lev[(u32)(l) * ls] + ((l) >= 2 ? rs : 0))
+FQ_DEV u32 find_leveled(Wk &w, u32 tag, const u64 *lev, u32 ls, u64 rs, int n_levels, double &avg, u64 tpl_q2, u64 tpl_q3, u32 tpl_total, Slot4 &s) {
   int i;
   Slot4 q;
   const bool letters = tag == 2;
@@ -1270,63 +1275,38 @@ FQ_DEV void slot_encode(Wk &w, u32 idx, Slot4 &s, u32 x) {
 
 // ---------------------------------------------------------------------------------------
 // context keys (code_ctx.cpp)
+// The quantisers of a count (code_ctx.cpp:15-239) are "digits up to D, then one class per threshold passed".  The thresholds
+// are compile-time constants: the class is a sum of comparisons against immediates -- no table in memory, no loop whose
+// trip count depends on the lane's count (64 lanes with 64 different counts run the longest of them).
+#define GE(x) ((u32)(c >= (x)))
 FQ_DEV u64 conv_lev1(u64 c, u32 cl) {  // code_ctx.cpp:26-81
-  u64 f = (u64)cl << 5;
-  if (cl == 0) {
-    if (c < 5) return f + c;
-    if (c < 8) return f + 5;
-    if (c < 16) return f + 6;
-    if (c < 32) return f + 7;
-    if (c < 64) return f + 8;
-    return f + 9;
-  }
-  const u32 lim[21] = {16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 288, 384, 512, 1024, 2048};
+  const u64 f = (u64)cl << 5;
+  if (cl == 0) return f + (c < 5 ? c : 5 + GE(8) + GE(16) + GE(32) + GE(64));
   if (c < 8) return f + c;
-  for (u32 i = 0; i < 21; ++i)
-    if (c < lim[i]) return f + 8 + i;
-  return f + 29;
+  return f + 8 + GE(16) + GE(24) + GE(32) + GE(40) + GE(48) + GE(56) + GE(64) + GE(80) + GE(96) + GE(112) + GE(128) + GE(144) + GE(160) +
+         GE(176) + GE(192) + GE(224) + GE(288) + GE(384) + GE(512) + GE(1024) + GE(2048);
 }
 FQ_DEV u64 conv_low(u64 c, u32 cl, bool lev3) {  // shared rows of code_ctx.cpp:84-110 and :167-198
-  u64 f = (u64)cl << 5;
-  if (cl == 0) {
-    if (c < 3) return f + c;
-    if (c < 5) return f + 3;
-    return f + 4;
-  }
-  if (cl == 1) {
-    if (c < 5) return f + c;
-    if (c < 8) return f + 5;
-    if (c < 13) return f + 6;
-    if (c < 20) return f + 7;
-    if (c < 30) return f + 8;
-    return f + 9;
-  }
+  const u64 f = (u64)cl << 5;
+  if (cl == 0) return f + (c < 3 ? c : 3 + GE(5));
+  if (cl == 1) return f + (c < 5 ? c : 5 + GE(8) + GE(13) + GE(20) + GE(30));
   // cl == 2
-  if (c < 10) return f + c;
-  if (c < (lev3 ? 13u : 15u)) return f + 10;
-  if (c < 20) return f + 11;
-  if (c < 30) return f + 12;
-  if (c < 50) return f + 13;
-  return f + 14;
+  return f + (c < 10 ? c : 10 + GE(lev3 ? 13u : 15u) + GE(20) + GE(30) + GE(50));
 }
 FQ_DEV u64 conv_lev24(u64 c, u32 cl) {  // code_ctx.cpp:84-164
   if (cl < 3) return conv_low(c, cl, false);
-  u64 f = (u64)cl << 5;
-  const u32 lim[19] = {16, 24, 32, 48, 64, 128, 256, 512, 1024, 2048, 2080, 2112, 2176, 2240, 2304, 2432, 2560, 2816, 3072};
+  const u64 f = (u64)cl << 5;
   if (c < 10) return f + c;
-  for (u32 i = 0; i < 19; ++i)
-    if (c < lim[i]) return f + 10 + i;
-  return f + 29;
+  return f + 10 + GE(16) + GE(24) + GE(32) + GE(48) + GE(64) + GE(128) + GE(256) + GE(512) + GE(1024) + GE(2048) + GE(2080) + GE(2112) + GE(2176) +
+         GE(2240) + GE(2304) + GE(2432) + GE(2560) + GE(2816) + GE(3072);
 }
 FQ_DEV u64 conv_lev3(u64 c, u32 cl) {  // code_ctx.cpp:167-239
   if (cl < 3) return conv_low(c, cl, true);
-  u64 f = (u64)cl << 5;
-  const u32 lim[14] = {18, 20, 25, 30, 40, 50, 60, 64, 68, 72, 76, 80, 84, 88};
+  const u64 f = (u64)cl << 5;
   if (c < 15) return f + c;
-  for (u32 i = 0; i < 14; ++i)
-    if (c < lim[i]) return f + 15 + i;
-  return f + 29;
+  return f + 15 + GE(18) + GE(20) + GE(25) + GE(30) + GE(40) + GE(50) + GE(60) + GE(64) + GE(68) + GE(72) + GE(76) + GE(80) + GE(84) + GE(88);
 }
+#undef GE
 enum { LV_NONE = 0, LV_PMER = 1, LV_SMER = 2, LV_BMER = 3, LV_MIXED = 4, LV_BMER_UNC = 5 };  // defs.h:45
 FQ_DEV u64 conv_count(u64 c, u32 level, u32 cl) {  // code_ctx.cpp:15-23
   if (level == LV_PMER) return conv_lev1(c, cl);
@@ -1987,7 +1967,7 @@ FQ_DEV void code_letter(Wk &w, u32 pos, u32 sym, u32 read_len) {  // dna.cpp:520
     const u32 e = w.cq_tail & (FQSX_CQ - 1);
     FQ_SYNC();
     if (FQ_LANE == 0) {
-      for (u32 l = 0; l < 10; ++l) w.sm->cq_key[e][l] = lev[l];
+      for (u32 l = 0; l < 10; ++l) w.sm->cq_key[l][e] = lev[l];
       w.sm->cq_kind[e] = SK_LETTER;
       w.sm->cq_rsym[e] = (u8)sym;
     }
@@ -1999,7 +1979,7 @@ FQ_DEV void code_letter(Wk &w, u32 pos, u32 sym, u32 read_len) {  // dna.cpp:520
   for (u32 l = 0; l < 10; ++l) w.sm->lev_tmp[l] = lev[l];
   FQ_SYNC();
   Slot4 s;
-  u32 idx = find_leveled(w, 2, w.sm->lev_tmp, 0, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
+  u32 idx = find_leveled(w, 2, w.sm->lev_tmp, 1, 0, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
   if (idx != FQSX_NIL) slot_encode(w, idx, s, sym);
 }
 
@@ -2163,7 +2143,7 @@ FQ_DEV void spec_store_lane(SpecBuf *sb, u32 jj, const SpecLane &L) {
   for (u32 x = 0; x < 6; ++x) { sb->sp_sdir[x][jj] = L.sdir[x]; sb->sp_src[x][jj] = L.src[x]; sb->sp_scur[x][jj] = L.scur[x]; }
   sb->sp_nrun[jj] = L.nrun;
   if (L.flag == 1) {
-    for (u32 l = 0; l < 7; ++l) sb->sp_key[jj][l] = L.key[l];
+    for (u32 l = 0; l < 7; ++l) sb->sp_key[l][jj] = L.key[l];
     sb->sp_rsym[jj] = L.rsym;
   }
   if (L.flag == 3) { sb->sx_lb[jj] = L.sx_lb; sb->sx_s[jj] = L.sx_s; sb->sx_ls[jj] = L.sx_ls; sb->sx_flag[jj] = L.sx_flag; }
@@ -2542,13 +2522,13 @@ FQ_DEV void code_keys(Wk &w, const u8 *p, u32 size, u32 i0, u32 j0, u32 m, bool 
       u64 lev[7];
       if (!reversed) ctx_codes(lev, cfg, c, w.s_let, pos, level, cz, 0, size);
       else ctx_codes(lev, cfg, c, w.s_let, size - pos - 1, level, cz, 0, ~0u);   // dna.cpp:750-752
-      for (u32 l = 0; l < 7; ++l) w.sb->sp_key[j][l] = lev[l];
+      for (u32 l = 0; l < 7; ++l) w.sb->sp_key[l][j] = lev[l];
       w.sb->sp_rsym[j] = (u8)rank_sym(w, c, sym);
       w.sb->sp_kind[j] = SK_RANK;
     } else if (kind == SK_LETTER_PENDING) {
       u64 lev[10];
       ctx_letters_keys(lev, cfg, pos, letters_before(w, p, pos, size, hist_start), size);   // dna.cpp:520-528,776-785
-      for (u32 l = 0; l < 10; ++l) w.sb->sp_key[j][l] = lev[l];
+      for (u32 l = 0; l < 10; ++l) w.sb->sp_key[l][j] = lev[l];
       w.sb->sp_rsym[j] = (u8)sym;
       w.sb->sp_kind[j] = SK_LETTER;
     }
@@ -2565,16 +2545,16 @@ FQ_DEV void code_one(Wk &w, u32 j) {
   Slot4 s;
   if (kind == SK_RANK) {
     const u64 rs = (u64)popc64(w.c_r_sym) << SH_RSYM;
-    u32 idx = find_leveled(w, 1, sm->cq_key[e], rs, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
+    u32 idx = find_leveled(w, 1, &sm->cq_key[0][e], FQSX_CQ, rs, 7, w.avg_code, TPL_CODES_Q2, TPL_CODES_Q3, TPL_CODES_TOT, s);
     if (idx != FQSX_NIL) slot_encode(w, idx, s, sy);
     w.c_r_sym = ((w.c_r_sym << 1) + (sy == 0 ? 1u : 0u)) & 0xff;   // update_ctx_r_sym, dna.cpp:664-671
   } else if (kind == SK_LETTER) {
-    u32 idx = find_leveled(w, 2, sm->cq_key[e], 0, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
+    u32 idx = find_leveled(w, 2, &sm->cq_key[0][e], FQSX_CQ, 0, 9, w.avg_letters, TPL_LET_Q2, TPL_LET_Q3, TPL_LET_TOT, s);
     if (idx != FQSX_NIL) slot_encode(w, idx, s, sy);
     w.c_r_sym = (w.c_r_sym << 1) & 0xff;
   } else {
-    const u64 k0 = sm->cq_key[e][0];
-    const u32 tot = (u32)sm->cq_key[e][1];
+    const u64 k0 = sm->cq_key[0][e];
+    const u32 tot = (u32)sm->cq_key[1][e];
     rc_encode_rd(w, (u32)k0, (u32)(k0 >> 32), tot, recip_u16(tot));
     w.c_r_sym = (w.c_r_sym << 1) & 0xff;   // (always followed by an SK_RESET entry before the next rank)
   }
@@ -2632,7 +2612,10 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len) {
       u32 hist = popc64((Z >> lo) & ((1ull << (t - lo)) - 1ull));
       if (incoming) hist += popc64(ctx_r_sym & ((1ull << (8 - t)) - 1ull));
       const u64 rs = letter ? 0ull : (u64)hist << SH_RSYM;
-      const u64 *lev = sm->cq_key[CQE(t)];
+      const u64 *lev = &sm->cq_key[0][CQE(t)];
+      const u32 ls = FQSX_CQ;
+      // (tried in round 4 and dropped: fetching the first slots of levels s0 - 1, s0, s0 + 1 together, so that the walk below finds
+      // its neighbours answered -- 175.3 vs 176.9 Mbases/s in steady state: the models wave is not what the worker waits for)
       RoHit h = ctx_probe_ro(w, tag, LEVKEY(s0), vis);
       int i = s0;
       if (h.present) {
@@ -2703,8 +2686,8 @@ FQ_DEV u32 code_run(Wk &w, u32 j0, u32 len) {
     bool bad = sm->fr_bad[t] != 0;
     u32 f = 0, c = 0, tot = 0;
     if (!bad && ((KR >> t) & 1)) {        // finished triple
-      const u64 k0 = sm->cq_key[CQE(t)][0];
-      f = (u32)k0; c = (u32)(k0 >> 32); tot = (u32)sm->cq_key[CQE(t)][1];
+      const u64 k0 = sm->cq_key[0][CQE(t)];
+      f = (u32)k0; c = (u32)(k0 >> 32); tot = (u32)sm->cq_key[1][CQE(t)];
     } else if (!bad) {
       const u64 below = sm->fr_same[t] & ((1ull << t) - 1ull);
       const u32 occ = popc64(below);
@@ -2894,7 +2877,7 @@ FQ_DEV void code_chunk(Wk &w, const u8 *p, u32 size, u32 i0, u32 j0, u32 m, bool
     const u32 e = (w.cq_tail + (j - j0)) & (FQSX_CQ - 1);
     const u32 kind = w.sb->sp_kind[j];
     const u32 nk = kind == SK_LETTER ? 10u : 7u;
-    for (u32 l = 0; l < nk; ++l) sm->cq_key[e][l] = w.sb->sp_key[j][l];
+    for (u32 l = 0; l < nk; ++l) sm->cq_key[l][e] = w.sb->sp_key[l][j];
     sm->cq_kind[e] = (u8)(kind | (first && j == j0 ? SK_RESET : 0u));
     sm->cq_rsym[e] = w.sb->sp_rsym[j];
   }
@@ -2928,17 +2911,24 @@ FQ_DEV bool qm_test(const u32 *bits, u64 g) {
   const u32 a = (u32)(h >> 51), b = (u32)(h >> 38) & 8191u;
   return ((bits[a >> 5] >> (a & 31)) & (bits[b >> 5] >> (b & 31)) & 1u) != 0;
 }
-FQ_DEV u64 quiet_miss_mask(Wk &w, u32 n) {
+// Round 4: the same test also answers, for EVERY position whose cascade stage P resolved (hits included), whether a pending
+// local insert could change its b-mer look-up (ncb: no) / its s-mer look-up (ncs: no) -- what the per-position path otherwise asks
+// pend_conflict for, twice per position, with a dozen dependent LDS round trips each.  quiet = the positions of the old mask.
+struct ConfMasks { u64 quiet, ncb, ncs; };
+FQ_DEV ConfMasks conflict_masks(Wk &w, u32 n, bool want_quiet) {
+  ConfMasks R;
+  R.quiet = R.ncb = R.ncs = 0;
   SpecBuf *sb = w.sb;
   WgShared *sm = w.sm;
   const DevCfg *cfg = w.cfg;
   const u32 lane = FQ_LANE;
   FQ_SYNC();
-  const bool cand = lane < n && sb->sp_flag[lane] == 3 && (sb->sx_flag[lane] & (SX_VALID | SX_HITS)) == SX_VALID;
+  const u32 xfl = lane < n && sb->sp_flag[lane] == 3 ? sb->sx_flag[lane] : 0u;
+  const bool cand = (xfl & SX_VALID) != 0, qcand = (xfl & (SX_VALID | SX_HITS)) == SX_VALID;
   const u64 A = wave_ballot(cand);
-  if (popc64(A) < 8) return 0;   // not worth the set-up: the per-position path handles them
+  if (popc64(A) < 4) return R;   // not worth the set-up: the per-position path handles them
   const u32 lo_b = w.pq_lo[0], hi_b = w.mn[MAIL_B], lo_s = w.pq_lo[1], hi_s = w.mn[MAIL_S];
-  if (hi_b - lo_b > FQSX_PQ || hi_s - lo_s > FQSX_PQ) return 0;
+  if (hi_b - lo_b > FQSX_PQ || hi_s - lo_s > FQSX_PQ) return R;
   const u32 k2b = 2 * cfg->gb.k, k2s = 2 * cfg->gs.k;
   const u64 lmb = (1ull << (k2b - 2)) - 1ull, lms = (1ull << (k2s - 2)) - 1ull;
   // this lane's two sibling groups
@@ -2961,7 +2951,7 @@ FQ_DEV u64 quiet_miss_mask(Wk &w, u32 n) {
   }
   FQ_SYNC();
   const u32 hb = grp_hash(gb), hs = grp_hash(gs);
-  bool maybe = qm_test(sm->qm_bits[ndb ? 0 : 1], gb) || qm_test(sm->qm_bits[nds ? 2 : 3], gs);
+  bool maybe_b = qm_test(sm->qm_bits[ndb ? 0 : 1], gb), maybe_s = qm_test(sm->qm_bits[nds ? 2 : 3], gs);
   // the entries of the chunk's earlier positions, exactly: every position files its lane under the 6-bit hashes of its
   // entries' groups (both readings; the bit sets above are reused as 4 x 64 lane masks), and a lane compares groups
   // only with the earlier lanes filed where its own group hashes to
@@ -2981,18 +2971,21 @@ FQ_DEV u64 quiet_miss_mask(Wk &w, u32 n) {
     lds_or64(&lm[3 * 64 + (grp_hash(pv & lms) & 63)], 1ull << lane);
   }
   FQ_SYNC();
-  if (cand && !maybe) {
-    const u64 lt = (1ull << lane) - 1ull;
-    for (u64 c = lm[(ndb ? 0 : 64) + (hb & 63)] & lt; c && !maybe; c &= c - 1ull) {
+  const u64 lt = (1ull << lane) - 1ull;
+  if (cand && !maybe_b)
+    for (u64 c = lm[(ndb ? 0 : 64) + (hb & 63)] & lt; c && !maybe_b; c &= c - 1ull) {
       const u64 pv = sb->pv_b[ctz64(c)] >> (64 - k2b);
-      maybe = ndb ? (pv >> 2) == gb : (pv & lmb) == gb;
+      maybe_b = ndb ? (pv >> 2) == gb : (pv & lmb) == gb;
     }
-    for (u64 c = lm[(nds ? 128 : 192) + (hs & 63)] & lt; c && !maybe; c &= c - 1ull) {
+  if (cand && !maybe_s)
+    for (u64 c = lm[(nds ? 128 : 192) + (hs & 63)] & lt; c && !maybe_s; c &= c - 1ull) {
       const u64 pv = sb->pv_s[ctz64(c)] >> (64 - k2s);
-      maybe = nds ? (pv >> 2) == gs : (pv & lms) == gs;
+      maybe_s = nds ? (pv >> 2) == gs : (pv & lms) == gs;
     }
-  }
-  return wave_ballot(cand && !maybe);
+  R.ncb = wave_ballot(cand && !maybe_b);
+  R.ncs = wave_ballot(cand && !maybe_s);
+  if (want_quiet) R.quiet = wave_ballot(qcand && !maybe_b && !maybe_s);
+  return R;
 }
 #endif
 
@@ -3188,9 +3181,35 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
       Fm |= (u64)f << t; Rm |= (u64)r << t;
 #endif
     }
-    u64 Qm = 0;       // positions nothing is found for anywhere unless their Hamming-1 sweep finds something (quiet_miss_mask)
+    u64 Qm = 0;       // positions nothing is found for anywhere unless their Hamming-1 sweep finds something (conflict_masks)
+#if FQ_WAVE <= 1
+    const u64 NCb = 0, NCs = 0;
+#else
+    // (both only concern positions stage P could not settle: a chunk whose lanes [j0, n) are all settled -- most chunks of covered
+    // sequence -- goes straight on; with the gate open repair_kmers_missing may fire: per-position path)
+    const u64 live = (n >= 64 ? ~0ull : (1ull << n) - 1ull) & (~0ull << j0);
+    u64 NCb = 0, NCs = 0;   // positions whose local b- / s-mer look-up no pending insert can change (conflict_masks)
+    if (pre && (live & ~Fm)) {
+      TM_BEGIN(t_qm);
+      local_refresh(w, j0, n);
+      const ConfMasks cmk = conflict_masks(w, n, !w.repm_gate);
+      Qm = cmk.quiet; NCb = cmk.ncb; NCs = cmk.ncs;
+      TM_END(w, TX_QMM, t_qm);
+    }
+#endif
+    // What the serial loop below reads about a position -- stage P's flags, the N run, the mailbox flags, the symbol and the
+    // repair symbol -- is fetched ONCE per chunk, one position per lane, and then handed out by v_readlane: the loop's time is a
+    // chain of dependent LDS round trips (a hundred-odd cycles each for a lone wave), and these were five of them per position.
 #if FQ_WAVE > 1
-    { TM_BEGIN(t_qm); if (pre) local_refresh(w, j0, n); if (pre && !w.repm_gate) Qm = quiet_miss_mask(w, n); TM_END(w, TX_QMM, t_qm); }   // (with the gate open repair_kmers_missing may fire: per-position path)
+    u32 pk = 0, pk2 = 4;
+    {
+      const u32 t = FQ_LANE;
+      if (t < n) {
+        pk = (u32)w.sb->sp_flag[t] | ((u32)w.sb->sx_flag[t] << 8) | ((u32)w.sb->sp_nrun[t] << 16) | ((u32)w.sb->pv_flag[t] << 24);
+        pk2 = (size <= FQSX_RD_LDS && i + t < size ? (u32)w.rdp[i + t] : 4u) | ((u32)w.sb->sp_rep[t] << 8) | ((u32)w.sb->sp_scur[2][t] << 16);
+      }
+    }
+#define PKJ(v, jj) ((u32)__builtin_amdgcn_readlane((int)(v), (int)(jj)))
 #endif
     u32 q_done = j0;  // chunk positions whose mailbox entries are already in the lists
     u32 w_pos = j0;   // w's k-mers = state before position w_pos of the chunk
@@ -3199,9 +3218,15 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
     bool foreseen = false;   // ... by the repair of a settled position, which a scout may have allowed for (scout_fix)
     for (u32 j = j0; j < n && !dirty && !w.err; ++j) {
       const u32 pos = i + j;
+#if FQ_WAVE > 1
+      const u32 pkj = PKJ(pk, j), pk2j = PKJ(pk2, j);
+      const u32 sym = size <= FQSX_RD_LDS ? (pk2j & 0xffu) : rd_sym(w, p, pos, size);
+      const u32 flag = pkj & 0xffu;
+#else
       const u32 sym = rd_sym(w, p, pos, size);
-      const u64 sym_k = sym == 4 ? 0 : sym;
       const u32 flag = w.sb->sp_flag[j];
+#endif
+      const u64 sym_k = sym == 4 ? 0 : sym;
 #if FQ_WAVE > 1
       if ((Qm >> j) & 1) {
         TM_BEGIN(t_qr);
@@ -3259,9 +3284,15 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         const u32 len = rr ? ctz64(rr) + 1 : nf;
         j += len - 1;
         const u32 pos = i + j;
+#if FQ_WAVE > 1
+        const u32 pk2e = PKJ(pk2, j);
+        const u32 sym = size <= FQSX_RD_LDS ? (pk2e & 0xffu) : rd_sym(w, p, pos, size);
+        const u32 rep = (pk2e >> 8) & 0xffu;
+#else
         const u32 sym = rd_sym(w, p, pos, size);
-        const u64 sym_k = sym == 4 ? 0 : sym;
         const u32 rep = w.sb->sp_rep[j];
+#endif
+        const u64 sym_k = sym == 4 ? 0 : sym;
 #ifdef FQSX_TIMING
         w.tm[CN_FAST] += len;
 #endif
@@ -3282,16 +3313,23 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         // not settled by stage P alone
         C4 counts;
         c4_zero(counts);
+#if FQ_WAVE > 1
+        u32 level = LV_NONE, nrun_here = (pkj >> 16) & 0xffu;
+        const u32 xf = flag == 3 ? (pkj >> 8) & 0xffu : 0u;
+        const u32 scur2_j = (pk2j >> 16) & 0xffu;
+#else
         u32 level = LV_NONE, nrun_here = w.sb->sp_nrun[j];
+        const u32 xf = flag == 3 ? w.sb->sx_flag[j] : 0;
+        const u32 scur2_j = w.sb->sp_scur[2][j];
+#endif
         bool rough = false, loaded = false, resolved = false;
         TM_COUNT(w, CN_SLOW);
-        const u32 xf = flag == 3 ? w.sb->sx_flag[j] : 0;
         const bool early_b = flag == 4;
         if (early_b) {
           // early position, b-mer almost full; the scout wave has probed its paddings in the global table and seen hits
           // (scout_settle_early): find_counts (dna.cpp:461-476) comes down to the merges, in trial order
           Kmer bmj;
-          bmj.dir = bmj.rc = 0; bmj.cur = w.sb->sp_scur[2][j];
+          bmj.dir = bmj.rc = 0; bmj.cur = scur2_j;
           kt_find(w, cfg->g_b, true, cfg->gb, bmj, RNG_B, CINC_B, counts, w.sb->ep_off[j][0]);
           resolved = true;
           level = LV_BMER;
@@ -3310,11 +3348,15 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
         if (xf & SX_VALID) {
           // the cascade was resolved in stage P; it stands unless a pending local insert interferes
           Kmer bmj, smj;
-          bmj.dir = w.sb->sp_sdir[2][j]; bmj.rc = w.sb->sp_src[2][j]; bmj.cur = w.sb->sp_scur[2][j];
-          smj.dir = w.sb->sp_sdir[1][j]; smj.rc = w.sb->sp_src[1][j]; smj.cur = w.sb->sp_scur[1][j];
-          // (a position of the quiet-miss mask has no such entry in either group: quiet_miss_mask)
-          bool conflict = ((Qm >> j) & 1) ? false : pend_conflict(w, 0, cfg->gb, bmj, q_done, j);
-          if (!conflict && !((Qm >> j) & 1) && !(xf & (SX_LB | SX_UNC | SX_S))) conflict = pend_conflict(w, 1, cfg->gs, smj, q_done, j);
+          bmj.dir = bmj.rc = 0; bmj.cur = 0;
+          // (a position of the conflict masks has no such entry in the group: conflict_masks; the k-mers are only fetched when asked for)
+          const bool ask_b = !((NCb >> j) & 1), ask_s = !((NCs >> j) & 1) && !(xf & (SX_LB | SX_UNC | SX_S));
+          if (ask_b || ask_s || !(xf & SX_HITS)) { bmj.dir = w.sb->sp_sdir[2][j]; bmj.rc = w.sb->sp_src[2][j]; bmj.cur = scur2_j; }   // (a conflict, or an empty cascade without a sweep probed ahead, needs the b-mer)
+          bool conflict = ask_b ? pend_conflict(w, 0, cfg->gb, bmj, q_done, j) : false;
+          if (!conflict && ask_s) {
+            smj.dir = w.sb->sp_sdir[1][j]; smj.rc = w.sb->sp_src[1][j]; smj.cur = w.sb->sp_scur[1][j];
+            conflict = pend_conflict(w, 1, cfg->gs, smj, q_done, j);
+          }
           if (conflict) {
             // An entry still on its way into the local tables lies in the position's sibling group -- typically the
             // second of two overlapping reads of this worker.  The look-up that entry can change comes first in the
@@ -3454,7 +3496,11 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
           w_pos = j + 1;
         } else {
           // stage P's entries stand (k-mers unmodified); settle the p-mer entry, which depends on the level
+#if FQ_WAVE > 1
+          u32 pf = pkj >> 24;
+#else
           u32 pf = w.sb->pv_flag[j];
+#endif
           if (pf & PV_PCAND) {
             pf |= (!early_b && lvl_sbm && c4_get(counts, sym) >= 3) ? PV_PHID : PV_P;   // (hidden only under a full b-mer)
             FQ_SYNC();
@@ -3584,15 +3630,15 @@ FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx, bool has_ne
     fq_sleep();
     if (spin_expired(spins)) { w.err = FQSX_ERR_PIPE; return; }   // never spin forever on the GPU
   }
-  const HeadRec *rec = &sm->hd[idx & 1];
+  const HeadRec *rec = &sm->hd[idx % FQSX_HD];
   const u32 n_raw = rec->n_raw;
   const bool same = rec->same != 0;
   // the head's symbols take their place in the stream
   if (cq_wait_space(w, n_raw)) {
     for (u32 j = FQ_LANE; j < n_raw; j += FQ_WAVE) {
       const u32 e = (w.cq_tail + j) & (FQSX_CQ - 1);
-      sm->cq_key[e][0] = rec->raw[j][0];
-      sm->cq_key[e][1] = rec->raw[j][1];
+      sm->cq_key[0][e] = rec->raw[j][0];
+      sm->cq_key[1][e] = rec->raw[j][1];
       sm->cq_kind[e] = SK_RAW;
       sm->cq_rsym[e] = 5;
     }
@@ -3608,7 +3654,7 @@ FQ_DEV void compress_read_rec(Wk &w, const u8 *p, u32 size, u32 idx, bool has_ne
     w.pm_u = w.pm; w.sm_u = w.sm_; w.bm_u = w.bm;
     w.cor_pos = 0;
     w.N_run = rec->n_run;
-    w.rdp = sm->rd[idx & 1];
+    w.rdp = sm->rd[idx % FQSX_HD];
     w.sc_read = idx;
     w.sc_abandoned = false;
     u32 hist[4] = {rec->hist[0], rec->hist[1], rec->hist[2], rec->hist[3]};
@@ -3846,21 +3892,21 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
   for (u64 i = cur; i < stop && !w.err; ++i) {
     const u32 idx = (u32)(i - cur);
     u32 spins = 0;
-    for (;;) {   // both records in use: by the resolving wave, by a scout wave, or by a restart request not yet taken up
-      bool busy = (i32)(idx - lds_load_acq(&sm->hd_taken)) >= 2;   // (read first: a request is posted before hd_taken moves on)
+    for (;;) {   // all records in use: by the resolving wave, by a scout wave, or by a restart request not yet taken up
+      bool busy = (i32)(idx - lds_load_acq(&sm->hd_taken)) >= (i32)FQSX_HD;   // (read first: a request is posted before hd_taken moves on)
       if (!lds_load_acq(&sm->sc_dead)) {
         const u32 req = lds_load_acq(&sm->sc_req_seq);
-        for (u32 x = 0; x < FQSX_NSC; ++x) busy |= lds_load_acq(&sm->sc_ack[x]) != req || (i32)(idx - lds_load_acq(&sm->sc_hd_taken[x])) >= 2;
+        for (u32 x = 0; x < FQSX_NSC; ++x) busy |= lds_load_acq(&sm->sc_ack[x]) != req || (i32)(idx - lds_load_acq(&sm->sc_hd_taken[x])) >= (i32)FQSX_HD;
       }
       if (!busy) break;
       fq_sleep();
       if (spin_expired(spins)) { w.err = FQSX_ERR_PIPE; break; }   // never spin forever on the GPU
     }
     if (w.err) break;
-    HeadRec *rec = &sm->hd[idx & 1];
+    HeadRec *rec = &sm->hd[idx % FQSX_HD];
     w.rec = rec;
     w.rec_idx = idx;
-    w.rdp = sm->rd[idx & 1];
+    w.rdp = sm->rd[idx % FQSX_HD];
     FQ_SYNC();
     if (FQ_LANE == 0) { rec->idx = ~0u; rec->n_raw = 0; rec->n_p = 0; }
     FQ_SYNC();
@@ -3997,7 +4043,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         if (restart) continue;
       }
     }
-    const HeadRec *rec = &sm->hd[idx & 1];
+    const HeadRec *rec = &sm->hd[idx % FQSX_HD];
     const bool rec_same = uniform32(rec->same) != 0;   // (wave-uniform values: kept in scalar registers)
     const u32 hist[4] = {uniform32(rec->hist[0]), uniform32(rec->hist[1]), uniform32(rec->hist[2]), uniform32(rec->hist[3])};
     const u64 hk_dir[3] = {uniform64(rec->kdir[0]), uniform64(rec->kdir[1]), uniform64(rec->kdir[2])};
@@ -4014,7 +4060,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
       const u64 o0 = cfg.read_off[ri], o1 = cfg.read_off[ri + 1];
       const u8 *p = cfg.bases + o0;
       const u32 size = (u32)(o1 - o0);
-      w.rdp = sm->rd[idx & 1];
+      w.rdp = sm->rd[idx % FQSX_HD];
       if (from_head) {
         w.pm.dir = hk_dir[0]; w.pm.rc = hk_rc[0]; w.pm.cur = hk_cur[0];
         w.sm_.dir = hk_dir[1]; w.sm_.rc = hk_rc[1]; w.sm_.cur = hk_cur[1];

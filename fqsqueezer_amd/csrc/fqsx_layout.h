@@ -16,7 +16,8 @@
 #define FQSX_SIV_BLK_LOG 14u     // fields per block of the p-mer vector's count index (16384 fields = 512 words = 4 KiB)
 #define FQSX_SIV_BLK (1u << FQSX_SIV_BLK_LOG)
 #define FQSX_NIL 0xffffffffu
-#define FQSX_RD_LDS 4096u        // reads up to this length are staged in LDS
+#define FQSX_RD_LDS 3072u        // reads up to this length are staged in LDS (longer ones are read from HBM, one base at a time)
+#define FQSX_HD 3u               // read-head records (and staging buffers) of a worker: the read-head wave runs up to FQSX_HD - 1 reads ahead
 #define FQSX_SPEC 64u            // positions speculated per chunk (one per lane)
 #define FQSX_PQ 512u             // entries of the LDS mirror of each local-insert list (power of two)
 #define FQSX_CQ 256u             // entries of the coding queue (power of two, >= 2 * FQSX_SPEC)

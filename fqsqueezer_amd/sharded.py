@@ -272,7 +272,12 @@ class NativeShardedDnaCodec:
         L.fqsx_rccl_comm_destroy.argtypes = [C.POINTER(_Comm)]
         self._rccl = transport == "rccl"
         self._staged = transport == "staged"
-        if self._rccl:
+        self._own_comm = True
+        if self._rccl and comm is not None:   # the process's communicator, made with an earlier codec: goes on with this one's stream
+            L.fqsx_rccl_comm_rebind.argtypes = [C.POINTER(_Comm), C.c_void_p]
+            self._comm, self._own_comm = comm, False
+            self._ck(L.fqsx_rccl_comm_rebind(C.byref(self._comm), self._h), "fqsx_rccl_comm_rebind")
+        elif self._rccl:
             if id_bytes is None or len(id_bytes) != 128:
                 raise ValueError("the RCCL transport needs the 128-byte unique id (rccl_unique_id on rank 0)")
             self._comm = _Comm()
@@ -340,7 +345,23 @@ class NativeShardedDnaCodec:
         self._lib.fqsx_shard_traffic(self._h, a)
         return {"phases": a[0], "collectives": a[1], "all_to_all_bytes": 8 * a[2], "all_gather_bytes": 8 * a[3]}
 
-    def close(self) -> None:
+    def rccl_info(self) -> dict:
+        """what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank)"""
+        a = (C.c_uint32 * 2)()
+        self._lib.fqsx_rccl_comm_info.argtypes = [C.POINTER(_Comm), C.POINTER(C.c_uint32)]
+        self._ck(self._lib.fqsx_rccl_comm_info(C.byref(self._comm), a), "fqsx_rccl_comm_info")
+        return {"ranks_seen": int(a[0]), "rank": int(a[1])}
+
+    def detach_comm(self) -> "_Comm":
+        """keep the RCCL communicator beyond this codec (hand it to the next NativeShardedDnaCodec as `comm`)"""
+        self._own_comm = False
+        return self._comm
+
+    def destroy_comm(self) -> None:
         if self._rccl and self._comm.ctx:
+            self._lib.fqsx_rccl_comm_destroy(C.byref(self._comm))
+
+    def close(self) -> None:
+        if self._rccl and self._own_comm and self._comm.ctx:
             self._lib.fqsx_rccl_comm_destroy(C.byref(self._comm))
         self.codec.close()

@@ -178,6 +178,10 @@ int fqsx_shard_is_partitioned(fqsx_dna *);
  * use).  Rank 0 calls fqsx_rccl_unique_id and hands the 128 bytes to the other ranks by any means (a file, a TCP store). */
 int fqsx_rccl_unique_id(uint8_t id[128]);
 int fqsx_rccl_comm_create(fqsx_dna *, const uint8_t id[128], uint32_t rank, uint32_t world, fqsx_comm *out);
+/* The communicator goes on with another codec (the next file of the process): its collectives run on that codec's stream. */
+int fqsx_rccl_comm_rebind(fqsx_comm *, fqsx_dna *);
+/* out[0] = ranks of the communicator as RCCL counts them (ncclCommCount), out[1] = this process's rank in it. */
+int fqsx_rccl_comm_info(fqsx_comm *, uint32_t out[2]);
 void fqsx_rccl_comm_destroy(fqsx_comm *);
 
 /* Kernel timing: when enabled every launch is bracketed by HIP events on the codec's stream.

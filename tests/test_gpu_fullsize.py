@@ -5,8 +5,13 @@ c18 = BASELINE configs[2] at its full size: 5 M pairs x 150 bp, fragments 300-60
 c19 = a configs[3]-shaped single-end file: 10 M x 150 bp, G = 300 Mbp, `-om s -gs 300` (k = 12/17/21/26; 4 GiB p-mer
       vector, global tables of ~10^9 slots -- far beyond the 256 MB Infinity Cache), per-block DNA digests, plus an
       encode -> decode round trip of the file's first blocks on the GPU and the table-capacity figures.
+c21 = SURVEY 8d-4's check of configs[3]: a 5 M-read prefix of its own file -- reads of a G = 3.1 Gbp genome at the reference's
+      DEFAULT geometry `-gs 3100` (k = 13/18/21/27, 16 GiB p-mer vector), T = 8: per-block DNA digests of the reference's file, an
+      encode -> decode round trip of the first blocks, capacity figures.  (tests/test_gpu_sharded.py runs it over four ranks.)
 The inputs are re-generated from their seeds (fqsqueezer_amd.synth); the sorted order comes from the GPU pre-pass.
-Set FQSX_FULLSIZE_BLOCKS=<n> to stop after n blocks (a quicker, weaker run)."""
+Set FQSX_FULLSIZE_BLOCKS=<n> to stop after n blocks (a quicker, weaker run).  c18 and c21 (T = 8: eight workgroups) stop after
+64 blocks unless FQSX_SLOW=1 (c18: all 256 blocks + the file's SHA-256, 218 s; c21: all 256 blocks, 175 s -- both run in full in
+round 4, profiles/r04_c21_full_tests.txt; the driver's suite has 900 s for everything)."""
 import hashlib
 import json
 import os
@@ -19,6 +24,8 @@ from fqsqueezer_amd import hostpipe as hp
 
 pytestmark = pytest.mark.gpu
 LIMIT = int(os.environ.get("FQSX_FULLSIZE_BLOCKS", "0")) or None
+C18_LIMIT = LIMIT if LIMIT is not None or os.environ.get("FQSX_SLOW") == "1" else 64
+C21_LIMIT = C18_LIMIT   # (T = 8: eight workgroups on the chip; all 256 blocks take 175 s -- profiles/r04_c21_full_tests.txt)
 
 
 def _need(name):
@@ -45,8 +52,9 @@ def c19_input():
     return rec, hp.form_blocks(rec, "se_sorted", groups=groups)
 
 
-def _run_c19(c19_input, name, roundtrip_blocks):
+def _run_c19(c19_input, name, roundtrip_blocks, min_kmers=2e8, limit=LIMIT):
     from fqsqueezer_amd.codec import DnaCodec
+    LIMIT = limit
     d = _need(name)
     rec, blks = c19_input
     header = bytes.fromhex(d["header"])
@@ -75,7 +83,7 @@ def _run_c19(c19_input, name, roundtrip_blocks):
         assert total == d["dna_bytes"]
     cap = enc.capacity()
     # the tables hold what was inserted: every distinct canonical k-mer once (genome both strands ~ 2 x 3e8 minus repeats, plus error k-mers)
-    assert cap["bmers"] > 2e8 and cap["smers"] > 2e8 and cap["bytes_per_bmer"] <= 48
+    assert cap["bmers"] > min_kmers and cap["smers"] > min_kmers and cap["bytes_per_bmer"] <= 48
     print(f"{name}: {cap}")
     return enc
 
@@ -87,6 +95,23 @@ def test_c19_10M_reads_gs300_t64_matches_reference_and_round_trips(c19_input):
 @pytest.mark.skipif(os.environ.get("FQSX_SLOW") != "1", reason="T = 8 puts eight workgroups on the chip: minutes; set FQSX_SLOW=1")
 def test_c19_10M_reads_gs300_t8_matches_reference(c19_input):
     _run_c19(c19_input, "c19_10M150_gs300_s_t8.json", roundtrip_blocks=0)
+
+
+@pytest.fixture(scope="module")
+def c21_input():
+    from fqsqueezer_amd.codec import sort_order
+    d = _need("c21_5M150_G3100_gs3100_s_t8.json")
+    rec = _se_records(d)
+    n, L = rec.seq.shape
+    groups = sort_order(rec.seq.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    return rec, hp.form_blocks(rec, "se_sorted", groups=groups)
+
+
+def test_c21_configs3_prefix_G3100Mbp_gs3100_matches_reference_and_round_trips(c21_input):
+    """BASELINE configs[3] at its own geometry with tables that FILL: 5 M x 150 bp of a 3.1 Gbp genome (0.24x coverage: nearly every
+    k-mer is new, ~6.5e8 distinct s- and b-mers each), default -gs 3100.  Every block equals the reference's."""
+    enc = _run_c19(c21_input, "c21_5M150_G3100_gs3100_s_t8.json", roundtrip_blocks=2 if C21_LIMIT else 8, min_kmers=5e8 if C21_LIMIT is None else 1e8, limit=C21_LIMIT)
+    enc.close()
 
 
 def test_c18_paired_end_5M_pairs_q8_matches_reference_file():
@@ -109,7 +134,7 @@ def test_c18_paired_end_5M_pairs_q8_matches_reference_file():
         file_h.update(chunk)
         file_n += len(chunk)
         g += 1
-        if LIMIT is not None and g > LIMIT:
+        if C18_LIMIT is not None and g > C18_LIMIT:
             return
     assert g - 1 == d["n_blocks"]
     assert file_n == d["file_bytes"] and file_h.hexdigest() == d["file_sha256"]

@@ -44,3 +44,23 @@ def test_two_ranks_gloo(tmp_path, built):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "MULTIRANK_OK" in r.stdout
+
+
+def test_bench_py_sharded_line_two_ranks_gloo(built):
+    """`torchrun --nproc-per-node=2 bench.py --gpus 2` -- the command line the driver uses for N > 1 -- takes the sharded, partitioned
+    path (one file over the ranks, strong scaling).  Rehearsed here on CPUs: FQSX_BENCH_EMU swaps RCCL for gloo and the HIP
+    kernels for their emulation build; everything else (argument defaults, the phase loop inside the library with its three
+    collectives, partitioned tables with descriptor passing, the JSON line) is the code the GPU run executes."""
+    import json
+    env = dict(os.environ, FQSX_BENCH_EMU=os.path.join(ROOT, "tests", "emu", "libfqsx_emu.so"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29518", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--reads", "3000", "--len", "90", "--genome", "40000", "--gs", "1", "--threads", "4"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1000:] + r.stderr[-3000:])
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["partitioned_tables"] is True
+    assert "ONE file sharded over 2" in line["config"]["workload"] and "EMULATION" in line["data"]
+    held = [x["table_bytes_held"] for x in line["per_rank"]]
+    assert len(held) == 2 and min(held) > 0 and abs(held[0] - held[1]) <= max(held) // 2, held   # each rank holds its owners' share
+    assert line["exchange_rank0_per_file"]["all_to_all_bytes"] > 0 and 0 < line["bits_per_base"] < 2.5
