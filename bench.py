@@ -63,6 +63,7 @@ def main() -> None:
     ap.add_argument("--no-t255", action="store_true", help="skip the extra pass with 255 workers")
     ap.add_argument("--concurrent", type=int, default=4, help="extra pass: this many codec instances at once (0/1 = skip)")
     ap.add_argument("--no-rows", action="store_true", help="skip the extra passes over the other rows (decoder, quality, PE, original order)")
+    ap.add_argument("--no-large", action="store_true", help="skip the extra pass over the large file (10 M x 150 bp, G = 300 Mbp, -gs 300: tables of GBs)")
     ap.add_argument("--chunked-tables", action="store_true",
                     help="the capacity mode (fqsx_dna_use_chunked_tables): k-mer tables in per-sub-table chunks, growth without old + new side by side")
     ap.add_argument("--partition", action="store_true",
@@ -203,6 +204,11 @@ def main() -> None:
                 "launches": dom_launches, "avg_launch_ms": round(dom_s * 1e3 / max(1, dom_launches), 4),
                 "algorithmic_bytes_per_launch": round(dom_bytes / max(1, dom_launches), 1),
                 "encode_kernel_s": round(enc_s, 4), "insert_kernel_s": round(ins_s, 4),
+                "bytes_the_kernel_reads": {"achieved": round((dom_bytes - 8.0 * st.get("siv_saved", 0)) / dom_s / 1e9, 3), "unit": "GB/s",
+                                           "frac": round((dom_bytes - 8.0 * st.get("siv_saved", 0)) / dom_s / 1e9 / 8000.0, 6),
+                                           "per_launch": round((dom_bytes - 8.0 * st.get("siv_saved", 0)) / max(1, dom_launches), 1),
+                                           "note": "the same formula without the p-mer-vector words the count index spares the kernel (siv_saved): what the kernel asks the "
+                                                   "memory system for; `achieved` / `frac` above follow SURVEY 8d literally (the words the ALGORITHM sweeps)"},
                 "probes_per_s": round((st["gprobe"] + st["lprobe"]) / max(enc_s, 1e-9), 1),
                 "siv_words_per_base": {"algorithm": round((st["siv_words"] + st.get("siv_saved", 0)) / max(1, st["bases"]), 2),
                                        "read_by_the_kernels": round(st["siv_words"] / max(1, st["bases"]), 2)}}
@@ -309,6 +315,55 @@ def main() -> None:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_rows
         rows = bench_rows.measure(300_000, a.len, a.threads, local_rank)
+        # HBM traffic of the rows' kernels from separate rocprofv3 --pmc passes of tools/bench_rows.py (profiles/r0N_rows_traffic.json), if recorded
+        for tf2 in ("r04_rows_traffic.json", "r03_rows_traffic.json"):
+            tp = os.path.join(ROOT, "profiles", tf2)
+            if not os.path.exists(tp):
+                continue
+            try:
+                tk = json.load(open(tp))
+                for row, kern in (("decode", "k_decode_se_sorted"), ("sorted", "k_encode_se_sorted"), ("original_order", "k_encode_se_orig"),
+                                  ("pe_sorted", "k_encode_pe_sorted"), ("quality_o", "k_qual_encode"), ("quality_8", "k_qual_encode")):
+                    kk = tk["kernels"].get(kern + (":" + row if kern == "k_qual_encode" else ""), tk["kernels"].get(kern))
+                    if kk and isinstance(rows.get(row), dict) and "roofline" in rows[row]:
+                        rows[row]["roofline"]["traffic"] = kk["bytes_per_launch"]
+                        rows[row]["roofline"]["traffic_source"] = f"profiles/{tf2} ({tk.get('build', '?')}): separate --pmc FETCH_SIZE / WRITE_SIZE passes; NOT measured by this run" + \
+                            ("" if kern + ":" + row in tk["kernels"] or kern != "k_qual_encode" else "; -qm o and -qm 8 launches mixed in one pass")
+                break
+            except Exception:   # noqa: BLE001 -- extra information only
+                pass
+
+    # ---- a file whose tables do not fit any cache (the headline file's are 0.5 GB, twice the Infinity Cache): 10 M x 150 bp of a
+    # 300 Mbp genome at -gs 300 (k = 12/17/21/26; the configs[3]-shaped c19 file of tests/test_gpu_fullsize.py), one pass, inputs in HBM
+    large = None
+    if world == 1 and not a.no_large and a.reads == 1_000_000 and a.threads == 64:
+        from fqsqueezer_amd.codec import sort_order
+        lr = synth_reads(10_000_000, 150, 300_000_000, 19)
+        lrec = hp.Records([b""] * 0, lr, lr)
+        lgroups = sort_order(lr.reshape(-1), np.arange(len(lr) + 1, dtype=np.uint64) * np.uint64(150), device=local_rank)
+        lorder = np.concatenate(lgroups)
+        per = -(-len(lr) // 256)
+        loff = np.arange(per + 1, dtype=np.uint64) * np.uint64(150)
+        lblocks = []
+        for i0 in range(0, len(lr), per):
+            idx = lorder[i0:i0 + per]
+            lblocks.append((torch.from_numpy(np.ascontiguousarray(lr[idx]).reshape(-1)).cuda(), torch.from_numpy(loff[:len(idx) + 1].view(np.int64).copy()).cuda(), loff[:len(idx) + 1]))
+        del lgroups, lorder
+        lc = DnaCodec(hp.make_header(64, "se_sorted", 300), device=local_rank)
+        torch.cuda.synchronize()
+        tm = [time.perf_counter()]
+        lbytes = 0
+        for g, (d_b, d_o, off) in enumerate(lblocks):
+            lbytes += lc.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g, collect=False)
+            tm.append(time.perf_counter())
+        lcap = lc.capacity()
+        lc.close()
+        nb_l = 1.5e9
+        large = {"value": round(nb_l / (tm[-1] - tm[0]) / 1e6, 4), "unit": "Mbases/s", "blocks_ge_100_value": round(sum(int(o[-1]) for (_, _, o) in lblocks[100:]) / (tm[-1] - tm[100]) / 1e6, 4),
+                 "bits_per_base": round(8.0 * lbytes / nb_l, 5), "table_bytes_held": lcap["table_bytes_held"], "bytes_per_bmer": lcap["bytes_per_bmer"],
+                 "device_bytes_peak": lcap["device_bytes_peak"], "growths": lcap["growths"],
+                 "workload": "10000000x150bp SE, G=300000000 (seed 19), -om s -gs 300, T=64, 256 blocks of the sorted order; one timed pass, inputs resident in HBM"}
+        del lblocks, lr, lrec
 
     # ---- CPU baseline on a bounded sample of the same workload (rank 0, N=1 only)
     cpu = None
@@ -322,7 +377,7 @@ def main() -> None:
         "config": {"workload": f"{a.reads}x{a.len}bp SE, G={a.genome} (seed 2+rank), -om s -gs {a.gs} -qm n -im n",
                    "workers_T": a.threads, "blocks": len(blocks), "per_gpu": "one independent file per GPU" + (" (--replicas)" if world > 1 else "")},
         "bits_per_base": round(8.0 * dna_bytes / n_bases, 5), "steady_state": steady, "pcie_inclusive_mbases_s": pcie, "workers_255": t255, "concurrent_files": conc,
-        "capacity": cap_line, "other_rows": rows, "roofline": roofline, "cpu_baseline": cpu,
+        "capacity": cap_line, "large_file": large, "other_rows": rows, "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
     if world > 1:

@@ -154,7 +154,7 @@ FQ_DEV void part_dstoff_leader(const DevCfg &cfg, u32 kind, u32 *demand, u32 seg
   if (seg1 && kind != MAIL_P) {   // the host's growth rule (block_segment): occupancy after the inserts <= cap / 2
     const KTab &t = kind == MAIL_S ? cfg.g_s : cfg.g_b;
     bool over = false;
-    for (u32 d = FQ_LANE; d < cfg.T; d += FQ_WAVE) over |= ((u64)t.filled[d] + cfg.mail[kind].dst_tot[d]) * 2 > t.cap_mask + 1;
+    for (u32 d = FQ_LANE; d < cfg.T; d += FQ_WAVE) over |= ((u64)t.filled[d] + cfg.mail[kind].dst_tot[d]) * 100 > t.nb * FQSX_BKT * cfg.tab_load_pct;
     if (wave_any(over) && FQ_LANE == 0) cfg.err[1] = seg1;
   }
 }
@@ -276,7 +276,7 @@ FQ_KERNEL void k_zero_words(u64 *p, u64 n, u32 sys) {
 }
 // (sub-tables first, first + step, ...: all of them on one GPU; a rank's own ones when the tables are partitioned)
 FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub, u32 first, u32 step, u32 sys) {
-  const u64 ocap = o.cap_mask + 1;
+  const u64 ocap = o.nb * FQSX_BKT;
   const u64 total = ocap * n_sub;
 #ifndef FQSX_EMU
   const u64 gstride = (u64)gridDim.x * blockDim.x;
@@ -287,12 +287,8 @@ FQ_KERNEL void k_rehash_ktab(KTab o, KTab n, u32 n_sub, u32 first, u32 step, u32
     u32 sub = first + (u32)(g / ocap) * step;
     u64 it = o.slots[(u64)sub * o.stride + (g % ocap)];
     if (!it) continue;
-    u64 *s = n.slots + (u64)sub * n.stride;
-    u64 p = tab_home(n, it >> n.cbits);
-    for (;;) {
-      if (s[p] == 0 && atomic_cas64(&s[p], 0, it) == 0) break;
-      p = (p + 1) & n.cap_mask;
-    }
+    bool claimed = false;
+    (void)tab_find_or_claim(n, n.slots + (u64)sub * n.stride, it >> n.cbits, it, claimed);
   }
   if (sys) fq_release_system();   // (the new chunks are mapped by the other ranks next: k_zero_words)
 }
@@ -502,14 +498,7 @@ FQ_KERNEL void k_shard_collect(DevCfg cfg, u32 kind, u64 *out) {
     if (kind == MAIL_P) { out[e] = (x << 2) | siv_test(&cfg, x); continue; }
     const KTab &t = kind == MAIL_S ? cfg.g_s : cfg.g_b;
     const u64 *sl = t.slots + (u64)sb_owner(&cfg, x) * t.stride;
-    const u64 v = x >> (64 - 2 * t.k);
-    u64 p = tab_home(t, v), item = 0;
-    for (u64 n = 0; n <= t.cap_mask; ++n) {
-      const u64 it = sl[p];
-      if (!it) break;
-      if ((it >> t.cbits) == v) { item = it; break; }
-      p = (p + 1) & t.cap_mask;
-    }
+    const u64 item = tab_locate(t, sl, x >> (64 - 2 * t.k)).item;
     out[e] = item;
   }
 }
@@ -539,32 +528,22 @@ FQ_KERNEL void k_shard_apply(DevCfg cfg, u32 kind, const u64 *items, u32 n) {
     const KTab &t = kind == MAIL_S ? cfg.g_s : cfg.g_b;
     const u64 v = item >> t.cbits;
     const u32 sub = sb_owner(&cfg, v << (64 - 2 * t.k));
-    u64 *sl = t.slots + (u64)sub * t.stride;
-    u64 p = tab_home(t, v);
-    for (u64 k = 0; k <= t.cap_mask; ++k) {
-      u64 it = sl[p];
-      if (!it) {
-        const u64 seen = atomic_cas64(&sl[p], 0, item);
-        if (seen == 0) {
+    bool claimed = false;
+    u64 *slot = tab_find_or_claim(t, t.slots + (u64)sub * t.stride, v, item, claimed);
+    if (!slot) continue;
+    if (claimed) {
 #ifndef FQSX_EMU
-          atomicAdd(&t.filled[sub], 1u);
+      atomicAdd(&t.filled[sub], 1u);
 #else
-          t.filled[sub] += 1;
+      t.filled[sub] += 1;
 #endif
-          break;
-        }
-        it = seen;
-      }
-      if ((it >> t.cbits) == v) {   // (counts of a k-mer only grow: the larger value is the later one)
-        u64 old = it;
-        while ((old & ((1ull << t.cbits) - 1ull)) < (item & ((1ull << t.cbits) - 1ull))) {
-          const u64 seen = atomic_cas64(&sl[p], old, item);
-          if (seen == old) break;
-          old = seen;
-        }
-        break;
-      }
-      p = (p + 1) & t.cap_mask;
+      continue;
+    }
+    u64 old = *(volatile u64 *)slot;   // (counts of a k-mer only grow: the larger value is the later one)
+    while ((old & ((1ull << t.cbits) - 1ull)) < (item & ((1ull << t.cbits) - 1ull))) {
+      const u64 seen = atomic_cas64(slot, old, item);
+      if (seen == old) break;
+      old = seen;
     }
   }
 }
@@ -612,6 +591,8 @@ struct fqsx_dna {
   std::vector<u64> alloc_bytes;   // size of allocs[i]
   u64 dev_bytes, dev_bytes_peak;  // device memory held now / at most so far (fqsx_dna_capacity)
   u32 n_growths;                  // growth events of the global k-mer / pair tables
+  u32 tab_load_pct, tab_after_pct;   // a global k-mer sub-table is grown before an insert phase would fill it beyond load_pct %, to a
+                                     // capacity the demand fills to after_pct % (FQSX_TAB_LOAD_PCT / FQSX_TAB_AFTER_PCT; 80 / 62)
   u8 *h_pin;          // pinned host scratch for the small device-to-host transfers of the phase loop
   u64 *d_end;         // block epilogue in one transfer: [T] stream lengths, [T] context-table occupancies, error word
   bool filled_valid;  // h_filled holds the context-table occupancies as of the end of the last encoded block
@@ -810,6 +791,16 @@ u64 pow2_at_least(u64 x) {
   return p;
 }
 
+// growth policy of the global k-mer tables (bucketed two-hash probing, fqsx_layout.h: KTab)
+bool tab_over(const fqsx_dna *c, u64 need, u64 cap) { return need * 100 > cap * c->tab_load_pct; }
+u64 tab_new_cap(const fqsx_dna *c, u64 need) {
+  // (while a table is small its density is nobody's concern, but every growth stops the block's queue and costs a host round trip:
+  // below 256 MB it grows to 40 % load, i.e. doubles)
+  const u32 after = need * c->T * sizeof(u64) * 100 / 40 < (256ull << 20) ? std::min<u32>(40u, c->tab_after_pct) : c->tab_after_pct;
+  u64 cap = (need * 100 + after - 1) / after + 2 * FQSX_BKT;
+  return (cap + FQSX_BKT - 1) / FQSX_BKT * FQSX_BKT;
+}
+
 KGeom make_geom(u32 k) {  // kmer.h:279-298
   KGeom g;
   g.k = k;
@@ -830,7 +821,7 @@ int ktab_alloc(fqsx_dna *c, KTab &t, u32 n_sub, u64 cap, u32 k, u32 cbits, bool 
   int rc = dalloc(c, &p, cap * n_sub * sizeof(u64), true);
   if (rc) return rc;
   t.slots = (u64 *)p;
-  t.cap_mask = cap - 1;
+  t.nb = cap / FQSX_BKT;   // (cap: a multiple of FQSX_BKT, at least two buckets)
   t.stride = cap;
   t.k = k;
   t.cbits = cbits;
@@ -879,7 +870,9 @@ int vtab_reserve(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 c
 #else
   const u64 min_chunk = c->vm_gran;
 #endif
-  const u64 stride = std::max<u64>(cap, min_chunk / sizeof(u64));   // (both powers of two: a sub-table is whole chunks)
+  // (a sub-table is one chunk: its capacity rounded up to the chunk granule -- at most 2 MiB of slack per sub-table)
+  const u64 gran_slots = min_chunk / sizeof(u64);
+  const u64 stride = (cap + gran_slots - 1) / gran_slots * gran_slots;
   v = fqsx_dna::VmTab();
   v.chunk_bytes = stride * sizeof(u64);
   v.va_bytes = v.chunk_bytes * T;
@@ -889,7 +882,7 @@ int vtab_reserve(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 c
   VMCHK(fqsx_vm::reserve(v.va_bytes, std::max<u64>(c->vm_gran, std::min<u64>(v.chunk_bytes, 2ull << 20)), &v.va, e_));
   v.live = true;
   t.slots = (u64 *)v.va;
-  t.cap_mask = cap - 1;
+  t.nb = cap / FQSX_BKT;
   t.stride = stride;
   t.k = k;
   t.cbits = cbits;
@@ -1183,8 +1176,8 @@ int block_prepare(fqsx_dna *c, const u8 *d_bases, const u64 *d_off, const u64 *h
     }
   }
   // active geometry of the local tables for this block (cleared after every phase)
-  cfg.l_b.cap_mask = need_lb - 1; cfg.l_b.stride = need_lb;
-  cfg.l_s.cap_mask = need_ls - 1; cfg.l_s.stride = need_ls;
+  cfg.l_b.nb = need_lb / FQSX_BKT; cfg.l_b.stride = need_lb;
+  cfg.l_s.nb = need_ls / FQSX_BKT; cfg.l_s.stride = need_ls;
   // ---- context tables: every coded symbol creates at most two contexts
   if (!c->filled_valid && (rc = d2h_sync(c, c->h_filled.data(), cfg.ctx_filled, T * sizeof(u32)))) return rc;
   c->filled_valid = false;
@@ -1261,7 +1254,7 @@ int grow_for_demand(fqsx_dna *c) {
     u64 &cap = which ? c->gb_cap : c->gs_cap;
     u64 need = 0;
     for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_demand[2 * T + 1 + which * T + o] + c->h_demand[which * T + o]);
-    if (need * 2 > cap && (rc = grow_global(c, t, cap, pow2_at_least(need * 2 + 2)))) return rc;
+    if (tab_over(c, need, cap) && (rc = grow_global(c, t, cap, tab_new_cap(c, need)))) return rc;
   }
   return FQSX_OK;
 }
@@ -1457,10 +1450,15 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   if ((rc = dalloc(c, &p, ((1ull << (2 * cfg.pmer)) >> FQSX_SIV_BLK_LOG) * 4 * sizeof(u32), true))) return rc;   // count index: all fields zero
   cfg.siv_idx = (u32 *)p;
   // owner-sharded global tables (application.cpp:87-88; counters defs.h:26-27)
+  c->tab_load_pct = 80; c->tab_after_pct = 62;
+  if (const char *e = getenv("FQSX_TAB_LOAD_PCT")) c->tab_load_pct = (u32)std::min<u64>(85, std::max<u64>(20, strtoull(e, nullptr, 10)));
+  if (const char *e = getenv("FQSX_TAB_AFTER_PCT")) c->tab_after_pct = (u32)std::min<u64>(c->tab_load_pct - 5, std::max<u64>(10, strtoull(e, nullptr, 10)));
+  cfg.tab_load_pct = c->tab_load_pct;
   c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(1024, (1ull << 22) / T));
   if (const char *e = getenv("FQSX_GTAB_INIT")) c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(64, strtoull(e, nullptr, 10)));   // (tests: growth from tiny tables)
   if ((rc = ktab_alloc(c, cfg.g_s, T, c->gs_cap, cfg.smer, 12, true))) return rc;
   if ((rc = ktab_alloc(c, cfg.g_b, T, c->gb_cap, cfg.bmer, 6, true))) return rc;
+  cfg.g_s.two = cfg.g_b.two = 1;   // two-choice buckets (a growth copies the descriptor, the kind with it); the local tables: one sequence
   // local tables: geometry chosen per block; counters allocated here
   c->ls_cap = c->lb_cap = 1024;
   if ((rc = ktab_alloc(c, cfg.l_s, T, c->ls_cap, cfg.smer, 12, false))) return rc;
@@ -1869,8 +1867,8 @@ int fqsx_shard_insert(fqsx_dna *c, uint64_t need_s, uint64_t need_b, uint64_t *c
   const u32 T = c->T;
   DevCfg &cfg = c->cfg;
   int rc;
-  if (need_s * 2 > c->gs_cap && (rc = grow_global(c, cfg.g_s, c->gs_cap, pow2_at_least(need_s * 2 + 2)))) return rc;
-  if (need_b * 2 > c->gb_cap && (rc = grow_global(c, cfg.g_b, c->gb_cap, pow2_at_least(need_b * 2 + 2)))) return rc;
+  if (tab_over(c, need_s, c->gs_cap) && (rc = grow_global(c, cfg.g_s, c->gs_cap, tab_new_cap(c, need_s)))) return rc;
+  if (tab_over(c, need_b, c->gb_cap) && (rc = grow_global(c, cfg.g_b, c->gb_cap, tab_new_cap(c, need_b)))) return rc;
   if ((rc = d2h_sync(c, c->siv_before, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
   LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
   u64 after[2];
@@ -2026,7 +2024,7 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
     for (u32 s = 0; s < T; ++s) { pe_tot[s % G] += C[3ull * T * T + s]; PM = std::max(PM, pe_tot[s % G]); }
   const u64 off_k[3] = {0, M[0], M[0] + M[1]}, off_siv = M[0] + M[1] + M[2], off_fill = off_siv + 2, off_pe = off_fill + FW, W = off_pe + 3 * PM;
   // ---- allocations and growths of this phase, if any (every rank answers alike: see shard_vote), then the vote
-  const bool grow_s = small[0] * 2 > c->gs_cap, grow_b = small[1] * 2 > c->gb_cap;
+  const bool grow_s = tab_over(c, small[0], c->gs_cap), grow_b = tab_over(c, small[1], c->gb_cap);
   // (tests: FQSX_TEST_FAIL="rank,phase" -- that rank reports a failed allocation in that phase, which every rank then treats as
   // an allocating one: all of them must come back with an error, none may be left waiting in a collective)
   int inj_rank = -1, inj_phase = -1;
@@ -2041,8 +2039,8 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
     if (!fail) fail = xbuf_fit(c, c->d_gathered, c->gathered_cap, W * G);
     // growth: every rank sees the same demand (the replicas are exact / the occupancies are exchanged); nobody looks a k-mer
     // up between collective 1 and the end of the phase, so the tables can be rebuilt here as well as before the inserts
-    if (!fail && grow_s) fail = grow_global(c, cfg.g_s, c->gs_cap, pow2_at_least(small[0] * 2 + 2));
-    if (!fail && grow_b) fail = grow_global(c, cfg.g_b, c->gb_cap, pow2_at_least(small[1] * 2 + 2));
+    if (!fail && grow_s) fail = grow_global(c, cfg.g_s, c->gs_cap, tab_new_cap(c, small[0]));
+    if (!fail && grow_b) fail = grow_global(c, cfg.g_b, c->gb_cap, tab_new_cap(c, small[1]));
     if (fail && c->part) fqsx_vm::mesh_close(c->mesh);   // (ranks waiting for this rank's descriptors fail instead of timing out)
     if ((rc = shard_vote(c, fail, "the allocations / table growth of a phase"))) return rc;
   }

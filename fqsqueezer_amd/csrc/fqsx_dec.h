@@ -235,10 +235,11 @@ FQ_DEV void suffix_dec(Wk &w, u8 *codes, u8 *p_out, u32 size, bool original_orde
   WgShared *sm = w.sm;
   u64 ctx_r_sym = 0;
   // The cluster a b-mer look-up starts in is fixed by the k-mer's kernel (symbols 2 .. k-3), so the look-up of position
-  // i + 1 -- sub-table, home slot, orientation -- is known before symbol i is decoded: its first two slots are requested
+  // i + 1 -- sub-table, home slot, orientation -- is known before symbol i is decoded: its two buckets are requested
   // while the context search and the range decoder of position i run, and matched against the full k-mer afterwards.
-  TabIt nf;
-  nf.s = nullptr; nf.p = 0; nf.it0 = nf.it1 = 0;
+  TabG nf;
+  nf.s = nullptr; nf.a = nf.b = 0;
+  for (u32 x = 0; x < FQSX_BKT; ++x) { nf.ia[x] = 0; nf.ib[x] = 0; }
   for (u32 i = start_pos ? start_pos : original_order ? cfg->prefix : cfg->pmer; i < size && !w.err; ++i) {
     km_insert_zero(w.pm, cfg->gp); km_insert_zero(w.sm_, cfg->gs); km_insert_zero(w.bm, cfg->gb);
     km_insert_zero(w.pm_u, cfg->gp); km_insert_zero(w.sm_u, cfg->gs); km_insert_zero(w.bm_u, cfg->gb);
@@ -252,7 +253,7 @@ FQ_DEV void suffix_dec(Wk &w, u8 *codes, u8 *p_out, u32 size, bool original_orde
       const u64 *sl = cfg->g_b.slots + (u64)sub * cfg->g_b.stride;
       u64 ns = 0;
       c4_zero(counts);
-      if (nf.s == sl && nf.p == tab_home(cfg->g_b, key >> (64 - 2 * cfg->g_b.k))) tab_rest(cfg->g_b, nf, key, nd, counts, ns);
+      if (nf.s == sl && nf.a == tab_home(cfg->g_b, key >> (64 - 2 * cfg->g_b.k)).a) tab_rest(cfg->g_b, nf, key, nd, counts, ns);
       else tab_scan(cfg->g_b, sub, key, nd, counts, ns);   // (a correction changed the k-mer's kernel: ask again)
       w.st[ST_GPROBE] += 1;
       w.st[ST_GSLOT] += ns;
@@ -273,7 +274,7 @@ FQ_DEV void suffix_dec(Wk &w, u8 *codes, u8 *p_out, u32 size, bool original_orde
       Kmer nb = w.bm;
       km_insert_zero(nb, cfg->gb);
       const u64 nkey = km_norm_dir(nb, cfg->gb) ? nb.dir : nb.rc;
-      nf = tab_first(cfg->g_b, sb_owner(cfg, nkey), nkey);
+      nf = tab_first_g(cfg->g_b, sb_owner(cfg, nkey), nkey);
     }
     TM_END(w, TM_FINDC, t_fc);
     TM_BEGIN(t_rg);

@@ -476,96 +476,266 @@ FQ_DEV u32 kmer_mix(u64 kern) {
   x ^= x >> 16;
   return x;
 }
-FQ_DEV u64 tab_home(const KTab &t, u64 v) {
-  u64 kern = (v >> 4) & ((1ull << (2 * t.k - 8)) - 1ull);
-  return (u64)kmer_mix(kern) & t.cap_mask;
+FQ_DEV u32 kmer_mix2(u32 h) {   // the second bucket of a k-mer: an independent hash of the first
+  h *= 0x9E3779B1u;
+  h ^= h >> 15; h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  return h;
 }
-// one cluster scan: counts of the 4 sibling k-mers (_update_counts_full, ht_kmer.h:205-263), in two parts so that a
-// caller can have the first round trips of several independent scans in flight at once: tab_first issues the loads
-// of the first two slots, tab_rest consumes them and walks on while the cluster continues.
-struct TabIt { const u64 *s; u64 p, it0, it1; };
-FQ_DEV TabIt tab_first(const KTab &t, u32 sub, u64 kmer_norm) {
-  TabIt r;
-  r.s = t.slots + (u64)sub * t.stride;
-  r.p = tab_home(t, kmer_norm >> (64 - 2 * t.k));
-  r.it0 = r.s[r.p];
-  r.it1 = r.s[(r.p + 1) & t.cap_mask];
+struct TabHome { u32 a, b; };
+FQ_DEV TabHome tab_home(const KTab &t, u64 v) {
+  const u64 kern = (v >> 4) & ((1ull << (2 * t.k - 8)) - 1ull);
+  const u32 h = kmer_mix(kern);
+  TabHome r;
+  r.a = (u32)(((u64)h * t.nb) >> 32);              // (fastrange: any number of buckets)
+  if (t.two) {
+    r.b = (u32)(((u64)kmer_mix2(h) * t.nb) >> 32);
+    if (r.b == r.a) r.b = (u64)r.a + 1 == t.nb ? 0u : r.a + 1u;
+  } else
+    r.b = (u64)r.a + 1 == t.nb ? 0u : r.a + 1u;    // one sequence: a, a + 1, a + 2, ...
   return r;
 }
-FQ_DEV void tab_rest(const KTab &t, const TabIt &f, u64 kmer_norm, bool is_dir, C4 &c, u64 &nslots) {
-  const u64 *s = f.s;
+// the bucket after p (p != a) in the overflow chain b, b + 1, b + 2, ... (a is never visited twice)
+FQ_DEV u32 tab_next(const KTab &t, u32 a, u32 p) {
+  u32 q = (u64)p + 1 == t.nb ? 0u : p + 1u;
+  if (q == a) q = (u64)q + 1 == t.nb ? 0u : q + 1u;
+  return q;
+}
+struct alignas(16) Slot2 { u64 x, y; };
+FQ_DEV void tab_load_bucket(const u64 *s, u32 bk, u64 it[FQSX_BKT]) {   // one 32-byte access (two 16-byte halves)
+  const Slot2 *p = (const Slot2 *)__builtin_assume_aligned(s + (u64)bk * FQSX_BKT, 32);
+  const Slot2 lo = p[0], hi = p[1];
+  it[0] = lo.x; it[1] = lo.y; it[2] = hi.x; it[3] = hi.y;
+}
+// The sibling group's counts out of one bucket (_update_counts_full, ht_kmer.h:205-263).  A wave issues one instruction every
+// four to five cycles, and a look-up examines eight slots whichever of them are occupied (64 lanes, 64 different buckets), so
+// the per-slot work is kept to a dozen instructions: one masked 64-bit compare decides "same sibling group" for either
+// orientation, the matching slot's count is added into a packed accumulator (4 x 16 bits: a sibling is stored once and a count
+// has at most 12 bits), free slots need no test of their own (their count bits are zero).
+struct TabQ { u64 mask, want; u32 sh, flip, cm; };
+FQ_DEV TabQ tab_query(const KTab &t, u64 kmer_norm, bool is_dir) {
   const u32 k2 = 2 * t.k;
   const u64 v = kmer_norm >> (64 - k2);
-  u64 p = f.p;
-  const u64 cm = (1ull << t.cbits) - 1ull;
-  const u64 lowmask = (1ull << (k2 - 2)) - 1ull;
-  const u64 grp = is_dir ? (v >> 2) : (v & lowmask);
-  u64 it0 = f.it0, it1 = f.it1;
-  for (u64 n = 0;; n += 2) {
-    // two consecutive slots per round trip (independent loads); most clusters end within them
-    ++nslots;
-    if (!it0) break;
-    u64 iv = it0 >> t.cbits;
-    if (is_dir) {
-      if ((iv >> 2) == grp) c4_add(c, (u32)(iv & 3), (u32)(it0 & cm));
-    } else {
-      if ((iv & lowmask) == grp) c4_add(c, 3u - (u32)(iv >> (k2 - 2)), (u32)(it0 & cm));
-    }
-    ++nslots;
-    if (!it1) break;
-    iv = it1 >> t.cbits;
-    if (is_dir) {
-      if ((iv >> 2) == grp) c4_add(c, (u32)(iv & 3), (u32)(it1 & cm));
-    } else {
-      if ((iv & lowmask) == grp) c4_add(c, 3u - (u32)(iv >> (k2 - 2)), (u32)(it1 & cm));
-    }
-    if (n + 2 > t.cap_mask) break;
-    p = (p + 2) & t.cap_mask;
-    it0 = s[p];
-    it1 = s[(p + 1) & t.cap_mask];
+  TabQ q;
+  q.cm = (1u << t.cbits) - 1u;
+  if (is_dir) {   // siblings differ in the LAST symbol: everything above it has to match
+    q.mask = ~0ull << (t.cbits + 2);
+    q.want = (v >> 2) << (t.cbits + 2);
+    q.sh = t.cbits; q.flip = 0;
+  } else {        // ... in the FIRST symbol (of the reverse complement: the letter is complemented)
+    const u64 lowmask = (1ull << (k2 - 2)) - 1ull;
+    q.mask = lowmask << t.cbits;
+    q.want = (v & lowmask) << t.cbits;
+    q.sh = t.cbits + k2 - 2; q.flip = 3;
   }
+  return q;
+}
+// returns the occupied slots of the bucket (it fills from slot 0 up: = the index of its first free slot; FQSX_BKT: full)
+FQ_DEV u32 tab_bucket_acc(const TabQ &q, const u64 it[FQSX_BKT], u64 &acc) {
+  u32 occ = 0;
+#pragma unroll
+  for (u32 j = 0; j < FQSX_BKT; ++j) {
+    occ += it[j] != 0 ? 1u : 0u;
+    const bool m = (it[j] & q.mask) == q.want;
+    const u32 sym = ((u32)(it[j] >> q.sh) & 3u) ^ q.flip;
+    const u64 add = (u64)((u32)it[j] & q.cm) << (16 * sym);
+    acc += m ? add : 0ull;
+  }
+  return occ;
+}
+FQ_DEV void tab_unpack(u64 acc, C4 &c) {
+  c.c[0] += (u32)(acc & 0xffff); c.c[1] += (u32)((acc >> 16) & 0xffff); c.c[2] += (u32)((acc >> 32) & 0xffff); c.c[3] += (u32)(acc >> 48);
+}
+// One look-up in two parts, so that a caller can have the first round trips of several independent look-ups in flight at
+// once: tab_first_* issues the loads, tab_rest consumes them and walks on in the rare case that the buckets are full.
+// Global tables (two-choice): both buckets are fetched together.  Local tables (one sequence, never more than a quarter full): one.
+struct TabG { const u64 *s; u32 a, b; u64 ia[FQSX_BKT], ib[FQSX_BKT]; };
+struct TabL { const u64 *s; u32 a; u64 it[FQSX_BKT]; };
+FQ_DEV TabG tab_first_g(const KTab &t, u32 sub, u64 kmer_norm) {
+  TabG r;
+  r.s = t.slots + (u64)sub * t.stride;
+  const TabHome h = tab_home(t, kmer_norm >> (64 - 2 * t.k));
+  r.a = h.a; r.b = h.b;
+  tab_load_bucket(r.s, r.a, r.ia);
+  tab_load_bucket(r.s, r.b, r.ib);
+  return r;
+}
+FQ_DEV TabL tab_first_l(const KTab &t, u32 sub, u64 kmer_norm) {
+  TabL r;
+  r.s = t.slots + (u64)sub * t.stride;
+  r.a = tab_home(t, kmer_norm >> (64 - 2 * t.k)).a;
+  tab_load_bucket(r.s, r.a, r.it);
+  return r;
+}
+FQ_DEV void tab_rest(const KTab &t, const TabG &f, u64 kmer_norm, bool is_dir, C4 &c, u64 &nslots) {
+  const TabQ q = tab_query(t, kmer_norm, is_dir);
+  u64 acc = 0;
+  const u32 oa = tab_bucket_acc(q, f.ia, acc), ob = tab_bucket_acc(q, f.ib, acc);
+  u32 ns = (oa < FQSX_BKT ? oa + 1 : FQSX_BKT) + (ob < FQSX_BKT ? ob + 1 : FQSX_BKT);   // (slots up to and including each bucket's first free one)
+  if (oa == FQSX_BKT && ob == FQSX_BKT) {   // both full: the overflow chain
+    u32 p = f.b;
+    for (u64 n = 0; n <= t.nb; ++n) {
+      p = tab_next(t, f.a, p);
+      u64 it[FQSX_BKT];
+      tab_load_bucket(f.s, p, it);
+      const u32 oc = tab_bucket_acc(q, it, acc);
+      ns += oc < FQSX_BKT ? oc + 1 : FQSX_BKT;
+      if (oc != FQSX_BKT) break;
+    }
+  }
+  tab_unpack(acc, c);
+  nslots += ns;
+}
+FQ_DEV void tab_rest(const KTab &t, const TabL &f, u64 kmer_norm, bool is_dir, C4 &c, u64 &nslots) {
+  const TabQ q = tab_query(t, kmer_norm, is_dir);
+  u64 acc = 0;
+  u32 oc = tab_bucket_acc(q, f.it, acc);
+  u32 ns = oc < FQSX_BKT ? oc + 1 : FQSX_BKT;
+  if (oc == FQSX_BKT) {
+    u32 p = f.a;
+    for (u64 n = 0; n <= t.nb; ++n) {
+      p = (u64)p + 1 == t.nb ? 0u : p + 1u;
+      u64 it[FQSX_BKT];
+      tab_load_bucket(f.s, p, it);
+      oc = tab_bucket_acc(q, it, acc);
+      ns += oc < FQSX_BKT ? oc + 1 : FQSX_BKT;
+      if (oc != FQSX_BKT) break;
+    }
+  }
+  tab_unpack(acc, c);
+  nslots += ns;
 }
 FQ_DEV void tab_scan(const KTab &t, u32 sub, u64 kmer_norm, bool is_dir, C4 &c, u64 &nslots) {
-  const TabIt f = tab_first(t, sub, kmer_norm);
-  tab_rest(t, f, kmer_norm, is_dir, c, nslots);
+  if (t.two) { const TabG f = tab_first_g(t, sub, kmer_norm); tab_rest(t, f, kmer_norm, is_dir, c, nslots); }
+  else { const TabL f = tab_first_l(t, sub, kmer_norm); tab_rest(t, f, kmer_norm, is_dir, c, nslots); }
+}
+// key v in a bucket: its slot (found_j), and the bucket's occupied slots (= its first free slot; FQSX_BKT: full)
+FQ_DEV void tab_bucket_find(const KTab &t, const u64 it[FQSX_BKT], u64 v, u32 &found_j, u32 &occ, u64 &nslots) {
+  const u64 km = ~0ull << t.cbits, kv = v << t.cbits;
+  found_j = FQSX_BKT; occ = 0;
+#pragma unroll
+  for (u32 j = 0; j < FQSX_BKT; ++j) {
+    occ += it[j] != 0 ? 1u : 0u;
+    if ((it[j] & km) == kv && it[j] != 0) found_j = j;   // (a key is stored once)
+  }
+  nslots += found_j != FQSX_BKT ? found_j + 1 : occ < FQSX_BKT ? occ + 1 : FQSX_BKT;
+}
+FQ_DEV u64 tab_pick(const u64 it[FQSX_BKT], u32 j) {   // it[j] without dynamic indexing (the array lives in registers)
+  u64 r = it[0];
+#pragma unroll
+  for (u32 x = 1; x < FQSX_BKT; ++x) r = j == x ? it[x] : r;
+  return r;
+}
+// Where key v is, or where it goes: its own slot, else -- two-choice tables -- the first free slot of the emptier of its two
+// buckets (ties: the first), else the first free slot along the overflow chain.  pos = slot index relative to s; item = the
+// slot's content (0: free, the key is not in the table).
+// (A function of its own, everything in and out BY VALUE: inlined at its dozen call sites the decode kernels took ten minutes to
+// compile, and the encode / insert kernels ran 2 % slower; a reference parameter of a real function is a scratch round trip.)
+struct TabLoc { u64 pos, item; u32 ns; };
+FQ_DEVN TabLoc tab_locate(const KTab t, const u64 *s, u64 v) {
+  TabLoc R;
+  R.pos = ~0ull; R.item = 0; R.ns = 0;
+  u64 nsl = 0;
+  const TabHome h = tab_home(t, v);
+  u64 ia[FQSX_BKT];
+  tab_load_bucket(s, h.a, ia);
+  u32 fa, oa;
+  bool chain = false;
+  if (t.two) {
+    u64 ib[FQSX_BKT];
+    tab_load_bucket(s, h.b, ib);
+    u32 fb, ob;
+    tab_bucket_find(t, ia, v, fa, oa, nsl);
+    tab_bucket_find(t, ib, v, fb, ob, nsl);
+    if (fa != FQSX_BKT) { R.item = tab_pick(ia, fa); R.pos = (u64)h.a * FQSX_BKT + fa; }
+    else if (fb != FQSX_BKT) { R.item = tab_pick(ib, fb); R.pos = (u64)h.b * FQSX_BKT + fb; }
+    else if (oa != FQSX_BKT || ob != FQSX_BKT) R.pos = oa <= ob ? (u64)h.a * FQSX_BKT + oa : (u64)h.b * FQSX_BKT + ob;   // (oa <= ob and oa full cannot both hold here)
+    else chain = true;
+  } else {
+    tab_bucket_find(t, ia, v, fa, oa, nsl);
+    if (fa != FQSX_BKT) { R.item = tab_pick(ia, fa); R.pos = (u64)h.a * FQSX_BKT + fa; }
+    else if (oa != FQSX_BKT) R.pos = (u64)h.a * FQSX_BKT + oa;
+    else chain = true;
+  }
+  if (chain) {
+    u32 p = t.two ? h.b : h.a;   // the chain behind the full bucket(s)
+    for (u64 n = 0; n <= t.nb; ++n) {
+      p = t.two ? tab_next(t, h.a, p) : ((u64)p + 1 == t.nb ? 0u : p + 1u);
+      u64 it[FQSX_BKT];
+      tab_load_bucket(s, p, it);
+      u32 fj, oc;
+      tab_bucket_find(t, it, v, fj, oc, nsl);
+      if (fj != FQSX_BKT) { R.item = tab_pick(it, fj); R.pos = (u64)p * FQSX_BKT + fj; break; }
+      if (oc != FQSX_BKT) { R.pos = (u64)p * FQSX_BKT + oc; break; }
+    }
+  }
+  R.ns = (u32)nsl;
+  return R;   // (pos == ~0: cannot happen, the tables are never full)
+}
+// The same among concurrent writers (growth re-inserts, replica updates): the slot that holds key v afterwards -- its own, or a
+// free one this thread has claimed with `item` (claimed = true).  A slot another thread takes first counts as occupied and the
+// search goes on; a key ends up in the overflow chain only after both its buckets have been seen full, which they then stay.
+FQ_DEV u64 *tab_find_or_claim(const KTab &t, u64 *s, u64 v, u64 item, bool &claimed) {
+  const TabHome h = tab_home(t, v);
+  claimed = false;
+  u64 ns_ = 0;
+  for (u32 attempt = 0; attempt < 64; ++attempt) {
+    u64 ia[FQSX_BKT], ib[FQSX_BKT];
+    for (u32 j = 0; j < FQSX_BKT; ++j) ia[j] = ((volatile u64 *)s)[(u64)h.a * FQSX_BKT + j];
+    u32 fa, oa, fb = FQSX_BKT, ob = FQSX_BKT;
+    tab_bucket_find(t, ia, v, fa, oa, ns_);
+    if (fa != FQSX_BKT) return s + (u64)h.a * FQSX_BKT + fa;
+    if (t.two) {
+      for (u32 j = 0; j < FQSX_BKT; ++j) ib[j] = ((volatile u64 *)s)[(u64)h.b * FQSX_BKT + j];
+      tab_bucket_find(t, ib, v, fb, ob, ns_);
+      if (fb != FQSX_BKT) return s + (u64)h.b * FQSX_BKT + fb;
+    }
+    if (oa == FQSX_BKT && ob == FQSX_BKT) break;   // full: the chain
+    u64 *slot = oa <= ob ? s + (u64)h.a * FQSX_BKT + oa : s + (u64)h.b * FQSX_BKT + ob;
+    const u64 seen = atomic_cas64(slot, 0, item);
+    if (seen == 0) { claimed = true; return slot; }
+    if ((seen >> t.cbits) == v) return slot;
+    // (somebody else's key went there: look again)
+  }
+  u32 p = t.two ? h.b : h.a;
+  for (u64 n = 0; n <= t.nb; ++n) {
+    p = t.two ? tab_next(t, h.a, p) : ((u64)p + 1 == t.nb ? 0u : p + 1u);
+    for (u32 j = 0; j < FQSX_BKT; ++j) {
+      u64 *slot = s + (u64)p * FQSX_BKT + j;
+      u64 it = *(volatile u64 *)slot;
+      if (!it) {
+        const u64 seen = atomic_cas64(slot, 0, item);
+        if (seen == 0) { claimed = true; return slot; }
+        it = seen;
+      }
+      if ((it >> t.cbits) == v) return slot;
+    }
+  }
+  return nullptr;   // (cannot happen: the tables are never full)
 }
 // exact look-up (count(), ht_kmer.h:330-362,441-453)
 FQ_DEV u32 tab_count(const KTab &t, u32 sub, u64 kmer_norm, u64 &nslots) {
-  const u64 *s = t.slots + (u64)sub * t.stride;
-  u64 v = kmer_norm >> (64 - 2 * t.k);
-  u64 p = tab_home(t, v);
-  for (u64 n = 0; n <= t.cap_mask; ++n) {
-    u64 it = s[p];
-    ++nslots;
-    if (!it) return 0;
-    if ((it >> t.cbits) == v) return (u32)(it & ((1ull << t.cbits) - 1ull));
-    p = (p + 1) & t.cap_mask;
-  }
-  return 0;
+  const TabLoc L = tab_locate(t, t.slots + (u64)sub * t.stride, kmer_norm >> (64 - 2 * t.k));
+  nslots += L.ns;
+  return (u32)(L.item & ((1ull << t.cbits) - 1ull));
 }
 // wave-uniform insert used for the worker-private local tables (insert(), ht_kmer.h:420-438)
 FQ_DEV void tab_insert_uniform(Wk &w, const KTab &t, u32 sub, u64 kmer_norm, u32 rng, const Cinc &ci) {
   u64 *s = t.slots + (u64)sub * t.stride;
-  u64 v = kmer_norm >> (64 - 2 * t.k);
-  u64 p = tab_home(t, v);
+  const u64 v = kmer_norm >> (64 - 2 * t.k);
   const u64 cm = (1ull << t.cbits) - 1ull;
-  for (u64 n = 0; n <= t.cap_mask; ++n) {
-    u64 it = s[p];
-    if (!it) {
-      u32 f = t.filled[sub];
-      if ((u64)f * 10 >= (t.cap_mask + 1) * 9) { w.err = FQSX_ERR_LTAB_FULL; return; }
-      s[p] = (v << t.cbits) | 1ull;  // Increment(0) == 1
-      t.filled[sub] = f + 1;
-      return;
-    }
-    if ((it >> t.cbits) == v) {
-      u32 cnt = (u32)(it & cm);
-      if (cnt < (u32)cm && cinc_inc1(w.sm, rng, ci, cnt) != cnt) s[p] = it + 1;
-      return;
-    }
-    p = (p + 1) & t.cap_mask;
+  const TabLoc L = tab_locate(t, s, v);
+  const u64 p = L.pos, it = L.item;
+  if (p == ~0ull) { w.err = FQSX_ERR_LTAB_FULL; return; }
+  if (!it) {
+    const u32 f = t.filled[sub];
+    if ((u64)f * 10 >= t.nb * FQSX_BKT * 9) { w.err = FQSX_ERR_LTAB_FULL; return; }
+    s[p] = (v << t.cbits) | 1ull;  // Increment(0) == 1
+    t.filled[sub] = f + 1;
+    return;
   }
-  w.err = FQSX_ERR_LTAB_FULL;
+  const u32 cnt = (u32)(it & cm);
+  if (cnt < (u32)cm && cinc_inc1(w.sm, rng, ci, cnt) != cnt) s[p] = it + 1;
 }
 
 // probe the first n entries of the LDS batch (keys/orientations) lane-parallel
@@ -637,7 +807,8 @@ FQ_DEV void insert_keys(const DevCfg &cfg, SM *sm, const KTab &t, u32 sub, const
     u64 touch = 0;
     if (o + FQ_WAVE + FQ_LANE < n) {
       nextk = keys[o + FQ_WAVE + FQ_LANE];
-      touch = touch_load(&s[tab_home(t, nextk >> (64 - 2 * t.k))]);
+      const TabHome th = tab_home(t, nextk >> (64 - 2 * t.k));
+      touch = touch_load(&s[(u64)th.a * FQSX_BKT]) ^ touch_load(&s[(u64)th.b * FQSX_BKT]);
     }
     insert_batch_k(cfg, sm, t, sub, k, n - o < FQ_WAVE ? n - o : FQ_WAVE, rng, ci, nslots, err);
     keep_live(touch);
@@ -1686,12 +1857,14 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
       ok[q] = halves == 2 ? co[q >> 1] : co[q];
       js[q] = halves == 2 ? cj[q >> 1] : cj[q];
     }
-    TabIt f[FQSX_SW];
+    TabG f[FQSX_SW];
     u64 key[FQSX_SW];
     bool nd[FQSX_SW], in[FQSX_SW];
 #pragma unroll
     for (int q = 0; q < (int)FQSX_SW; ++q) {
-      key[q] = 0; nd[q] = false; f[q].s = nullptr; f[q].p = 0; f[q].it0 = 0; f[q].it1 = 0;
+      key[q] = 0; nd[q] = false; f[q].s = nullptr; f[q].a = f[q].b = 0;
+#pragma unroll
+      for (u32 x = 0; x < FQSX_BKT; ++x) { f[q].ia[x] = 0; f[q].ib[x] = 0; }
       const u32 pr = ((u32)q & (halves - 1u)) * FQ_WAVE + lane;   // this lane's probe of the group
       in[q] = ok[q] && pr < n3;
       if (in[q]) {
@@ -1704,7 +1877,7 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
         const u64 rr = (crc & ~(3ull << shr)) + ((3 - sy) << shr);
         nd[q] = (d & g.kernel_mask) < (rr & g.kernel_mask);
         key[q] = nd[q] ? d : rr;
-        f[q] = tab_first(cfg->g_b, sb_owner(cfg, key[q]), key[q]);
+        f[q] = tab_first_g(cfg->g_b, sb_owner(cfg, key[q]), key[q]);
       }
     }
     u64 res[FQSX_SW], hmv[FQSX_SW];
@@ -2256,12 +2429,16 @@ FQ_DEV bool speculate_t(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool revers
       const u64 ks = nds ? sk.dir : sk.rc;
       const bool ndu = km_norm_dir(bu, cfg->gb);
       const u64 ku = ndu ? bu.dir : bu.rc;
-      const TabIt fb = tab_first(cfg->g_b, sb_owner(cfg, key), key);
-      TabIt flb = fb, fs = fb, fls = fb, fu = fb;
+      const TabG fb = tab_first_g(cfg->g_b, sb_owner(cfg, key), key);
+      TabG fs = fb, fu = fb;
+      TabL flb, fls;
+      flb.s = nullptr; flb.a = 0; fls.s = nullptr; fls.a = 0;
+#pragma unroll
+      for (u32 x = 0; x < FQSX_BKT; ++x) { flb.it[x] = 0; fls.it[x] = 0; }
       if (casc && !unc) {   // (after a correction the corrected b-mer mostly hits: those lanes start the cascade only on a miss)
-        flb = tab_first(cfg->l_b, w.tid, key);
-        fs = tab_first(cfg->g_s, sb_owner(cfg, ks), ks);
-        fls = tab_first(cfg->l_s, w.tid, ks);
+        flb = tab_first_l(cfg->l_b, w.tid, key);
+        fs = tab_first_g(cfg->g_s, sb_owner(cfg, ks), ks);
+        fls = tab_first_l(cfg->l_s, w.tid, ks);
       }
       tab_rest(cfg->g_b, fb, key, nd, c, ns);
       ++np;
@@ -2289,10 +2466,10 @@ FQ_DEV bool speculate_t(Wk &w, const u8 *p, u32 size, u32 i0, u32 n, bool revers
         if (casc) {
           xf = SX_VALID;
           if (unc) {   // the four first round trips together, now that they are needed
-            flb = tab_first(cfg->l_b, w.tid, key);
-            fu = tab_first(cfg->g_b, sb_owner(cfg, ku), ku);
-            fs = tab_first(cfg->g_s, sb_owner(cfg, ks), ks);
-            fls = tab_first(cfg->l_s, w.tid, ks);
+            flb = tab_first_l(cfg->l_b, w.tid, key);
+            fu = tab_first_g(cfg->g_b, sb_owner(cfg, ku), ku);
+            fs = tab_first_g(cfg->g_s, sb_owner(cfg, ks), ks);
+            fls = tab_first_l(cfg->l_s, w.tid, ks);
           }
           C4 l;
           c4_zero(l);
@@ -3014,7 +3191,7 @@ FQ_DEV void local_refresh(Wk &w, u32 j0, u32 n) {
     const u64 bd = sb->sp_sdir[2][lane], br = sb->sp_src[2][lane], sd = sb->sp_sdir[1][lane], sr = sb->sp_src[1][lane];
     const bool ndb = (bd & cfg->gb.kernel_mask) < (br & cfg->gb.kernel_mask), nds = (sd & cfg->gs.kernel_mask) < (sr & cfg->gs.kernel_mask);
     const u64 kb = ndb ? bd : br, ks = nds ? sd : sr;
-    const TabIt fb = tab_first(cfg->l_b, w.tid, kb), fs = tab_first(cfg->l_s, w.tid, ks);
+    const TabL fb = tab_first_l(cfg->l_b, w.tid, kb), fs = tab_first_l(cfg->l_s, w.tid, ks);
     u32 xf = sb->sx_flag[lane] & (SX_VALID | SX_UNC | SX_S);
     C4 c;
     c4_zero(c);
@@ -4436,30 +4613,16 @@ FQ_DEV void insert_batch_k(const DevCfg &cfg, SM *sm, const KTab &t, u32 tid, u6
   const u64 cm = (1ull << t.cbits) - 1ull;
   const u32 lane = FQ_LANE;
   const u64 v = lane < n ? mykey >> (64 - 2 * t.k) : 0;
-  const u64 home = tab_home(t, v);
   u32 filled = t.filled[tid];
   for (u32 done = 0; done < n;) {
     u64 pos = 0, item = 0;
     bool act = lane >= done && lane < n, found = false;
     if (act) {
-      // four consecutive slots per round trip (independent loads): a cluster holds up to four siblings, and the lane
-      // with the longest walk sets the pace of the whole batch
-      u64 p = home;
-      bool end = false;
-      for (u64 q = 0; q <= t.cap_mask && !end; q += 4) {
-        u64 it[4];
-#pragma unroll
-        for (u32 j = 0; j < 4; ++j) it[j] = s[(p + j) & t.cap_mask];
-#pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-          if (end) continue;
-          ++nslots;
-          if (!it[j]) end = true;
-          else if ((it[j] >> t.cbits) == v) { found = true; item = it[j]; end = true; }
-          else p = (p + 1) & t.cap_mask;
-        }
-      }
-      pos = p;
+      // the key's own slot, or the free slot it goes to (two-choice: the emptier of its two buckets, both fetched together; the
+      // lane with the longest walk sets the pace of the whole batch)
+      const TabLoc L = tab_locate(t, s, v);
+      pos = L.pos; item = L.item; nslots += L.ns;
+      found = item != 0;
     }
     IB_MARK(0);
     // a new key can also extend a cluster another lane scanned, but that lane then targets a
@@ -4493,7 +4656,7 @@ FQ_DEV void insert_batch_k(const DevCfg &cfg, SM *sm, const KTab &t, u32 tid, u6
 #endif
     IB_MARK(1);
     const u32 n_new = popc64(wave_ballot(act && !found));
-    if ((u64)(filled + n_new) * 10 >= (t.cap_mask + 1) * 9) { err = FQSX_ERR_GTAB_FULL; return; }
+    if ((u64)(filled + n_new) * 10 >= t.nb * FQSX_BKT * 9) { err = FQSX_ERR_GTAB_FULL; return; }
     const u32 cnt = (u32)(item & cm);
     const bool draw = act && found && cnt > ci.thr && cnt < ci.maxv;
     const u64 dm = wave_ballot(draw);

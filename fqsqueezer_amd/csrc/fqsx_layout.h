@@ -28,16 +28,29 @@ struct KGeom {
   u64 mask, kernel_mask;
 };
 
-// One open-addressed table of normalised k-mers: slot = (kmer_right_aligned << cbits) | count,
-// 0 = empty.  Home position = murmur64(kernel) & cap_mask where kernel = symbols 2..k-3, so
-// the 4 (direct) or 4 (rc) sibling k-mers of a look-up sit in one probe cluster
-// (cf. ht_kmer.h:115-130,143-156).  `stride` separates the per-owner sub-tables.
+// One open-addressed table of normalised k-mers: slot = (kmer_right_aligned << cbits) | count, 0 = empty; `stride` separates the
+// per-owner sub-tables.  Round 4: BUCKETS of FQSX_BKT = 4 slots (32 bytes, one aligned access) and, for the global tables, TWO
+// candidate buckets a and b per k-mer -- hashes of its kernel (symbols 2..k-3), so that the 4 (direct) or 4 (rc) sibling k-mers
+// of a look-up share them (cf. ht_kmer.h:115-130,143-156).  A new key goes into the emptier of the two; only when both are full
+// does it go down an overflow chain b + 1, b + 2, ...  Buckets fill from slot 0 up and never lose a key, so a look-up reads a and
+// b -- both loads issued together -- and is done unless both are full (below 1 % of the look-ups at 80 % load).
+// Why: rounds 1-3 probed linearly from one home slot and kept the tables at most half full -- 21.5 bytes of table per stored
+// k-mer where the reference spends 5-6 (ht_kmer.h:34,69,88-112).  A wave probes 64 different k-mers at once and waits for the
+// slowest lane, so what a denser table may not do is add DEPENDENT round trips for some of the lanes: measured on the way, a
+// single sequence a, b, b + 1, ... through 8-slot buckets at 62-80 % load (one access for 7 look-ups in 8, a second one for the
+// rest) ran 12 % slower on the benchmark file and 20 % slower on the 10 M-read file whose tables live in HBM.  Two choices cost
+// a second, independent access per look-up and about twice the comparisons, but no second round trip: 3 % slower on both files
+// (tools/ab_bench.py, gpurun_out r04_ab7 / r04_ab8_10M) at 10-13 bytes per k-mer, growth in steps of x1.3 (the number of buckets
+// is any number >= 2: fastrange instead of a mask).  The workers' local tables (emptied every phase, never more than a quarter
+// full) keep ONE sequence a, a + 1, ... and fetch one bucket (two = 0).
+#define FQSX_BKT 4u
 struct KTab {
   u64 *slots;
-  u64 cap_mask;   // capacity-1 of every sub-table
+  u64 nb;         // buckets of every sub-table (capacity = nb * FQSX_BKT slots; < 2^32)
   u64 stride;     // slots between consecutive sub-tables (>= capacity)
   u32 *filled;    // [n_sub] occupied slots
   u32 k, cbits;
+  u32 two, pad_;  // 1: two-choice (global tables), 0: one sequence (local tables)
 };
 
 // Context slot (32 B): adaptive 5-symbol model + visit counter, keyed by (tag,key).
@@ -196,6 +209,8 @@ struct DevCfg {
   // Sharded mode: worker w -- its coder state, RNG streams, local tables and the sub-tables it owns --
   // lives on rank w % shard_world; every rank holds a read-only replica of all sub-tables.  shard_world == 1: one GPU.
   u32 shard_rank, shard_world;
+  u32 tab_load_pct;            // a global s- / b-mer sub-table is grown before an insert phase would fill it beyond this (host: fqsx_dna.tab_load_pct)
+  u32 pad_tab_;
   u32 sys_scope;               // the s- / b-mer tables are partitioned over more than one rank: sub-tables of other GPUs are read
                                // through peer mappings, so the kernels that write own sub-tables end with a system-scope release and
                                // the kernels that look k-mers up start behind a system-scope acquire (fqsx_plat.h)

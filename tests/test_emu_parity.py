@@ -46,7 +46,8 @@ def test_chunked_tables_grow_sub_table_by_sub_table(name, monkeypatch):
     monkeypatch.setenv("FQSX_CHUNKED_TABLES", "1")
     codec = check_against_fqs(emu, c1_records(), name)
     cap = codec.capacity()
-    assert cap["growths"] >= 4 and cap["table_bytes_held"] == 8 * (cap["smer_slots"] + cap["bmer_slots"])
+    # (a sub-table is one chunk: its capacity -- any number of four-slot buckets -- rounded up to the allocation granule, a page here)
+    assert cap["growths"] >= 4 and 0 <= cap["table_bytes_held"] - 8 * (cap["smer_slots"] + cap["bmer_slots"]) <= 2 * 4 * 4096
     monkeypatch.setenv("FQSX_CHUNKED_TABLES", "0")
     plain = check_against_fqs(emu, c1_records(), name).capacity()
     assert (plain["smers"], plain["bmers"], plain["growths"]) == (cap["smers"], cap["bmers"], cap["growths"])
@@ -62,7 +63,7 @@ def test_tables_turn_into_chunked_tables_at_a_size_by_themselves(monkeypatch):
     monkeypatch.setenv("FQSX_CHUNK_AUTO_KB", "64")
     codec = check_against_fqs(emu, c1_records(), "c1_10k_s_t4.fqs")
     cap = codec.capacity()
-    assert cap["growths"] >= 6 and cap["table_bytes_held"] == 8 * (cap["smer_slots"] + cap["bmer_slots"])
+    assert cap["growths"] >= 6 and 0 <= cap["table_bytes_held"] - 8 * (cap["smer_slots"] + cap["bmer_slots"]) <= 2 * 4 * 4096
     assert cap["device_bytes_peak"] - cap["device_bytes"] < 8 * cap["bmer_slots"] // 4, cap   # (the last growths went sub-table by sub-table)
 
 
