@@ -672,6 +672,25 @@ FQ_DEVN TabLoc tab_locate(const KTab t, const u64 *s, u64 v) {
   R.ns = (u32)nsl;
   return R;   // (pos == ~0: cannot happen, the tables are never full)
 }
+// the same for a one-sequence (local) table, inlined: the inserter wave of a worker runs it for every batch of local inserts, and
+// the wave that resolves the reads waits for that wave whenever a look-up could be changed by an insert still on its way
+FQ_DEV TabLoc tab_locate1(const KTab &t, const u64 *s, u64 v) {
+  TabLoc R;
+  R.pos = ~0ull; R.item = 0; R.ns = 0;
+  u64 nsl = 0;
+  u32 p = tab_home(t, v).a;
+  for (u64 n = 0; n <= t.nb; ++n) {
+    u64 it[FQSX_BKT];
+    tab_load_bucket(s, p, it);
+    u32 fj, oc;
+    tab_bucket_find(t, it, v, fj, oc, nsl);
+    if (fj != FQSX_BKT) { R.item = tab_pick(it, fj); R.pos = (u64)p * FQSX_BKT + fj; break; }
+    if (oc != FQSX_BKT) { R.pos = (u64)p * FQSX_BKT + oc; break; }
+    p = (u64)p + 1 == t.nb ? 0u : p + 1u;
+  }
+  R.ns = (u32)nsl;
+  return R;
+}
 // The same among concurrent writers (growth re-inserts, replica updates): the slot that holds key v afterwards -- its own, or a
 // free one this thread has claimed with `item` (claimed = true).  A slot another thread takes first counts as occupied and the
 // search goes on; a key ends up in the overflow chain only after both its buckets have been seen full, which they then stay.
@@ -4620,7 +4639,7 @@ FQ_DEV void insert_batch_k(const DevCfg &cfg, SM *sm, const KTab &t, u32 tid, u6
     if (act) {
       // the key's own slot, or the free slot it goes to (two-choice: the emptier of its two buckets, both fetched together; the
       // lane with the longest walk sets the pace of the whole batch)
-      const TabLoc L = tab_locate(t, s, v);
+      const TabLoc L = t.two ? tab_locate(t, s, v) : tab_locate1(t, s, v);
       pos = L.pos; item = L.item; nslots += L.ns;
       found = item != 0;
     }

@@ -54,6 +54,13 @@ def encode_blocks(header: bytes, blocks, arrays, sizes_of, paired: bool, device:
             yield blk
         if stats is not None:
             stats["dna"] = dna.stats()
+            stats["dna_capacity"] = dna.capacity()
+            try:   # everything this process holds on the device at the end of the file: DNA tables + quality models + id models + block buffers
+                import torch
+                free, total = torch.cuda.mem_get_info(device)
+                stats["device_bytes_in_use"] = int(total - free)
+            except Exception:   # noqa: BLE001 -- extra information only
+                pass
     finally:
         pool.shutdown(wait=True)
         dna.close()
@@ -64,15 +71,33 @@ def encode_blocks(header: bytes, blocks, arrays, sizes_of, paired: bool, device:
             qual.close()
 
 
-def _encode(header: bytes, blocks, arrays, sizes_of, paired: bool, device: int, lib_path: Optional[str]) -> bytes:
-    return hp.write_fqs(header, encode_blocks(header, blocks, arrays, sizes_of, paired, device, lib_path))
+def _encode(header: bytes, blocks, arrays, sizes_of, paired: bool, device: int, lib_path: Optional[str], gpu_ids: bool = True) -> bytes:
+    return hp.write_fqs(header, encode_blocks(header, blocks, arrays, sizes_of, paired, device, lib_path, gpu_ids=gpu_ids))
+
+
+# the id kernel stages an id line in LDS: lines up to 1024 bytes, 128 tokens, instrument names up to 63 bytes (csrc/fqsx_idk.h:15-17)
+_ID_LINE_MAX, _ID_TOKENS_MAX = 1024, 128
+
+
+def _ids_fit_the_kernel(*recs) -> bool:
+    """False if an id of the file is beyond what the GPU id coder stages (the host coder, like the reference, has no limits):
+    a cheap pre-scan so that the file falls back to the host coder as a whole instead of failing in mid-file."""
+    for rec in recs:
+        for x in rec.ids:
+            if len(x) > _ID_LINE_MAX or len(x) > 64 and sum(ch in b" :._/-|=#" for ch in x) >= _ID_TOKENS_MAX // 2:
+                return False
+    return True
 
 
 def compress_records(rec: hp.Records, threads: int, order: str = "s", genome_size_mbp: int = 3100, device: int = 0,
                      lib_path: Optional[str] = None, quality_mode: str = "none", id_mode: str = "none",
-                     quality_thr: int = 20, as_blocks: bool = False):
+                     quality_thr: int = 20, as_blocks: bool = False, gpu_ids: Optional[bool] = None):
     """`fqs e -s -om <order> -t <threads> -gs <g> -qm <..> -im <..>` on single-end records.  Returns the file's bytes, or
-    -- as_blocks -- (header, generator of container blocks) for files too large to hold (hostpipe.fqs_chunks serialises them)."""
+    -- as_blocks -- (header, generator of container blocks) for files too large to hold (hostpipe.fqs_chunks serialises them).
+    gpu_ids: the id stream from the GPU kernel (True), from the host coder (False: one thread per worker, no limits on the id
+    lines), or -- None -- the kernel unless an id of the file is beyond its staging limits."""
+    if gpu_ids is None:
+        gpu_ids = id_mode == "none" or _ids_fit_the_kernel(rec)
     mode = "se_sorted" if order == "s" else "se_original"
     header = hp.make_header(threads, mode, genome_size_mbp, quality_mode, id_mode, quality_thr)
     sizes = rec.record_sizes()
@@ -85,14 +110,16 @@ def compress_records(rec: hp.Records, threads: int, order: str = "s", genome_siz
 
     groups = _gpu_groups(rec, device, lib_path) if mode == "se_sorted" else None
     if as_blocks:
-        return header, encode_blocks(header, hp.form_blocks(rec, mode, groups=groups), arrays, lambda idx: sizes[idx], False, device, lib_path)
-    return _encode(header, hp.form_blocks(rec, mode, groups=groups), arrays, lambda idx: sizes[idx], False, device, lib_path)
+        return header, encode_blocks(header, hp.form_blocks(rec, mode, groups=groups), arrays, lambda idx: sizes[idx], False, device, lib_path, gpu_ids=gpu_ids)
+    return _encode(header, hp.form_blocks(rec, mode, groups=groups), arrays, lambda idx: sizes[idx], False, device, lib_path, gpu_ids)
 
 
 def compress_records_pe(rec1: hp.Records, rec2: hp.Records, threads: int, order: str = "s", genome_size_mbp: int = 3100,
                         device: int = 0, lib_path: Optional[str] = None, quality_mode: str = "none", id_mode: str = "none",
-                        quality_thr: int = 20, as_blocks: bool = False):
-    """`fqs e -p ...` on two mate files (records interleaved mate 1 / mate 2 inside a block)."""
+                        quality_thr: int = 20, as_blocks: bool = False, gpu_ids: Optional[bool] = None, stats: Optional[dict] = None):
+    """`fqs e -p ...` on two mate files (records interleaved mate 1 / mate 2 inside a block).  gpu_ids: see compress_records."""
+    if gpu_ids is None:
+        gpu_ids = id_mode == "none" or _ids_fit_the_kernel(rec1, rec2)
     mode = "pe_sorted" if order == "s" else "pe_original"
     header = hp.make_header(threads, mode, genome_size_mbp, quality_mode, id_mode, quality_thr)
     s1, s2 = rec1.record_sizes(), rec2.record_sizes()
@@ -110,5 +137,5 @@ def compress_records_pe(rec1: hp.Records, rec2: hp.Records, threads: int, order:
 
     groups = _gpu_groups(rec1, device, lib_path) if mode == "pe_sorted" else None   # mates follow mate 1's order, io.h:541-550
     if as_blocks:
-        return header, encode_blocks(header, hp.form_blocks_pe(rec1, rec2, mode, groups=groups), arrays, sizes_of, True, device, lib_path)
-    return _encode(header, hp.form_blocks_pe(rec1, rec2, mode, groups=groups), arrays, sizes_of, True, device, lib_path)
+        return header, encode_blocks(header, hp.form_blocks_pe(rec1, rec2, mode, groups=groups), arrays, sizes_of, True, device, lib_path, stats=stats, gpu_ids=gpu_ids)
+    return _encode(header, hp.form_blocks_pe(rec1, rec2, mode, groups=groups), arrays, sizes_of, True, device, lib_path, gpu_ids)

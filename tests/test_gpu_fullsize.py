@@ -140,6 +140,32 @@ def test_c18_paired_end_5M_pairs_q8_matches_reference_file():
     assert file_n == d["file_bytes"] and file_h.hexdigest() == d["file_sha256"]
 
 
+def test_c22_configs4_modes_1M_pairs_lossless_qualities_and_ids_match_reference_file():
+    """BASELINE configs[4]'s modes (-p -om s -qm o -im o) at 1 M pairs x 150 bp with varied Illumina-style ids: the meta, id, DNA and
+    quality streams of every block -- DNA, quality and id kernels on the GPU side by side -- and the SHA-256 of the whole file equal
+    the reference's (tools/make_golden.py c22)."""
+    from fqsqueezer_amd.fqsfile import compress_records_pe
+    from fqsqueezer_amd.synth import synth_ids_varied, synth_pairs, synth_quals
+    name = "c22_pe1M_s_oo_t8.json"
+    d = _need(name)
+    n, seed = d["pairs"], d["seed"]
+    r1, r2 = synth_pairs(n, d["len"], d["genome"], seed)
+    rec1 = hp.Records(synth_ids_varied(n, seed, 1), r1, synth_quals(n, d["len"], seed))
+    rec2 = hp.Records(synth_ids_varied(n, seed, 2), r2, synth_quals(n, d["len"], seed + 1))
+    header, blocks = compress_records_pe(rec1, rec2, d["threads"], d["om"], d["gs"], quality_mode=QM[d["qm"]], id_mode=IM[d["im"]], as_blocks=True)
+    assert header.hex() == d["header"]
+    names = {hp.STREAM_META: "meta", hp.STREAM_ID: "id", hp.STREAM_DNA: "dna", hp.STREAM_QUALITY: "quality"}
+    file_h, file_n, g = hashlib.sha256(), 0, 0
+    for chunk in hp.fqs_chunks(header, _tee_blocks(blocks, d, hp.stored_streams(header), names, name)):
+        file_h.update(chunk)
+        file_n += len(chunk)
+        g += 1
+        if LIMIT is not None and g > LIMIT:
+            return
+    assert g - 1 == d["n_blocks"]
+    assert file_n == d["file_bytes"] and file_h.hexdigest() == d["file_sha256"]
+
+
 def _tee_blocks(blocks, d, sids, names, name):
     """checks every block's streams against the reference's digests on their way into the container"""
     for g, b in enumerate(blocks):

@@ -35,6 +35,8 @@ Fixtures (data only -- inputs are re-generated deterministically by fqsqueezer_a
                             beyond the Infinity Cache): DNA digests per block (only with --only c19 / c19t64; ~15 / ~45 GiB, 30-60 min)
   c21_5M150_G3100_gs3100_s_t8.json  SURVEY 8d-4: a prefix of configs[3]'s own file -- 5 M x 150bp from a G = 3.1 Gbp genome, seed 21,
                             -om s at the DEFAULT -gs 3100, T = 8: DNA digests per block (only with --only c21; ~50 GiB, about an hour)
+  c22_pe1M_s_oo_t8.json     BASELINE configs[4]'s modes at 1 M pairs: 150bp mates, G=15Mbp, seed 22, varied ids, -p -om s -qm o -im o -gs 15, T=8:
+                            all four streams of every block + the file's SHA-256 (only with --only c22; ~10 min)
 Usage: python tools/make_golden.py [--work /tmp/w] [--only c1|c2|c3]
 """
 import argparse, hashlib, json, os, subprocess, sys
@@ -234,6 +236,8 @@ def main():
         c19(a, 64 if a.only == "c19t64" else 8)
     if a.only == "c21":
         c21(a, 8)
+    if a.only == "c22":
+        c22(a)
     if a.only in ("", "c3"):
         fq = os.path.join(a.work, "c3.fq")
         if not os.path.exists(fq):
@@ -369,6 +373,23 @@ def c21(a, t):
     run_ref(fq, out, "s", t, 3100, a.work)
     meta = {"reads": 5000000, "len": 150, "genome": 3100000000, "seed": 21, "gs": 3100, "om": "s", "threads": t}
     json.dump(digest(out, meta), open(os.path.join(GOLD, f"c21_5M150_G3100_gs3100_s_t{t}.json"), "w"))
+
+
+def c22(a):
+    """BASELINE configs[4]'s modes at 1 M pairs: 150 bp mates (fragments 300-600) of a 15 Mbp genome (20x), varied Illumina-style ids,
+    -p -om s -qm o -im o (lossless qualities and ids) -gs 15, T = 8: every stream of every block + the file's SHA-256."""
+    from fqsqueezer_amd.synth import synth_ids_varied, synth_pairs, synth_quals
+    npairs, G, seed = 1000000, 15000000, 22
+    r1, r2 = synth_pairs(npairs, 150, G, seed)
+    f1, f2 = os.path.join(a.work, "c22_1.fq"), os.path.join(a.work, "c22_2.fq")
+    write_fq_ids(f1, synth_ids_varied(npairs, seed, 1), r1, synth_quals(npairs, 150, seed))
+    write_fq_ids(f2, synth_ids_varied(npairs, seed, 2), r2, synth_quals(npairs, 150, seed + 1))
+    out = os.path.join(a.work, "c22.fqs")
+    subprocess.check_call([REF, "e", "-p", "-om", "s", "-t", "8", "-gs", "15", "-qm", "o", "-im", "o", "-v", "0",
+                           "-tmp", os.path.join(a.work, "tmp22_"), "-out", out, f1, f2], stdout=subprocess.DEVNULL)
+    meta = {"pairs": npairs, "len": 150, "genome": G, "seed": seed, "gs": 15, "om": "s", "qm": "o", "im": "o", "threads": 8,
+            "paired": True, "varied_ids": True}
+    json.dump(fdigest(out, meta), open(os.path.join(GOLD, "c22_pe1M_s_oo_t8.json"), "w"))
 
 
 def ragged():
