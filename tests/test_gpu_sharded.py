@@ -240,3 +240,63 @@ def test_partitioned_tables_c18_paired_end_full_size_against_the_reference(tmp_p
     assert r.returncode == 0, (r.stdout[-1500:] + (r.stderr[max(0, i - 500):i + 2500] if i >= 0 else r.stderr[-3000:]))
     assert "PARTITIONED_C18_OK" in r.stdout
     print(r.stdout[r.stdout.find("PARTITIONED_C18_OK"):][:700])
+
+
+# ---- the real thing: one rank per PHYSICAL GPU, RCCL inside the library, partitioned tables read over xGMI.  Needs a node with at
+# least two GPUs (a gpurun box has one: skipped there; the driver's multi-GPU node runs bench.py --gpus N, which takes the same path).
+XGMI_WORKER = r'''
+import faulthandler, os, sys
+faulthandler.enable()
+sys.path.insert(0, os.environ["FQSX_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from fqsqueezer_amd import hostpipe as hp
+from fqsqueezer_amd.codec import DnaCodec
+from fqsqueezer_amd.sharded import NativeShardedDnaCodec
+from fqsqueezer_amd.synth import synth_reads
+rank, world, dev = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+T = 16
+header = hp.make_header(T, "se_sorted", 1)
+reads = synth_reads(40000, 100, 300000, 41)
+rec = hp.Records([b"@r%d" % i for i in range(len(reads))], reads, reads)
+blocks = [hp.block_arrays(rec, idx) for idx in hp.form_blocks(rec, "se_sorted")[:80]]
+ids = [NativeShardedDnaCodec.rccl_unique_id() if rank == 0 else None]
+dist.broadcast_object_list(ids, src=0)
+sh = NativeShardedDnaCodec(header, rank, world, device=dev, transport="rccl", id_bytes=ids[0], partition=True)
+assert sh.partitioned, sh.partition_note            # (a node whose GPUs cannot reach each other would fall back to replicas)
+assert sh.rccl_info()["ranks_seen"] == world
+one = DnaCodec(header, device=dev)                   # the one-GPU run on this rank's own device, for comparison
+for g, (bases, off) in enumerate(blocks):
+    mine = sh.encode_block(bases, off, g)
+    ref = one.encode_block(bases, off, g)
+    assert sorted(mine) == list(range(rank, T, world))
+    for w, s in mine.items():
+        assert s == ref[w], f"rank {rank}: block {g} worker {w} differs from the one-GPU run"
+cap, cap1 = sh.codec.capacity(), one.capacity()
+assert (cap["smers"], cap["bmers"]) == (cap1["smers"], cap1["bmers"]), (cap, cap1)
+lst = [None] * world
+dist.all_gather_object(lst, (cap["table_bytes_held"], 8 * (cap["smer_slots"] + cap["bmer_slots"]), sh.traffic))
+if rank == 0:
+    print("PARTITIONED_XGMI_OK", world, [x[0] for x in lst], lst[0][1], lst[0][2])
+sh.close(); one.close()
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_partitioned_tables_one_rank_per_physical_gpu_over_rccl(tmp_path):
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU on this box: the xGMI path needs a node with at least two")
+    world = min(n_dev, 4)
+    script = tmp_path / "x.py"
+    script.write_text(XGMI_WORKER)
+    env = dict(os.environ, FQSX_ROOT=ROOT, FQSX_GTAB_INIT="4096", HSA_ENABLE_IPC_MODE_LEGACY="0")   # (small tables: collective growths with re-export)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", "29567", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    i = r.stderr.find("Fatal Python error")
+    assert r.returncode == 0, (r.stdout[-1500:] + (r.stderr[max(0, i - 500):i + 2500] if i >= 0 else r.stderr[-3000:]))
+    assert "PARTITIONED_XGMI_OK" in r.stdout
