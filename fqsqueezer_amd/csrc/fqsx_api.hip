@@ -24,7 +24,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <string>
 #include <vector>
 
@@ -846,11 +845,6 @@ void vtab_drop(fqsx_dna *c, fqsx_dna::VmTab &v, u32 o) {
   v.mapped[o] = 0;
   if (o % c->shard_world == c->shard_rank) { c->dev_bytes -= v.chunk_bytes; c->vm_own_bytes -= v.chunk_bytes; }
 }
-// Address ranges no table lives in any more, kept for the next table of this process that fits (see vtab_free: on the HIP build a
-// range is never handed back, so without reuse every growth of every codec would take fresh address space for good)
-struct VaRange { u8 *va; u64 bytes; };
-static std::vector<VaRange> g_va_free;
-static std::mutex g_va_mu;
 void vtab_free(fqsx_dna *c, fqsx_dna::VmTab &v) {
   if (!v.live) return;
   std::string e;
@@ -858,13 +852,14 @@ void vtab_free(fqsx_dna *c, fqsx_dna::VmTab &v) {
 #ifdef FQSX_EMU
   (void)fqsx_vm::unreserve(v.va, v.va_bytes, e);
 #else
-  { std::lock_guard<std::mutex> lk(g_va_mu); g_va_free.push_back({v.va, v.va_bytes}); }
+  // (Round 4 tried to use kept ranges again for later tables of the process -- mapping new chunks of another size into a range
+  // that had stayed reserved: the runtime aborted inside the first encode launch behind such a reuse,
+  // tests/test_gpu_parity.py::test_hip_chunked_tables_grow_sub_table_by_sub_table.  So a range is used once.)
   // The address range is NOT handed back (hipMemAddressFree): with the HIP runtime a PyTorch wheel loads (ROCm 7.0) a range
   // that is freed and later reserved again -- by the next growth, or by another allocation that lands there -- is read through
   // stale translations (found with tests/test_gpu_parity.py::test_hip_chunked_tables_*: wrong table contents from the first
   // reuse on; never with the ranges kept).  Unmapped address space costs nothing; a codec's ranges add up to less than twice
-  // its final tables.  Kept ranges are used again, in place, by later tables (vtab_reserve): mapping new chunks into a range
-  // that stayed reserved is the ordinary use of the API.
+  // its final tables.
 #endif
   v = fqsx_dna::VmTab();
 }
@@ -887,19 +882,7 @@ int vtab_reserve(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 c
   v.h.assign(T, fqsx_vm::Handle());
   v.mapped.assign(T, 0);
   // (2 MiB alignment once the chunks are that large, so that the driver can use large page-table fragments)
-#ifndef FQSX_EMU
-  {   // a kept range of this process that is large enough (and not more than twice too large)
-    std::lock_guard<std::mutex> lk(g_va_mu);
-    for (size_t i = 0; i < g_va_free.size(); ++i)
-      if (g_va_free[i].bytes >= v.va_bytes && g_va_free[i].bytes <= 2 * v.va_bytes) {
-        v.va = g_va_free[i].va;
-        v.va_bytes = g_va_free[i].bytes;   // (the whole range stays this table's, so that it goes back on the list as it was)
-        g_va_free.erase(g_va_free.begin() + i);
-        break;
-      }
-  }
-#endif
-  if (!v.va) VMCHK(fqsx_vm::reserve(v.va_bytes, std::max<u64>(c->vm_gran, std::min<u64>(v.chunk_bytes, 2ull << 20)), &v.va, e_));
+  VMCHK(fqsx_vm::reserve(v.va_bytes, std::max<u64>(c->vm_gran, std::min<u64>(v.chunk_bytes, 2ull << 20)), &v.va, e_));
   v.live = true;
   t.slots = (u64 *)v.va;
   t.nb = cap / FQSX_BKT;

@@ -152,8 +152,8 @@ dist.destroy_process_group()
 
 
 # c17 = the reference's DEFAULT geometry (-gs 3100: k = 13 / 18 / 21 / 27, 16 GiB p-mer vector per rank) on 1 M reads, T = 8, over four ranks
-# c21 = SURVEY 8d-4's prefix of configs[3]'s own file (5 M reads of a G = 3.1 Gbp genome, -gs 3100, T = 8) over four ranks: the first 64
-# blocks by default (eight workers spread over four ranks sharing one GPU, collectives staged through gloo), all 256 with FQSX_SLOW=1
+# c21 = SURVEY 8d-4's prefix of configs[3]'s own file (5 M reads of a G = 3.1 Gbp genome, -gs 3100, T = 8) over four ranks: the first 32
+# blocks by default (64 ran in round 4: profiles/r04_c21_full_tests.txt) (eight workers spread over four ranks sharing one GPU, collectives staged through gloo), all 256 with FQSX_SLOW=1
 @pytest.mark.parametrize("golden,world,port", [("c19_10M150_gs300_s_t64.json", 2, 29563), ("c17_1M150_gs3100_s_t8.json", 4, 29564),
                                                ("c21_5M150_G3100_gs3100_s_t8.json", 4, 29566)])
 def test_partitioned_tables_c19_two_ranks_against_the_reference(tmp_path, golden, world, port):
@@ -164,7 +164,7 @@ def test_partitioned_tables_c19_two_ranks_against_the_reference(tmp_path, golden
     env = dict(os.environ, FQSX_ROOT=ROOT, FQSX_GOLDEN=golden)
     slow = os.environ.get("FQSX_SLOW") == "1"
     if golden.startswith("c21") and not slow and "FQSX_FULLSIZE_BLOCKS" not in env:
-        env["FQSX_FULLSIZE_BLOCKS"] = "64"
+        env["FQSX_FULLSIZE_BLOCKS"] = "32"
     if not golden.startswith("c21") and not slow:   # (both ran green in rounds 3 and 4; c21 over four ranks covers the path in the driver's suite)
         pytest.skip("c19 over two ranks (60 s) and c17 over four (28 s) run with FQSX_SLOW=1: the suite's time goes to c21")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
