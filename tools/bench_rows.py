@@ -32,8 +32,9 @@ PEAK = 8000.0
 def dna_bytes(st: dict, pairs: int = 0) -> float:
     """SURVEY.md 8(d): B = sum_probes(24 + 4 slots) + sum_global_inserts(24 + 4 slots + 4) + 8 siv_words + 24 ctx_slots + 80 coded;
     paired-end adds the pair table: 8 finds + 14 inserts of a 16-byte item behind a 24-byte descriptor per pair."""
-    probes, slots = st["gprobe"] + st["lprobe"], st["gslot"] + st["lslot"]
-    return (24.0 * probes + 4.0 * slots + 28.0 * st["gins"] + 4.0 * st["gins_slot"] + 8.0 * (st["siv_words"] + st.get("siv_saved", 0))
+    # (slots per cluster scan: the reference's measured 3.96 -- this library's two-choice buckets read eight slots per probe whatever they hold; bench.py)
+    probes = st["gprobe"] + st["lprobe"]
+    return ((24.0 + 4.0 * 3.96) * probes + (28.0 + 4.0 * 3.96) * st["gins"] + 8.0 * (st["siv_words"] + st.get("siv_saved", 0))
             + 24.0 * st["ctx_slots"] + 80.0 * st["coded"] + 22.0 * 40.0 * pairs)
 
 
@@ -55,7 +56,11 @@ def ref_run(args, units: float, unit: str, what: str):
     return {"value": round(units / dt / 1e6, 4), "unit": unit, "cores": 8, "kind": "reference", "wall_s": round(dt, 2), "sample": what}
 
 
-def measure(n_reads: int = 300_000, read_len: int = 150, T: int = 64, device: int = 0, cpu_reads: int = 100_000) -> dict:
+def measure(n_reads: int = 300_000, read_len: int = 150, T: int = 64, device: int = 0, cpu_reads: int = 100_000, only=None) -> dict:
+    """only: a set of row names (decode, sorted, original_order, pe_sorted, quality_o, quality_8, id_lossless, full_mode_pe_q8) -- the
+    rocprofv3 --pmc passes run one kernel's rows at a time, so that a kernel's counters are one row's (tools/gpu_round.sh rows)"""
+    def want(row):
+        return only is None or row in only
     import torch
     from fqsqueezer_amd import hostpipe as hp
     from fqsqueezer_amd.codec import DnaCodec, QualCodec
@@ -83,9 +88,11 @@ def measure(n_reads: int = 300_000, read_len: int = 150, T: int = 64, device: in
     # ---- DNA decoder (k_decode_*): encode the file once, then time decoding it (streams host -> device per block)
     header = hp.make_header(T, "se_sorted", gs)
     blocks = [hp.block_arrays(rec, idx) for idx in hp.form_blocks(rec, "se_sorted")]
-    enc = DnaCodec(header, device=device)
-    streams = [enc.encode_block(b, o, g) for g, (b, o) in enumerate(blocks)]
-    enc.close()
+    streams = []
+    if want("decode"):
+        enc = DnaCodec(header, device=device)
+        streams = [enc.encode_block(b, o, g) for g, (b, o) in enumerate(blocks)]
+        enc.close()
 
     def decode_pass(profile):
         dec = DnaCodec(header, device=device)
@@ -101,12 +108,13 @@ def measure(n_reads: int = 300_000, read_len: int = 150, T: int = 64, device: in
         dec.close()
         return dt, ok, st, kt
 
-    dt, ok, _, _ = decode_pass(False)
-    _, _, st, kt = decode_pass(True)
-    out["decode"] = {"value": round(n_bases / dt / 1e6, 3), "unit": "Mbases/s", "round_trip_ok": ok,
+    if want("decode"):
+      dt, ok, _, _ = decode_pass(False)
+      _, _, st, kt = decode_pass(True)
+      out["decode"] = {"value": round(n_bases / dt / 1e6, 3), "unit": "Mbases/s", "round_trip_ok": ok,
                      "roofline": roofline(dna_bytes(st), kt["encode_ms"], kt["encode_launches"], "k_decode_se_sorted")}
-    out["decode_mbases_s"], out["decode_round_trip_ok"] = out["decode"]["value"], ok
-    if have_ref:
+      out["decode_mbases_s"], out["decode_round_trip_ok"] = out["decode"]["value"], ok
+    if have_ref and want("decode"):
         f = os.path.join(td, "d.fqs")
         subprocess.run([REF, "e", "-s", "-om", "s", "-t", "8", "-gs", str(gs), "-qm", "n", "-im", "n", "-v", "0", "-tmp", tmp, "-out", f, fq],
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -128,18 +136,20 @@ def measure(n_reads: int = 300_000, read_len: int = 150, T: int = 64, device: in
                 res = {"value": round(nb / dt / 1e6, 3), "unit": "Mbases/s", "bits_per_base": round(8.0 * nbytes / nb, 5)}
             else:
                 st, kt = c.stats(), c.kernel_times()
-                res["roofline"] = roofline(dna_bytes(st, pairs) - 28.0 * st["gins"] - 4.0 * st["gins_slot"], kt["encode_ms"], kt["encode_launches"], kernel)
+                res["roofline"] = roofline(dna_bytes(st, pairs) - (28.0 + 4.0 * 3.96) * st["gins"], kt["encode_ms"], kt["encode_launches"], kernel)
             c.close()
         return res
 
-    db = [dev(b, o) + (o,) for (b, o) in blocks]
-    out["sorted"] = encode_row(header, db, n_bases, "k_encode_se_sorted")
-    out["sorted_mbases_s"], out["sorted_bits_per_base"] = out["sorted"]["value"], out["sorted"]["bits_per_base"]
+    if want("sorted"):
+        db = [dev(b, o) + (o,) for (b, o) in blocks]
+        out["sorted"] = encode_row(header, db, n_bases, "k_encode_se_sorted")
+        out["sorted_mbases_s"], out["sorted_bits_per_base"] = out["sorted"]["value"], out["sorted"]["bits_per_base"]
     hdr_o = hp.make_header(T, "se_original", gs)
-    db = [dev(*hp.block_arrays(rec, idx)) + (hp.block_arrays(rec, idx)[1],) for idx in hp.form_blocks(rec, "se_original")]
-    out["original_order"] = encode_row(hdr_o, db, n_bases, "k_encode_se_orig")
-    out["original_order_mbases_s"], out["original_order_bits_per_base"] = out["original_order"]["value"], out["original_order"]["bits_per_base"]
-    if have_ref:
+    if want("original_order"):
+        db = [dev(*hp.block_arrays(rec, idx)) + (hp.block_arrays(rec, idx)[1],) for idx in hp.form_blocks(rec, "se_original")]
+        out["original_order"] = encode_row(hdr_o, db, n_bases, "k_encode_se_orig")
+        out["original_order_mbases_s"], out["original_order_bits_per_base"] = out["original_order"]["value"], out["original_order"]["bits_per_base"]
+    if have_ref and want("original_order"):
         out["original_order"]["cpu"] = ref_run(["e", "-s", "-om", "o", "-t", "8", "-gs", str(gs), "-qm", "n", "-im", "n", "-v", "0", "-tmp", tmp, "-out", os.path.join(td, "o.fqs"), fq],
                                                nc * read_len, "Mbases/s", f"`fqs-1.1 e -s -om o -qm n -im n -t 8`, {nc} reads")
 
@@ -149,21 +159,25 @@ def measure(n_reads: int = 300_000, read_len: int = 150, T: int = 64, device: in
     rec2 = hp.Records([read_id(i, 2) for i in range(n_pairs)], r2, quals[n_pairs:2 * n_pairs])
     hdr_p = hp.make_header(T, "pe_sorted", gs)
     db = []
-    for idx in hp.form_blocks_pe(rec1, rec2, "pe_sorted"):
-        b, o = hp.block_arrays_pe(rec1, rec2, idx)
-        db.append(dev(b, o) + (o,))
-    out["pe_sorted"] = encode_row(hdr_p, db, 2 * n_pairs * read_len, "k_encode_pe_sorted", pairs=n_pairs)
-    out["pe_sorted_mbases_s"], out["pe_sorted_bits_per_base"] = out["pe_sorted"]["value"], out["pe_sorted"]["bits_per_base"]
+    if want("pe_sorted"):
+        for idx in hp.form_blocks_pe(rec1, rec2, "pe_sorted"):
+            b, o = hp.block_arrays_pe(rec1, rec2, idx)
+            db.append(dev(b, o) + (o,))
+        out["pe_sorted"] = encode_row(hdr_p, db, 2 * n_pairs * read_len, "k_encode_pe_sorted", pairs=n_pairs)
+        out["pe_sorted_mbases_s"], out["pe_sorted_bits_per_base"] = out["pe_sorted"]["value"], out["pe_sorted"]["bits_per_base"]
     npc = min(cpu_reads // 2, n_pairs)
     f1, f2 = os.path.join(td, "p1.fq"), os.path.join(td, "p2.fq")
-    if have_ref:
+    if have_ref and (want("pe_sorted") or want("full_mode_pe_q8")):
         write_fastq(f1, r1[:npc], quals[:npc], mate=1)
         write_fastq(f2, r2[:npc], quals[n_pairs:n_pairs + npc], mate=2)
+    if have_ref and want("pe_sorted"):
         out["pe_sorted"]["cpu"] = ref_run(["e", "-p", "-om", "s", "-t", "8", "-gs", str(gs), "-qm", "n", "-im", "n", "-v", "0", "-tmp", tmp, "-out", os.path.join(td, "p.fqs"), f1, f2],
                                           2 * npc * read_len, "Mbases/s", f"`fqs-1.1 e -p -om s -qm n -im n -t 8`, {npc} pairs")
 
     # ---- quality coder (k_qual_encode), iid 7-level qualities: lossless (-qm o) and Illumina-8 (-qm 8)
     for qm, tag, flag in (("lossless", "quality_o", "o"), ("illumina_8", "quality_8", "8")):
+        if not want(tag):
+            continue
         hq = hp.make_header(T, "se_sorted", gs, qm, "none")
         qb = [hp.qual_arrays(rec, idx) for idx in hp.form_blocks(rec, "se_sorted")]
         dq = [dev(q, o) + (o,) for (q, o) in qb]
@@ -202,30 +216,32 @@ def measure(n_reads: int = 300_000, read_len: int = 150, T: int = 64, device: in
     # (one host thread per worker) on the same blocks
     from fqsqueezer_amd.codec import IdCodec
     hi = hp.make_header(T, "se_sorted", gs, "none", "lossless")
-    ib = [hp.id_arrays(rec, idx) for idx in hp.form_blocks(rec, "se_sorted")]
+    ib = [hp.id_arrays(rec, idx) for idx in hp.form_blocks(rec, "se_sorted")] if want("id_lossless") else []
     id_bytes = sum(int(o[-1]) for (_, o) in ib)
     row = {}
-    for tag2, devarg in (("gpu", device), ("host_threads", None)):
+    for tag2, devarg in ((("gpu", device), ("host_threads", None)) if want("id_lossless") else ()):
         c = IdCodec(hi, device=devarg)
         t0 = time.perf_counter()
         nbytes = sum(sum(len(x) for x in c.encode_block(a, o, False)) for (a, o) in ib)
         dt = time.perf_counter() - t0
         c.close()
         row[tag2] = {"value": round(n_reads / dt / 1e6, 3), "unit": "Mids/s", "id_mbytes_s": round(id_bytes / dt / 1e6, 2), "stream_bytes": nbytes}
-    row["identical_streams"] = row["gpu"]["stream_bytes"] == row["host_threads"]["stream_bytes"]
-    row["note"] = "host buffers in, streams out (the upload is inside); the DNA path codes 0.67 Mreads/s of 150 bp at 100 Mbases/s, so either id coder runs beside it"
-    out["id_lossless"] = row
+    if want("id_lossless"):
+        row["identical_streams"] = row["gpu"]["stream_bytes"] == row["host_threads"]["stream_bytes"]
+        row["note"] = "host buffers in, streams out (the upload is inside); the DNA path codes 0.67 Mreads/s of 150 bp at 100 Mbases/s, so either id coder runs beside it"
+        out["id_lossless"] = row
 
     # ---- full mode end to end (BASELINE configs[2]'s modes: -p -om s -qm 8, default -im i): the DNA and the quality kernels on
     # two HIP streams, the id kernel on a third, the meta coder on a host thread (fqsfile.encode_blocks), host buffers in, container blocks out
     from fqsqueezer_amd.fqsfile import compress_records_pe
-    t0 = time.perf_counter()
-    hdr_f, blks = compress_records_pe(rec1, rec2, T, "s", gs, device=device, quality_mode="illumina_8", id_mode="instrument", as_blocks=True)
-    n_out = sum(len(ch) for ch in hp.fqs_chunks(hdr_f, blks))
-    dt = time.perf_counter() - t0
-    out["full_mode_pe_q8"] = {"value": round(2 * n_pairs * read_len / dt / 1e6, 3), "unit": "Mbases/s", "file_bytes": n_out,
-                              "note": "whole file from host buffers, GPU sort pre-pass included: 4 streams per block, DNA + quality + id kernels concurrently, meta on a host thread"}
-    if have_ref:
+    if want("full_mode_pe_q8"):
+        t0 = time.perf_counter()
+        hdr_f, blks = compress_records_pe(rec1, rec2, T, "s", gs, device=device, quality_mode="illumina_8", id_mode="instrument", as_blocks=True)
+        n_out = sum(len(ch) for ch in hp.fqs_chunks(hdr_f, blks))
+        dt = time.perf_counter() - t0
+        out["full_mode_pe_q8"] = {"value": round(2 * n_pairs * read_len / dt / 1e6, 3), "unit": "Mbases/s", "file_bytes": n_out,
+                                  "note": "whole file from host buffers, GPU sort pre-pass included: 4 streams per block, DNA + quality + id kernels concurrently, meta on a host thread"}
+    if have_ref and want("full_mode_pe_q8"):
         out["full_mode_pe_q8"]["cpu"] = ref_run(["e", "-p", "-om", "s", "-t", "8", "-gs", str(gs), "-qm", "8", "-v", "0", "-tmp", tmp, "-out", os.path.join(td, "f.fqs"), f1, f2],
                                                 2 * npc * read_len, "Mbases/s", f"`fqs-1.1 e -p -om s -qm 8 -t 8` (default -im i), {npc} pairs")
     import shutil
@@ -235,4 +251,4 @@ def measure(n_reads: int = 300_000, read_len: int = 150, T: int = 64, device: in
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
-    print(json.dumps(measure(n)))
+    print(json.dumps(measure(n, only=set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None)))
