@@ -591,6 +591,7 @@ struct fqsx_dna {
   std::vector<u64> alloc_bytes;   // size of allocs[i]
   u64 dev_bytes, dev_bytes_peak;  // device memory held now / at most so far (fqsx_dna_capacity)
   u32 n_growths;                  // growth events of the global k-mer / pair tables
+  u32 tab_small_pct;              // ... while the table is below 256 MB: to this load (40: it doubles; FQSX_TAB_AFTER_PCT sets both)
   u32 tab_load_pct, tab_after_pct;   // a global k-mer sub-table is grown before an insert phase would fill it beyond load_pct %, to a
                                      // capacity the demand fills to after_pct % (FQSX_TAB_LOAD_PCT / FQSX_TAB_AFTER_PCT; 80 / 62)
   u8 *h_pin;          // pinned host scratch for the small device-to-host transfers of the phase loop
@@ -796,7 +797,7 @@ bool tab_over(const fqsx_dna *c, u64 need, u64 cap) { return need * 100 > cap * 
 u64 tab_new_cap(const fqsx_dna *c, u64 need) {
   // (while a table is small its density is nobody's concern, but every growth stops the block's queue and costs a host round trip:
   // below 256 MB it grows to 40 % load, i.e. doubles)
-  const u32 after = need * c->T * sizeof(u64) * 100 / 40 < (256ull << 20) ? std::min<u32>(40u, c->tab_after_pct) : c->tab_after_pct;
+  const u32 after = need * c->T * sizeof(u64) * 100 / 40 < (256ull << 20) ? std::min<u32>(c->tab_small_pct, c->tab_after_pct) : c->tab_after_pct;
   u64 cap = (need * 100 + after - 1) / after + 2 * FQSX_BKT;
   return (cap + FQSX_BKT - 1) / FQSX_BKT * FQSX_BKT;
 }
@@ -1455,7 +1456,8 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   // owner-sharded global tables (application.cpp:87-88; counters defs.h:26-27)
   c->tab_load_pct = 80; c->tab_after_pct = 62;
   if (const char *e = getenv("FQSX_TAB_LOAD_PCT")) c->tab_load_pct = (u32)std::min<u64>(85, std::max<u64>(20, strtoull(e, nullptr, 10)));
-  if (const char *e = getenv("FQSX_TAB_AFTER_PCT")) c->tab_after_pct = (u32)std::min<u64>(c->tab_load_pct - 5, std::max<u64>(10, strtoull(e, nullptr, 10)));
+  c->tab_small_pct = 40;
+  if (const char *e = getenv("FQSX_TAB_AFTER_PCT")) c->tab_small_pct = c->tab_after_pct = (u32)std::min<u64>(c->tab_load_pct - 5, std::max<u64>(10, strtoull(e, nullptr, 10)));
   cfg.tab_load_pct = c->tab_load_pct;
   c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(1024, (1ull << 22) / T));
   if (const char *e = getenv("FQSX_GTAB_INIT")) c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(64, strtoull(e, nullptr, 10)));   // (tests: growth from tiny tables)

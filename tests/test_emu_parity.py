@@ -140,3 +140,22 @@ def test_abi_rejects_bad_headers():
     for bad in [b"XCSD" + good[4:], good[:4] + bytes([0]) + good[5:], good[:5] + bytes([4]) + good[6:]]:
         with pytest.raises(FqsxError):
             emu(bad)
+
+
+@pytest.mark.parametrize("name", ["c1_10k_s_t4.fqs", "c5_pe4k_s_t4.fqs"])
+def test_overflow_chains_of_the_two_choice_tables(name, monkeypatch):
+    """The global k-mer tables are two-choice buckets (four slots, two hashed buckets per k-mer, new keys into the emptier one); a key
+    whose two buckets are both full goes down an overflow chain, which at the default 80 % load is rare.  Tables that start at 64
+    slots per owner and are only grown at 85 % load (to 80 %) run hundreds of keys through the chains -- look-ups, in-order batch
+    inserts, re-inserts at a growth -- and the streams must stay the reference's (results never depend on the layout)."""
+    monkeypatch.setenv("FQSX_GTAB_INIT", "64")
+    monkeypatch.setenv("FQSX_TAB_LOAD_PCT", "85")
+    monkeypatch.setenv("FQSX_TAB_AFTER_PCT", "80")
+    if name.startswith("c5"):
+        check_against_fqs_pe(emu, c5_records(), name)
+        check_decode_fqs(emu, c5_records(), name)        # (the decoder walks the same chains)
+    else:
+        codec = check_against_fqs(emu, c1_records(), name)
+        cap = codec.capacity()
+        assert cap["bytes_per_bmer"] < 10.2 and cap["growths"] >= 20, cap   # (8 bytes per slot at >= 80 % load)
+        check_decode_fqs(emu, c1_records(), name)

@@ -46,6 +46,23 @@ def test_hip_chunked_tables_grow_sub_table_by_sub_table(name, monkeypatch):
     assert (plain["smers"], plain["bmers"], plain["growths"]) == (cap["smers"], cap["bmers"], cap["growths"])
 
 
+@pytest.mark.parametrize("name", ["c1_10k_s_t4.fqs", "c5_pe4k_s_t4.fqs"])
+def test_hip_overflow_chains_of_the_two_choice_tables(name, monkeypatch):
+    """Two-choice buckets driven to 85 % load from 64-slot sub-tables: hundreds of keys whose two buckets are both full go down the
+    overflow chains -- lane-parallel look-ups of the scouts, in-order batch inserts, parallel re-inserts at ~50 growths, and the
+    decoder walking the same chains.  Streams stay the reference's (tests/test_emu_parity.py has the 1-lane twin)."""
+    monkeypatch.setenv("FQSX_GTAB_INIT", "64")
+    monkeypatch.setenv("FQSX_TAB_LOAD_PCT", "85")
+    monkeypatch.setenv("FQSX_TAB_AFTER_PCT", "80")
+    if name.startswith("c5"):
+        check_against_fqs_pe(gpu, c5_records(), name)
+        check_decode_fqs(gpu, c5_records(), name)
+    else:
+        cap = check_against_fqs(gpu, c1_records(), name).capacity()
+        assert cap["bytes_per_bmer"] < 10.2 and cap["growths"] >= 20, cap
+        check_decode_fqs(gpu, c1_records(), name)
+
+
 def test_hip_tables_turn_into_chunked_tables_at_a_size_by_themselves(monkeypatch):
     """a table of one GPU that reaches FQSX_CHUNK_AUTO_KB (default 2 GiB: the c19 test passes it) continues as a chunked table"""
     monkeypatch.setenv("FQSX_GTAB_INIT", "256")
