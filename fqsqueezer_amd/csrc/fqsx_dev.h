@@ -1925,27 +1925,24 @@ FQ_DEV void scout_rough(Wk &w, u32 n) {
       const u64 r0 = halves == 2 ? res[qa] : res[s], r1 = halves == 2 ? res[qb] : 0ull;
       const u32 nh0 = popc64(hm0), nh = nh0 + popc64(hm1);
       const u32 nsum = halves == 2 ? nsv[qa] + nsv[qb] : nsv[s];
+      // Merging the hits' counts (Increment(a, b), utils.h:327-333) is plain addition, and draws nothing, as long as every
+      // sum stays within the exact range of the counter code -- and the partial sums only grow, so what decides is the total
+      // over ALL the sweep's hits, however many: then the sums stand in for the hits (round 4: rounds 2-3 only looked at
+      // sweeps with at most three hits)
+      bool summed = false;
+      if (nh) {   // (uniform)
+        const u64 sum = wave_sum64(r0 + r1);   // (a 16-bit field holds 128 x 63)
+        const u32 thr = (CINC_B).thr;
+        summed = (u32)(sum & 0xffff) <= thr && (u32)((sum >> 16) & 0xffff) <= thr && (u32)((sum >> 32) & 0xffff) <= thr && (u32)(sum >> 48) <= thr;
+        if (summed && lane == 0) { sb->rc_val[j][0] = sum; sb->rc_hit[j] = nh >= 64 ? ~0ull : (1ull << nh) - 1ull; sb->rc_ns[j] = nsum; sb->rr_idx[j] = 0xfd; }
+      }
+      if (summed) continue;
       if (nh <= 3) {
         // the hits' counts in probe order (the first half's probes come first)
         if (r0 != 0) sb->rc_val[j][popc64(hm0 & lt)] = r0;
         if (r1 != 0) sb->rc_val[j][nh0 + popc64(hm1 & lt)] = r1;
-        u32 form = 0xfe;
-        if (nh) {
-          // Merging the hits' counts (Increment(a, b), utils.h:327-333) is plain addition, and draws nothing, as long as
-          // every sum stays within the exact range of the counter code: then the sums are stored in place of the hits
-          FQ_SYNC();
-          u64 sum = 0;
-          for (u32 x = 0; x < nh; ++x) sum += sb->rc_val[j][x];   // (<= 3 x 63 per 16-bit field)
-          const u32 thr = (CINC_B).thr;
-          const bool exact = (u32)(sum & 0xffff) <= thr && (u32)((sum >> 16) & 0xffff) <= thr && (u32)((sum >> 32) & 0xffff) <= thr && (u32)(sum >> 48) <= thr;
-          FQ_SYNC();
-          if (exact) {
-            form = 0xfd;
-            if (lane == 0) sb->rc_val[j][0] = sum;
-          }
-        }
         // (rc_hit is only ever counted: one bit per hit)
-        if (lane == 0) { sb->rc_hit[j] = halves == 2 ? (1ull << nh) - 1ull : hm0; sb->rc_ns[j] = nsum; sb->rr_idx[j] = (u8)form; }
+        if (lane == 0) { sb->rc_hit[j] = halves == 2 ? (1ull << nh) - 1ull : hm0; sb->rc_ns[j] = nsum; sb->rr_idx[j] = 0xfe; }
       } else if (halves == 1 && big < FQSX_RR) {
         if (lane < n3) sb->rr_res[big][lane] = r0;
         if (lane == 0) { sb->rr_hit[big] = hm0; sb->rr_ns[big] = nsum; sb->rr_idx[j] = (u8)big; }
