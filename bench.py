@@ -103,6 +103,8 @@ def main() -> None:
             raise SystemExit("FQSX_BENCH_EMU only rehearses the sharded multi-rank line (tests/test_multirank_cpu.py)")
         import torch.distributed as dist
         dist.init_process_group("gloo")
+        if world > 1 and os.environ.get("FQSX_BENCH_GUARD", "1") == "1":
+            return guarded_sharded_main(a, rank, local_rank, world, emu_lib=emu)
         return sharded_main(a, rank, local_rank, world, emu_lib=emu)
 
     import torch
@@ -121,6 +123,8 @@ def main() -> None:
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if a.sharded and world > 1:
+        return guarded_sharded_main(a, rank, local_rank, world)
     if a.sharded:
         return sharded_main(a, rank, local_rank, world)
 
@@ -400,7 +404,7 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def sharded_main(a, rank, local_rank, world, emu_lib=None):
+def sharded_main(a, rank, local_rank, world, emu_lib=None, replicas=None, emit=True):
     """ONE file (seed 2) over the N GPUs, strong scaling: logical worker w on rank w % N, per synchronisation phase an all-reduce of
     the count matrix, the three mailboxes in one grouped all-to-all and one all-gather (RCCL on the codec's stream, inside
     libfqsx.so: fqsx_shard_encode_block); with --partition (the default for N > 1) every rank holds 1/N of the k-mer tables and
@@ -497,33 +501,6 @@ def sharded_main(a, rank, local_rank, world, emu_lib=None):
                                 "those workers / rank 0's encode-kernel time (HIP events on the codec's stream); look-ups of the other ranks' "
                                 "sub-tables are xGMI loads, not HBM reads of this GPU"}
 
-    # ---- the other multi-GPU mode beside it: N independent 1 M-read files, one per GPU (weak scaling, no collective)
-    replicas = None
-    if gpu and world > 1:
-        r_reads = synth_reads(1_000_000, a.len, 7_500_000, 2 + rank)
-        r_rec = hp.Records([read_id(i) for i in range(len(r_reads))], r_reads, r_reads)
-        r_header = hp.make_header(a.threads, "se_sorted", 8)
-        r_blocks = []
-        for idx in hp.form_blocks(r_rec, "se_sorted"):
-            bases, off = hp.block_arrays(r_rec, idx)
-            r_blocks.append((torch.from_numpy(np.ascontiguousarray(bases)).cuda(), torch.from_numpy(off.view(np.int64)).cuda(), off))
-
-        def r_step():
-            c = DnaCodec(r_header, device=local_rank)
-            for g, (d_b, d_o, off) in enumerate(r_blocks):
-                c.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g, collect=False)
-            c.close()
-
-        r_step()
-        sync()
-        t1 = time.perf_counter()
-        r_step()
-        sync()
-        tr = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
-        replicas = {"value": round(world * 150.0 / float(tr.item()), 4), "unit": "Mbases/s", "scaling": "weak",
-                    "workload": "1000000x150bp SE, G=7500000 (seed 2+rank), -om s -gs 8, one independent file per GPU, no data-path collective; one timed pass"}
-
     if rank == 0:
         line = {
             "metric": "Mbases/s compressed (DNA stream, SE sorted)", "value": round(value, 4), "unit": "Mbases/s",
@@ -540,14 +517,130 @@ def sharded_main(a, rank, local_rank, world, emu_lib=None):
             "partitioned_tables": bool(info.get("partitioned")), "ranks_seen": info.get("ranks_seen"),
             "per_rank": held, "exchange_rank0_per_file": traffic, "replicas": replicas,
             "roofline": roofline, "cpu_baseline": None}
-        print(json.dumps(line), flush=True)
+        if emit:
+            print(json.dumps(line), flush=True)
     dist.barrier()
     if gpu and comm[0] is not None:
         from fqsqueezer_amd.sharded import _Comm  # noqa: F401
         import ctypes as C
         from fqsqueezer_amd.codec import load_library
         load_library().fqsx_rccl_comm_destroy(C.byref(comm[0]))
-    dist.destroy_process_group()
+    if emit:
+        dist.destroy_process_group()
+    return line if rank == 0 else None
+
+
+def replicas_pass(a, rank, local_rank, world):
+    """The other multi-GPU mode: N independent 1 M-read files, one per GPU (weak scaling, no data-path collective); one timed pass."""
+    import torch
+    import torch.distributed as dist
+    from fqsqueezer_amd import hostpipe as hp
+    from fqsqueezer_amd.codec import DnaCodec
+    from fqsqueezer_amd.synth import read_id, synth_reads
+    r_reads = synth_reads(1_000_000, a.len, 7_500_000, 2 + rank)
+    r_rec = hp.Records([read_id(i) for i in range(len(r_reads))], r_reads, r_reads)
+    r_header = hp.make_header(a.threads, "se_sorted", 8)
+    r_blocks = []
+    for idx in hp.form_blocks(r_rec, "se_sorted"):
+        bases, off = hp.block_arrays(r_rec, idx)
+        r_blocks.append((torch.from_numpy(np.ascontiguousarray(bases)).cuda(), torch.from_numpy(off.view(np.int64)).cuda(), off))
+
+    def r_step():
+        c = DnaCodec(r_header, device=local_rank)
+        nb = 0
+        for g, (d_b, d_o, off) in enumerate(r_blocks):
+            nb += c.encode_block_dev(d_b.data_ptr(), d_o.data_ptr(), off, g, collect=False)
+        c.close()
+        return nb
+
+    def sync():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    r_step()
+    sync()
+    t1 = time.perf_counter()
+    nb = r_step()
+    sync()
+    tr = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+    tot = torch.tensor([nb], dtype=torch.int64, device="cuda")
+    dist.all_reduce(tot)
+    return {"value": round(world * 150.0 / float(tr.item()), 4), "unit": "Mbases/s", "scaling": "weak", "ms_per_step": round(float(tr.item()) * 1e3, 2),
+            "bits_per_base": round(8.0 * int(tot.item()) / (world * 150e6), 5),
+            "workload": "1000000x150bp SE, G=7500000 (seed 2+rank), -om s -gs 8, one independent file per GPU, no data-path collective; one timed pass"}
+
+
+def guarded_sharded_main(a, rank, local_rank, world, emu_lib=None):
+    """The driver's `--gpus N` line must come out whatever the node does to the sharded mode (RCCL inside libfqsx.so, descriptor passing
+    and peer mappings between N real GPUs).  So: the replicas mode is measured first (it needs nothing but N GPUs), the sharded file
+    runs on a side thread under a deadline, the ranks agree over a gloo group (CPU sockets: it still answers when a GPU stream is
+    stuck in a collective) whether it finished everywhere, and if it did not rank 0 prints the replicas line -- `scaling: weak`, with
+    the failure spelled out in `sharded_failed` -- and the processes leave without waiting for the stuck stream."""
+    import datetime
+    import threading
+    import torch.distributed as dist
+    gpu = emu_lib is None
+    side = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
+    replicas = replicas_pass(a, rank, local_rank, world) if gpu else None
+    res = {}
+    store = None
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:
+        pass
+
+    def body():
+        try:
+            if gpu:
+                import torch
+                torch.cuda.set_device(local_rank)   # (the current device is per thread)
+            if os.environ.get("FQSX_BENCH_TEST_RAISE") == str(rank):   # tests: one rank fails alone, before any collective
+                raise RuntimeError("injected failure")
+            res["line"] = sharded_main(a, rank, local_rank, world, emu_lib=emu_lib, replicas=replicas, emit=False)
+            res["ok"] = True
+        except BaseException as e:   # noqa: BLE001 -- whatever it is, the other ranks have to hear of it
+            res["err"] = f"rank {rank}: {type(e).__name__}: {e}"[:600]
+            try:
+                store.set("fqsx_shard_failed", res["err"])
+            except Exception:
+                pass
+
+    th = threading.Thread(target=body, daemon=True)
+    th.start()
+    deadline = time.time() + float(os.environ.get("FQSX_BENCH_SHARD_DEADLINE_S", "420"))
+    while th.is_alive() and time.time() < deadline:
+        th.join(1.0)
+        try:
+            if th.is_alive() and store is not None and store.check(["fqsx_shard_failed"]):
+                th.join(5.0)
+                break
+        except Exception:
+            store = None
+    if th.is_alive() and "err" not in res:
+        res["err"] = f"rank {rank}: the sharded pass had not finished" + (" when another rank reported a failure" if time.time() < deadline else " at its deadline")
+    import torch
+    ok = torch.tensor([1 if res.get("ok") else 0], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=side)
+    if int(ok.item()):
+        if rank == 0:
+            print(json.dumps(res["line"]), flush=True)
+        dist.destroy_process_group()
+        return
+    errs = [None] * world
+    dist.all_gather_object(errs, res.get("err"), group=side)
+    if rank == 0:
+        r = replicas or {"value": 0.0, "ms_per_step": None, "bits_per_base": None, "workload": "(no replicas pass in the CPU rehearsal)"}
+        print(json.dumps({
+            "metric": "Mbases/s compressed (DNA stream, SE sorted)", "value": r["value"], "unit": "Mbases/s", "n_gpus": world, "steps": 1, "warmup": 1,
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": r["workload"], "workers_T": a.threads, "per_gpu": "one independent file per GPU"},
+            "bits_per_base": r["bits_per_base"],
+            "sharded_failed": {"what": "the sharded-partitioned pass (one file over the N GPUs) did not finish on every rank; this line is the replicas mode instead",
+                               "ranks": [e for e in errs if e]},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    sys.stdout.flush()
+    os._exit(0)   # (a rank stuck in a collective never returns: no destructors, no process-group teardown)
 
 
 def cpu_baseline(a, hp, reads, rec):

@@ -3,6 +3,7 @@ world_size 2 on the gloo backend; the ranks run the emulated kernels."""
 import os
 import subprocess
 import sys
+import pytest
 
 from conftest import ROOT
 
@@ -64,3 +65,21 @@ def test_bench_py_sharded_line_two_ranks_gloo(built):
     held = [x["table_bytes_held"] for x in line["per_rank"]]
     assert len(held) == 2 and min(held) > 0 and abs(held[0] - held[1]) <= max(held) // 2, held   # each rank holds its owners' share
     assert line["exchange_rank0_per_file"]["all_to_all_bytes"] > 0 and 0 < line["bits_per_base"] < 2.5
+
+
+@pytest.mark.parametrize("inject", [{"FQSX_TEST_FAIL": "1,3"}, {"FQSX_BENCH_TEST_RAISE": "1"}], ids=["voted-in-the-library", "one-rank-alone"])
+def test_bench_py_prints_a_line_when_the_sharded_pass_fails(built, inject):
+    """The driver's multi-GPU line has one shot on a node nobody rehearsed on: when the sharded pass fails on any rank (here: an
+    injected allocation failure inside rank 1's phase loop, which the library's vote turns into an error on every rank) the
+    ranks agree over a gloo side group and rank 0 still prints a line -- the replicas mode on GPUs, marked `sharded_failed` --
+    and all processes leave with exit code 0.  Second case: one rank raises alone while the other already waits in a collective
+    (it hears of it through the rendezvous store and stops waiting)."""
+    import json
+    env = dict(os.environ, FQSX_BENCH_EMU=os.path.join(ROOT, "tests", "emu", "libfqsx_emu.so"), FQSX_BENCH_SHARD_DEADLINE_S="120", **inject)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--reads", "3000", "--len", "90", "--genome", "40000", "--gs", "1", "--threads", "4"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1000:] + r.stderr[-3000:])
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["sharded_failed"]["ranks"], line
