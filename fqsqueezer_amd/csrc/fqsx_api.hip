@@ -240,9 +240,13 @@ FQ_KERNEL64 void k_pe_insert_buckets(DevCfg cfg) {   // grid = T (owner); also l
 FQ_KERNEL64 void k_pe_insert(DevCfg cfg) {
   FQ_SHARED InsShared sm;
   if (phase_skip(cfg)) return;
+  // (partitioned pair table: every rank holds every source's triples, but a sub-table is written by its owner's rank alone)
+  if (cfg.pe_part && FQ_BLOCK % cfg.shard_world != cfg.shard_rank) return;
   pe_insert_body(cfg, &sm, FQ_BLOCK, false, nullptr);
+  if (cfg.sys_scope) fq_release_system();
 }
-FQ_KERNEL void k_rehash_ptab(PTab o, PTab n, u32 n_sub) {
+// re-insert the occupied slots of sub-tables first, first + step, ... (n_sub of them) of `o` into the (empty, larger) table `n`
+FQ_KERNEL void k_rehash_ptab(PTab o, PTab n, u32 n_sub, u32 first, u32 step, u32 sys) {
   const u64 ocap = o.cap_mask + 1, total = ocap * n_sub;
 #ifndef FQSX_EMU
   const u64 gstride = (u64)gridDim.x * blockDim.x;
@@ -250,7 +254,7 @@ FQ_KERNEL void k_rehash_ptab(PTab o, PTab n, u32 n_sub) {
 #else
   for (u64 g = 0; g < total; ++g) {
 #endif
-    const u32 sub = (u32)(g / ocap);
+    const u32 sub = first + (u32)(g / ocap) * step;
     const u64 k = o.key[(u64)sub * o.stride + (g % ocap)], v = o.val[(u64)sub * o.stride + (g % ocap)];
     if (k == 0 && v == 0) continue;
     u64 *nk = n.key + (u64)sub * n.stride, *nv = n.val + (u64)sub * n.stride;
@@ -260,6 +264,7 @@ FQ_KERNEL void k_rehash_ptab(PTab o, PTab n, u32 n_sub) {
       p = (p + 1) & n.cap_mask;
     }
   }
+  if (sys) fq_release_system();
 }
 // re-insert every occupied slot of `o` into the (empty, larger) table `n`; layout-free, so parallel
 // n zero words at p (the chunks of a chunked table are cleared by a kernel of the codec's own stream, so that the order
@@ -401,19 +406,20 @@ FQ_KERNEL64 void k_shard_siv_sum(DevCfg cfg, const u64 *before, const u64 *gathe
 // Partitioned tables: a sub-table's occupancy counter is only kept by its owner's rank, but every rank needs all of them
 // for the growth rule (k_shard_need).  They ride along with the all-gather: out[which * n_max + j] = filled of this rank's
 // j-th own sub-table of the s- (which 0) / b-mer (1) table ...
-FQ_KERNEL64 void k_shard_fill_pack(DevCfg cfg, u64 *out, u32 n_max) {
-  for (u32 i = FQ_LANE; i < 2 * n_max; i += FQ_WAVE) {
+// (n_arr = 3: the pair table's counters behind them -- a partitioned pair table, cfg.pe_part)
+FQ_KERNEL64 void k_shard_fill_pack(DevCfg cfg, u64 *out, u32 n_max, u32 n_arr) {
+  for (u32 i = FQ_LANE; i < n_arr * n_max; i += FQ_WAVE) {
     const u32 which = i / n_max, o = cfg.shard_rank + (i % n_max) * cfg.shard_world;
-    out[i] = o < cfg.T ? (which ? cfg.g_b : cfg.g_s).filled[o] : 0;
+    out[i] = o < cfg.T ? (which == 2 ? cfg.g_pe.filled : which ? cfg.g_b.filled : cfg.g_s.filled)[o] : 0;
   }
 }
 // ... and the other ranks' counters into this rank's copy of the arrays
-FQ_KERNEL64 void k_shard_fill_unpack(DevCfg cfg, const u64 *gathered, u64 stride, u64 off, u32 n_max) {
+FQ_KERNEL64 void k_shard_fill_unpack(DevCfg cfg, const u64 *gathered, u64 stride, u64 off, u32 n_max, u32 n_arr) {
   for (u32 q = 0; q < cfg.shard_world; ++q) {
     if (q == cfg.shard_rank) continue;
-    for (u32 i = FQ_LANE; i < 2 * n_max; i += FQ_WAVE) {
+    for (u32 i = FQ_LANE; i < n_arr * n_max; i += FQ_WAVE) {
       const u32 which = i / n_max, o = q + (i % n_max) * cfg.shard_world;
-      if (o < cfg.T) (which ? cfg.g_b : cfg.g_s).filled[o] = (u32)gathered[(u64)q * stride + off + i];
+      if (o < cfg.T) (which == 2 ? cfg.g_pe.filled : which ? cfg.g_b.filled : cfg.g_s.filled)[o] = (u32)gathered[(u64)q * stride + off + i];
     }
   }
 }
@@ -628,8 +634,9 @@ struct fqsx_dna {
     u64 va_bytes = 0, chunk_bytes = 0;
     std::vector<fqsx_vm::Handle> h;   // [T] own (created) and imported chunks
     std::vector<u8> mapped;           // [T] chunk o is mapped (and its handle held)
+    u64 own_bytes = 0;                // physical memory of this rank's own chunks
     bool live = false;
-  } vm_s, vm_b;
+  } vm_s, vm_b, vm_pk, vm_pv;         // s-mer and b-mer table; the pair table's key and value arrays
   u64 vm_own_bytes;   // physical table memory held by this rank
 };
 
@@ -844,7 +851,7 @@ void vtab_drop(fqsx_dna *c, fqsx_dna::VmTab &v, u32 o) {
   (void)fqsx_vm::unmap(v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, e);
   (void)fqsx_vm::release(v.h[o], e);
   v.mapped[o] = 0;
-  if (o % c->shard_world == c->shard_rank) { c->dev_bytes -= v.chunk_bytes; c->vm_own_bytes -= v.chunk_bytes; }
+  if (o % c->shard_world == c->shard_rank) { c->dev_bytes -= v.chunk_bytes; c->vm_own_bytes -= v.chunk_bytes; v.own_bytes -= v.chunk_bytes; }
 }
 void vtab_free(fqsx_dna *c, fqsx_dna::VmTab &v) {
   if (!v.live) return;
@@ -864,8 +871,8 @@ void vtab_free(fqsx_dna *c, fqsx_dna::VmTab &v) {
 #endif
   v = fqsx_dna::VmTab();
 }
-// the address range of a table of T sub-tables with `cap` slots each; nothing mapped yet
-int vtab_reserve(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 cbits) {
+// the address range of T sub-tables with `cap` 8-byte slots each (*stride: slots from one sub-table to the next); nothing mapped yet
+int vtab_reserve_raw(fqsx_dna *c, fqsx_dna::VmTab &v, u64 cap, u64 *stride_out) {
   const u32 T = c->T;
 #ifndef FQSX_EMU
   // a chunk is at least 2 MiB (and 2 MiB-aligned, below): with 4 KiB-granular chunks the 1 M-read file ran 7 % slower than on
@@ -885,6 +892,13 @@ int vtab_reserve(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 c
   // (2 MiB alignment once the chunks are that large, so that the driver can use large page-table fragments)
   VMCHK(fqsx_vm::reserve(v.va_bytes, std::max<u64>(c->vm_gran, std::min<u64>(v.chunk_bytes, 2ull << 20)), &v.va, e_));
   v.live = true;
+  *stride_out = stride;
+  return FQSX_OK;
+}
+int vtab_reserve(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 cbits) {
+  u64 stride = 0;
+  const int rc = vtab_reserve_raw(c, v, cap, &stride);
+  if (rc) return rc;
   t.slots = (u64 *)v.va;
   t.nb = cap / FQSX_BKT;
   t.stride = stride;
@@ -895,7 +909,7 @@ int vtab_reserve(fqsx_dna *c, KTab &t, fqsx_dna::VmTab &v, u64 cap, u32 k, u32 c
 // this rank's sub-table o: physical memory, mapped, empty
 int vtab_create_own(fqsx_dna *c, fqsx_dna::VmTab &v, u32 o) {
   VMCHK(fqsx_vm::create(c->device, v.chunk_bytes, &v.h[o], e_));
-  c->dev_bytes += v.chunk_bytes; c->vm_own_bytes += v.chunk_bytes;
+  c->dev_bytes += v.chunk_bytes; c->vm_own_bytes += v.chunk_bytes; v.own_bytes += v.chunk_bytes;
   c->dev_bytes_peak = std::max(c->dev_bytes_peak, c->dev_bytes);
   VMCHK(fqsx_vm::map(c->device, v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, v.h[o], e_));
   v.mapped[o] = 1;
@@ -1008,16 +1022,61 @@ int ptab_alloc(fqsx_dna *c, PTab &t, u32 n_sub, u64 cap, bool with_filled) {
   }
   return FQSX_OK;
 }
+// the pair table as chunked table: key and value array in one address range each, one chunk per sub-table (both arrays have the
+// same stride, so the kernels index them alike); Collective in a world of several ranks
+int ptab_reserve(fqsx_dna *c, PTab &t, fqsx_dna::VmTab &vk, fqsx_dna::VmTab &vv, u64 cap) {
+  u64 sk = 0, sv = 0;
+  int rc;
+  if ((rc = vtab_reserve_raw(c, vk, cap, &sk)) || (rc = vtab_reserve_raw(c, vv, cap, &sv))) return rc;
+  t.key = (u64 *)vk.va;
+  t.val = (u64 *)vv.va;
+  t.cap_mask = cap - 1;
+  t.stride = sk;
+  return FQSX_OK;
+}
 int grow_gpe(fqsx_dna *c, u64 new_cap) {
   PTab n = c->cfg.g_pe;
-  int rc = ptab_alloc(c, n, c->T, new_cap, false);
-  if (rc) return rc;
-  LAUNCH(c, 2, k_rehash_ptab, REHASH_GRID, 256, c->cfg.g_pe, n, c->T);
+  int rc;
+  const char *auto_env = getenv("FQSX_CHUNK_AUTO_KB");
+  const u64 auto_bytes = (auto_env ? strtoull(auto_env, nullptr, 10) : (2048ull << 10)) << 10;
+  bool chunked = c->part || c->vm_pk.live;
+  if (!chunked && c->shard_world == 1 && auto_bytes && new_cap * c->T * sizeof(u64) >= auto_bytes) {   // (as grow_global)
+    if (!c->vm_gran) VMCHK(fqsx_vm::granularity(c->device, &c->vm_gran, e_));
+    chunked = c->vm_gran >= sizeof(u64) && !(c->vm_gran & (c->vm_gran - 1));
+  }
+  if (chunked) {   // sub-table by sub-table, every rank its own (see grow_global)
+    fqsx_dna::VmTab nk, nv;
+    const bool old_chunked = c->vm_pk.live;
+    if ((rc = ptab_reserve(c, n, nk, nv, new_cap))) return rc;
+    const u32 G = c->shard_world, n_own = (c->T - c->shard_rank + G - 1) / G;
+    const char *step_env = getenv("FQSX_CHUNK_STEP_KB");
+    const u64 step_bytes = (step_env ? strtoull(step_env, nullptr, 10) : (256ull << 10)) << 10;
+    const u32 per_step = (u32)std::max<u64>(1, std::min<u64>(n_own, step_bytes / (2 * nk.chunk_bytes)));
+    for (u32 j0 = 0; j0 < n_own; j0 += per_step) {
+      const u32 nb = std::min(per_step, n_own - j0), first = c->shard_rank + j0 * G;
+      for (u32 j = 0; j < nb; ++j)
+        if ((rc = vtab_create_own(c, nk, first + j * G)) || (rc = vtab_create_own(c, nv, first + j * G))) return rc;
+      LAUNCH(c, 2, k_rehash_ptab, REHASH_GRID, 256, c->cfg.g_pe, n, nb, first, G, c->cfg.sys_scope);
 #ifndef FQSX_EMU
-  HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
 #endif
-  dfree(c, c->cfg.g_pe.key);
-  dfree(c, c->cfg.g_pe.val);
+      if (old_chunked)
+        for (u32 j = 0; j < nb; ++j) { vtab_drop(c, c->vm_pk, first + j * G); vtab_drop(c, c->vm_pv, first + j * G); }
+    }
+    if ((rc = vtab_exchange(c, nk)) || (rc = vtab_exchange(c, nv))) return rc;
+    if (old_chunked) { vtab_free(c, c->vm_pk); vtab_free(c, c->vm_pv); }
+    else { dfree(c, c->cfg.g_pe.key); dfree(c, c->cfg.g_pe.val); }
+    c->vm_pk = nk;
+    c->vm_pv = nv;
+  } else {
+    if ((rc = ptab_alloc(c, n, c->T, new_cap, false))) return rc;
+    LAUNCH(c, 2, k_rehash_ptab, REHASH_GRID, 256, c->cfg.g_pe, n, c->T, 0u, 1u, 0u);
+#ifndef FQSX_EMU
+    HIPCHK(hipStreamSynchronize(c->stream));
+#endif
+    dfree(c, c->cfg.g_pe.key);
+    dfree(c, c->cfg.g_pe.val);
+  }
   c->cfg.g_pe = n;
   c->gpe_cap = new_cap;
   c->n_growths += 1;
@@ -1674,6 +1733,8 @@ void fqsx_dna_destroy(fqsx_dna *c) {
 #endif
   vtab_free(c, c->vm_s);
   vtab_free(c, c->vm_b);
+  vtab_free(c, c->vm_pk);
+  vtab_free(c, c->vm_pv);
   fqsx_vm::mesh_close(c->mesh);
   std::vector<void *> a = c->allocs;
   for (void *p : a) dfree(c, p);
@@ -2024,7 +2085,8 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
       M[k] = std::max(M[k], n_items[(u64)k * G + q]);
     }
   const u32 n_own_max = (T + G - 1) / G;
-  const u64 FW = c->part ? 2ull * n_own_max : 0;
+  const u32 n_fill = c->part ? (cfg.pe_part ? 3u : 2u) : 0u;   // occupancy arrays the owners report: s-mer, b-mer (, pair) table
+  const u64 FW = (u64)n_fill * n_own_max;
   if (c->paired)
     for (u32 s = 0; s < T; ++s) { pe_tot[s % G] += C[3ull * T * T + s]; PM = std::max(PM, pe_tot[s % G]); }
   const u64 off_k[3] = {0, M[0], M[0] + M[1]}, off_siv = M[0] + M[1] + M[2], off_fill = off_siv + 2, off_pe = off_fill + FW, W = off_pe + 3 * PM;
@@ -2059,7 +2121,7 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   for (u32 k = 0; k < 3; ++k)
     if (n_items[(u64)k * G + me]) LAUNCH(c, 2, k_shard_collect, REHASH_GRID, 256, cfg, k, c->d_items + off_k[k]);
   LAUNCH(c, 2, k_shard_siv_delta, 1, 64, cfg, (const u64 *)c->d_small, c->d_items + off_siv);
-  if (FW) LAUNCH(c, 2, k_shard_fill_pack, 1, 64, cfg, c->d_items + off_fill, n_own_max);
+  if (FW) LAUNCH(c, 2, k_shard_fill_pack, 1, 64, cfg, c->d_items + off_fill, n_own_max, n_fill);
   if (c->paired && PM) LAUNCH(c, 2, k_shard_pe_pack, T, 64, cfg, c->d_items + off_pe);
   COMMCHK(c->comm.allgather_u64(c->comm.ctx, c->d_items, W, c->d_gathered), "all-gather of the applied items");   // collective 3
   c->sh_gather_words += W * (G - 1);
@@ -2068,8 +2130,10 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
       for (u32 k = 0; k < 3; ++k)
         if (n_items[(u64)k * G + q]) LAUNCH(c, 2, k_shard_apply, REHASH_GRID, 256, cfg, k, (const u64 *)(c->d_gathered + (u64)q * W + off_k[k]), (u32)n_items[(u64)k * G + q]);
   LAUNCH(c, 2, k_shard_siv_sum, 1, 64, cfg, (const u64 *)c->d_small, (const u64 *)c->d_gathered, W, off_siv);
-  if (FW) LAUNCH(c, 2, k_shard_fill_unpack, 1, 64, cfg, (const u64 *)c->d_gathered, W, off_fill, n_own_max);
-  // ---- paired-end: every rank applies every source's triples to its replica of the pair table
+  if (FW) LAUNCH(c, 2, k_shard_fill_unpack, 1, 64, cfg, (const u64 *)c->d_gathered, W, off_fill, n_own_max, n_fill);
+  // ---- paired-end: every rank holds every source's triples (the all-gather above) and applies them to its replica of the pair
+  // table -- or, with partitioned tables, those of its own owners to its own sub-tables (k_pe_insert; the owners' occupancy
+  // counters came with the all-gather, so the growth rule below sees the same numbers on every rank)
   if (c->paired) {
     if (G > 1 && PM) LAUNCH(c, 2, k_shard_pe_unpack, T, 64, cfg, (const u64 *)c->d_gathered, W, off_pe, (const u32 *)(c->d_cglob + 3ull * T * T));
     LAUNCH(c, 2, k_pe_demand, T, 64, cfg, c->d_demand, 0u);
@@ -2077,11 +2141,20 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
     if ((rc = d2h_sync(c, c->h_filled.data(), cfg.g_pe.filled, T * sizeof(u32)))) return rc;
     u64 need = 0;
     for (u32 o = 0; o < T; ++o) need = std::max<u64>(need, (u64)c->h_filled[o] + c->h_demand[o]);
-    if (need * 2 > c->gpe_cap) {   // (the replicas of the pair table are exact: every rank grows in the same phase, and votes on it)
+    if (need * 2 > c->gpe_cap) {   // (replicas / exchanged occupancies are exact: every rank grows in the same phase, and votes on it)
       const int fail = grow_gpe(c, pow2_at_least(need * 2 + 2));
+      if (fail && c->part) fqsx_vm::mesh_close(c->mesh);
       if ((rc = shard_vote(c, fail, "the growth of the pair table"))) return rc;
     }
     LAUNCH(c, 2, k_pe_insert, T, 64, cfg);
+    if (cfg.pe_part) {
+      // The triples arrive with the phase's last collective, so these inserts are the one table update no collective follows --
+      // and the next segment's look-ups read the other ranks' sub-tables.  One more (one-word) all-reduce on the stream: no rank
+      // starts its next encode launch before every rank's inserts are complete.  (Sending the triples to their owners' ranks
+      // with the mailboxes instead -- inserts before the all-gather, as for the k-mer tables -- would save it: not built.)
+      COMMCHK(c->comm.allreduce_sum_u32(c->comm.ctx, c->d_cglob, 1), "barrier behind the pair-table inserts");
+      c->sh_collectives += 1;
+    }
     if ((rc = dzero(c, cfg.l_pe.key, c->cur_need_lpe * T * sizeof(u64)))) return rc;
     if ((rc = dzero(c, cfg.l_pe.val, c->cur_need_lpe * T * sizeof(u64)))) return rc;
     if ((rc = dzero(c, cfg.l_pe.filled, T * sizeof(u32)))) return rc;
@@ -2118,6 +2191,16 @@ int tables_to_chunks(fqsx_dna *c) {
   c->cfg.g_s.slots = c->cfg.g_b.slots = nullptr;
   if ((rc = vtab_alloc(c, c->cfg.g_s, c->vm_s, c->gs_cap, c->cfg.smer, 12))) return rc;
   if ((rc = vtab_alloc(c, c->cfg.g_b, c->vm_b, c->gb_cap, c->cfg.bmer, 6))) return rc;
+  if (c->paired) {   // the pair table with them: a rank holds (and writes) its own owners' sub-tables, key and value array alike
+    dfree(c, c->cfg.g_pe.key);
+    dfree(c, c->cfg.g_pe.val);
+    c->cfg.g_pe.key = c->cfg.g_pe.val = nullptr;
+    if ((rc = ptab_reserve(c, c->cfg.g_pe, c->vm_pk, c->vm_pv, c->gpe_cap))) return rc;
+    for (u32 o = c->shard_rank; o < c->T; o += c->shard_world)
+      if ((rc = vtab_create_own(c, c->vm_pk, o)) || (rc = vtab_create_own(c, c->vm_pv, o))) return rc;
+    if ((rc = vtab_exchange(c, c->vm_pk)) || (rc = vtab_exchange(c, c->vm_pv))) return rc;
+    c->cfg.pe_part = c->shard_world > 1 ? 1u : 0u;
+  }
 #ifndef FQSX_EMU
   HIPCHK(hipStreamSynchronize(c->stream));
 #endif
@@ -2413,7 +2496,8 @@ int fqsx_dna_capacity(fqsx_dna *c, uint64_t out[16]) {
     out[11] = c->gpe_cap * T;
   }
   out[12] = sizeof(u64);   // bytes per global-table slot
-  out[13] = c->vm_own_bytes + (c->vm_s.live ? 0 : c->gs_cap * T * sizeof(u64)) + (c->vm_b.live ? 0 : c->gb_cap * T * sizeof(u64));   // s- + b-mer table memory this rank holds
+  out[13] = (c->vm_s.live ? c->vm_s.own_bytes : c->gs_cap * T * sizeof(u64)) + (c->vm_b.live ? c->vm_b.own_bytes : c->gb_cap * T * sizeof(u64));   // s- + b-mer table memory this rank holds
+  if (c->paired) out[14] = c->vm_pk.live ? c->vm_pk.own_bytes + c->vm_pv.own_bytes : c->gpe_cap * T * 2 * sizeof(u64);   // pair-table memory this rank holds
   return FQSX_OK;
 }
 

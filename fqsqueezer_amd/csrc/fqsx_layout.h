@@ -214,7 +214,7 @@ struct DevCfg {
   u32 sys_scope;               // the s- / b-mer tables are partitioned over more than one rank: sub-tables of other GPUs are read
                                // through peer mappings, so the kernels that write own sub-tables end with a system-scope release and
                                // the kernels that look k-mers up start behind a system-scope acquire (fqsx_plat.h)
-  u32 pad_sys_;
+  u32 pe_part;                 // sharded mode, partitioned tables: the pair table is partitioned too -- a rank applies the triples of its own owners only
   const u8 *vmap;              // [256] owner -> position of its group in the partitioned mailbox: identity, or rank-major
                                // (all owners of rank 0, then rank 1, ...) so that what goes to one rank is contiguous
   u32 *shard_cnt;              // [3][T][T] entries source s pushed for owner o in this phase (own sources; else 0)

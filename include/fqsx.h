@@ -110,8 +110,9 @@ int fqsx_dna_stats(fqsx_dna *, uint64_t out[64]);
  * fqs/application.cpp:733-741): [0] distinct s-mers stored [1] distinct b-mers stored [2] s-mer table slots (all owners)
  * [3] b-mer table slots [4] p-mer vector bytes [5] context-table slots (all workers) [6] contexts stored
  * [7] device bytes held now [8] ... at most so far (old + new table during a growth included) [9] table growth events
- * [10] minimizer pairs stored (paired-end) [11] pair-table slots [12] bytes per k-mer table slot
- * [13] bytes of s- + b-mer table memory this rank holds (all of it, or its owners' share with partitioned tables). */
+ * [10] minimizer pairs stored (paired-end) [11] pair-table slots (16 bytes each) [12] bytes per k-mer table slot
+ * [13] bytes of s- + b-mer table memory this rank holds (all of it, or its owners' share with partitioned tables)
+ * [14] bytes of pair-table memory this rank holds (likewise). */
 int fqsx_dna_capacity(fqsx_dna *, uint64_t out[16]);
 
 /* One GPU's capacity mode (no counterpart in the reference, whose sub-tables are separate heap vectors that grow one by one,
@@ -164,7 +165,10 @@ int fqsx_shard_traffic(fqsx_dna *, uint64_t out[4]);
  * sees one table in one address range and a look-up of a foreign sub-table is a load over xGMI.  Writes stay with the owner
  * (insert phase); the phase's collectives order them before the next look-ups.  The all-gather of a phase then carries no
  * k-mer items, only the owners' occupancy counters, the p-mer items and statistics and the paired-end triples (the p-mer
- * vector and the pair table stay replicated).  Streams are bit-identical to the one-GPU run's.
+ * vector stays replicated).  A paired-end codec's pair table (fqs/application.h:54 ht_pe_mers, owner function
+ * fqs/ht_kmer.h:599-602) is partitioned the same way: every rank receives every source's triples but applies those of its
+ * own owners only, and a fourth one-word all-reduce closes such a phase (the inserts follow the phase's last collective).
+ * Streams are bit-identical to the one-GPU run's.
  * Memory order: the kernels that write own sub-tables (insert phase, growth) end with a system-scope release and the encode /
  * decode kernels start behind a system-scope acquire (csrc/fqsx_plat.h), so that an owner's writes are in its HBM before the
  * phase's last collective and no GPU serves a foreign look-up from a line it cached in an earlier launch.

@@ -89,6 +89,20 @@ def test_emu_paired_end_growth_posted_by_the_device_is_recovered(name, monkeypat
     assert cap["growths"] >= 8 and cap["pair_slots"] > 64 * 4, cap
 
 
+@pytest.mark.parametrize("name", ["c5_pe4k_o_t4.fqs", "c5_pe4k_s_t4.fqs"])
+def test_emu_paired_end_chunked_pair_table(name, monkeypatch):
+    """chunked tables of a paired-end codec: the pair table's key and value arrays are chunked with the k-mer tables (one chunk per
+    sub-table and array), and grow sub-table by sub-table"""
+    monkeypatch.setenv("FQSX_GTAB_INIT", "256")
+    monkeypatch.setenv("FQSX_PTAB_INIT", "64")
+    monkeypatch.setenv("FQSX_CHUNK_STEP_KB", "1")
+    monkeypatch.setenv("FQSX_CHUNKED_TABLES", "1")
+    codec = check_against_fqs_pe(emu, c5_records(), name)
+    cap = codec.capacity()
+    assert cap["growths"] >= 8 and cap["pair_slots"] > 64 * 4, cap
+    assert 0 <= cap["pair_bytes_held"] - 16 * cap["pair_slots"] <= 2 * 4 * 4096, cap
+
+
 @pytest.mark.parametrize("name", ["c20_pelong_o_t2.fqs", "c20_pelong_s_t2.fqs"])
 def test_emu_paired_end_mates_longer_than_the_lds_staging(name):
     """5000 bp mates (the reference takes up to 2^24 bases, fqs/meta.cpp:69): code lines and the reverse-complement line of an

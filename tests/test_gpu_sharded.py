@@ -51,10 +51,14 @@ cap, cap1 = sh.codec.capacity(), one.capacity()
 assert (cap["smers"], cap["bmers"]) == (cap1["smers"], cap1["bmers"]), (cap, cap1)
 assert cap["growths"] >= 2, cap
 lst = [None] * world
-dist.all_gather_object(lst, (cap["table_bytes_held"], 8 * (cap["smer_slots"] + cap["bmer_slots"]), sh.traffic))
+dist.all_gather_object(lst, (cap["table_bytes_held"], 8 * (cap["smer_slots"] + cap["bmer_slots"]), sh.traffic, cap["pair_bytes_held"], 16 * cap["pair_slots"]))
 if rank == 0:
     held, whole = [x[0] for x in lst], lst[0][1]   # (held counts whole chunks, and a chunk is at least 2 MiB: >= for these small tables)
     assert sum(held) >= whole and max(held) * T <= sum(held) * ((T + world - 1) // world), (held, whole)
+    if mode.startswith("pe"):   # the pair table is partitioned with them: a rank holds (and writes) its owners' sub-tables only
+        pheld, pwhole = [x[3] for x in lst], lst[0][4]
+        assert (cap["pairs"], cap["pair_slots"]) == (cap1["pairs"], cap1["pair_slots"]) and cap["pair_slots"] > 256 * T, (cap, cap1)
+        assert sum(pheld) >= pwhole and max(pheld) * T <= sum(pheld) * ((T + world - 1) // world), (pheld, pwhole)
     print("PARTITIONED_GPU_OK", world, T, mode, held, whole, lst[0][2])
 sh.close(); one.close()
 dist.destroy_process_group()
@@ -65,7 +69,7 @@ dist.destroy_process_group()
 def test_partitioned_tables_ranks_share_one_gpu(tmp_path, world, T, mode, port):
     script = tmp_path / "w.py"
     script.write_text(WORKER)
-    env = dict(os.environ, FQSX_ROOT=ROOT, FQSX_T=str(T), FQSX_MODE=mode, FQSX_GTAB_INIT="1024")   # (small tables: several collective growths)
+    env = dict(os.environ, FQSX_ROOT=ROOT, FQSX_T=str(T), FQSX_MODE=mode, FQSX_GTAB_INIT="1024", FQSX_PTAB_INIT="256")   # (small tables: several collective growths)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)

@@ -95,13 +95,14 @@ for g, (bases, off) in enumerate(blocks):
         assert s == ref[w], f"rank {rank}: block {g} worker {w} differs from the one-process run"
 tr = sh.traffic
 # three collectives per phase + one status vote in each phase in which buffers or tables grow (every rank alike): a few per file
-votes = tr["collectives"] - 3 * tr["phases"]
+# (a partitioned pair table: one more per phase, the barrier behind its inserts)
+votes = tr["collectives"] - (4 if part and mode.startswith("pe") and world > 1 else 3) * tr["phases"]
 assert 0 <= votes <= tr["phases"] // 2 and tr["phases"] > len(blocks), tr
 cap, cap1 = sh.codec.capacity(), one.capacity()
 assert (cap["smers"], cap["bmers"]) == (cap1["smers"], cap1["bmers"])     # every rank knows every sub-table's occupancy
 assert cap["growths"] >= 2, cap                                              # the tables grew on the way (from 64-slot sub-tables)
 lst = [None] * world
-dist.all_gather_object(lst, (tr, cap["table_bytes_held"], 8 * (cap["smer_slots"] + cap["bmer_slots"])))
+dist.all_gather_object(lst, (tr, cap["table_bytes_held"], 8 * (cap["smer_slots"] + cap["bmer_slots"]), cap["pair_bytes_held"], 16 * cap["pair_slots"]))
 if rank == 0:
     assert tr["all_to_all_bytes"] > 0 and tr["all_gather_bytes"] > 0
     held, whole = [x[1] for x in lst], lst[0][2]
@@ -109,8 +110,14 @@ if rank == 0:
         # (a sub-table is one chunk: its capacity rounded up to the allocation granule, a page in this build)
         slack = 2 * T * 4096
         assert whole <= sum(held) <= whole + slack and max(held) <= (whole + slack) * ((T + world - 1) // world) // T, (held, whole)
+        # the pair table of a paired-end file with them (key and value array: two chunks per sub-table); it grew on the way
+        pheld, pwhole = [x[3] for x in lst], lst[0][4]
+        if mode.startswith("pe"):
+            assert pwhole > 16 * 64 * T and pwhole <= sum(pheld) <= pwhole + slack and max(pheld) <= (pwhole + slack) * ((T + world - 1) // world) // T, (pheld, pwhole)
+            assert (cap["pairs"], cap["pair_slots"]) == (cap1["pairs"], cap1["pair_slots"])   # (the owners' occupancies travel with the all-gather)
     else:
         assert all(h == whole for h in held), (held, whole)
+        assert all(x[3] == x[4] for x in lst), lst
     print("NATIVE_SHARDED_OK", world, T, mode, "partitioned" if part else "replicas", held, whole, lst[0][0])
 dist.destroy_process_group()
 '''
@@ -126,7 +133,7 @@ def test_native_sharded_driver_streams_identical_to_one_process_run(tmp_path, bu
     script = tmp_path / "w.py"
     script.write_text(NATIVE_WORKER)
     env = dict(os.environ, FQSX_ROOT=ROOT, FQSX_EMU_LIB=os.path.join(ROOT, "tests", "emu", "libfqsx_emu.so"), FQSX_T=str(T), FQSX_MODE=mode,
-               FQSX_PARTITION=str(partition), FQSX_GTAB_INIT="64",
+               FQSX_PARTITION=str(partition), FQSX_GTAB_INIT="64", FQSX_PTAB_INIT="64",
                FQSX_SHARD_APPLY_OWN="1" if world == 2 else "0")   # (world 2 also applies the rank's own items to its replica: must change nothing)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
