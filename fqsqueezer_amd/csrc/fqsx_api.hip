@@ -1518,6 +1518,7 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   c->tab_small_pct = 40;
   if (const char *e = getenv("FQSX_TAB_AFTER_PCT")) c->tab_small_pct = c->tab_after_pct = (u32)std::min<u64>(c->tab_load_pct - 5, std::max<u64>(10, strtoull(e, nullptr, 10)));
   cfg.tab_load_pct = c->tab_load_pct;
+  if (const char *e = getenv("FQSX_WHATIF")) { u32 r = 0, u = 0; if (sscanf(e, "%u,%u", &r, &u) == 2) cfg.whatif = (r << 16) | (u & 0xffffu); }
   c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(1024, (1ull << 22) / T));
   if (const char *e = getenv("FQSX_GTAB_INIT")) c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(64, strtoull(e, nullptr, 10)));   // (tests: growth from tiny tables)
   if ((rc = ktab_alloc(c, cfg.g_s, T, c->gs_cap, cfg.smer, 12, true))) return rc;

@@ -1105,6 +1105,18 @@ FQ_DEV u64 siv_count_equal(Wk &w, u64 lo, u64 hi, u64 flag) {
 // The coder state is wave-uniform and kept in scalar registers (readfirstlane at enc_open), so the dependent chain of
 // a coding step -- multiply-high, compare, add, shift -- runs on the scalar unit.  Output bytes are gathered into the
 // aligned 8-byte word they belong to and leave with one store per word.
+// What-if profiling (-DFQSX_WHATIF, tools/gpu_whatif.py): `ev` events of role `role` cost an extra ev * units * ~0.2 us when the
+// run asks for that role (DevCfg.whatif) -- the file's slowdown per microsecond added says how much of the role is critical path.
+#ifdef FQSX_WHATIF
+FQ_DEV void whatif_delay(const DevCfg &cfg, u32 role, u32 ev) {
+  if ((cfg.whatif >> 16) != role) return;
+  const u32 n = (cfg.whatif & 0xffffu) * ev;
+  for (u32 i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+}
+#define WHATIF(cfg, role, ev) whatif_delay(cfg, role, ev)
+#else
+#define WHATIF(cfg, role, ev) do { } while (0)
+#endif
 FQ_DEV void enc_open(Wk &w, u64 low, u64 range, u64 len, const DevCfg &cfg) {
   w.enc.low = uniform64(low); w.enc.range = uniform64(range); w.enc.len = uniform64(len);
   w.enc.cap = cfg.out_cap; w.enc.out = cfg.out + (u64)w.tid * cfg.out_cap;
@@ -3336,6 +3348,7 @@ FQ_DEV void suffix(Wk &w, const u8 *p, u32 size, bool original_order, u32 start_
     if ((dbg & FQSX_DBG_ABANDON) && w.scout && w.sc_read % 3 == 2 && at != at_first) w.sc_abandoned = true;   // ... this one after its first chunk
     bool pre = false;
     u32 n, j0 = 0;
+    WHATIF(*w.cfg, 1, 1);
     if (!(at >= own_lo && at < own_hi) && w.scout && !w.sc_abandoned) pre = scout_seek(w, at, fixed, fixed_pub);   // stage P done ahead of time by a scout wave
     if (pre) {
       // lanes a scout has speculated again for a repair it foresaw (scout_fix) are only good if this wave took that
@@ -3909,7 +3922,10 @@ FQ_DEV void coder_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg
     const u32 tail = lds_load_acq(&sm->cq_tail);
     if (tail != head) {
       TM_BEGIN(t_c);
+      const u32 head0 = head;
       head += cq_process(w, head, tail - head);
+      (void)head0;
+      WHATIF(cfg, 2, (head >> 6) - (head0 >> 6));   // (per 64 queue entries ~ per chunk)
       FQ_SYNC();
       lds_store_rel(&sm->cq_head, head);
       TM_END(w, TM_FAST, t_c);
@@ -3985,6 +4001,7 @@ FQ_DEV void rc_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 seg, u
         rc_encode_m(w, sm->rq_f[e], sm->rq_c[e], sm->rq_t[e], sm->rq_m[e]);
       }
 #endif
+      WHATIF(cfg, 3, ((head + n) >> 6) - (head >> 6));
       head += n;
       FQ_SYNC();
       lds_store_rel(&sm->rq_head, head);
@@ -4026,6 +4043,7 @@ FQ_DEV void inserter_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 
       if (tgt > la[qi]) {
         const Mail &m = cfg.mail[kind];
         const u32 n = tgt - la[qi] < FQ_WAVE ? tgt - la[qi] : FQ_WAVE;
+        WHATIF(cfg, 6, 1);
         insert_batch(cfg, sm, qi ? cfg.l_s : cfg.l_b, tid, m.list + (u64)tid * m.cap + la[qi], n, qi ? RNG_LS : RNG_LB,
                      qi ? CINC_S : CINC_B, ns, err);
         if (err) {   // table full: report, and release every waiter
@@ -4082,6 +4100,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
   u64 stop = last;
   if (seg < S) stop = ((u64)seg + 1) * (last - first) / ((u64)S + 1) + first + 1;   // application.cpp:643
   if (stop > last) stop = last;
+  WHATIF(cfg, 7, 1);   // (once per launch, ahead of everything: the calibration of the what-if profile)
   for (u64 i = cur; i < stop && !w.err; ++i) {
     const u32 idx = (u32)(i - cur);
     u32 spins = 0;
@@ -4112,6 +4131,7 @@ FQ_DEV void head_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_re
       prev_size = (u32)(o0 - q0);
     }
     u32 hist[4];
+    WHATIF(cfg, 5, 1);
     const bool same = read_head(w, cfg.bases + o0, (u32)(o1 - o0), prev, prev_size, true, hist);
     FQ_SYNC();
     if (FQ_LANE == 0) {
@@ -4271,6 +4291,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         SpecLane spl;
         SpecHead sph;
         TM_BEGIN(t_sp);
+        WHATIF(cfg, 4, 1);
         const bool whole = speculate_t<true>(w, p, size, i0, n, false, i0 - base_pos, 0, &spl, &sph);
         TM_END(w, TM_SC_SPEC, t_sp);
         if (!whole) { TM_COUNT(w, CN_SC_ABORT); restart = true; break; }
@@ -4302,6 +4323,7 @@ FQ_DEV void scout_segment_body(const DevCfg &cfg, WgShared *sm, u32 tid, u32 n_r
         lds_store_rel(&w.sb->h_pub, seq + 1);   // the resolving wave may start on the chunk ...
 #if FQ_WAVE > 1
         TM_BEGIN(t_sr);
+        WHATIF(cfg, 8, 1);
         scout_rough(w, n_sw);                    // ... while its sweeps are still being probed (rr_front)
         TM_END(w, TM_SC_ROUGH, t_sr);
 #endif
@@ -4716,6 +4738,7 @@ FQ_DEV void insert_batch_k(const DevCfg &cfg, SM *sm, const KTab &t, u32 tid, u6
 #endif
 #undef IB_MARK
 }
+
 
 // ---- stable partition of the mailbox lists by owner -----------------------------------------
 FQ_DEV u32 mail_owner(const DevCfg &cfg, u32 kind, u64 x) { return kind == MAIL_P ? p_owner(&cfg, x) : sb_owner(&cfg, x); }

@@ -210,7 +210,8 @@ struct DevCfg {
   // lives on rank w % shard_world; every rank holds a read-only replica of all sub-tables.  shard_world == 1: one GPU.
   u32 shard_rank, shard_world;
   u32 tab_load_pct;            // a global s- / b-mer sub-table is grown before an insert phase would fill it beyond this (host: fqsx_dna.tab_load_pct)
-  u32 pad_tab_;
+  u32 whatif;                  // -DFQSX_WHATIF builds (tools/gpu_whatif.py): (role << 16) | delay units -- one role is slowed down, the file's rate says
+                               // how much of that role's time is on the critical path; product builds never read it
   u32 sys_scope;               // the s- / b-mer tables are partitioned over more than one rank: sub-tables of other GPUs are read
                                // through peer mappings, so the kernels that write own sub-tables end with a system-scope release and
                                // the kernels that look k-mers up start behind a system-scope acquire (fqsx_plat.h)
