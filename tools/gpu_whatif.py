@@ -17,11 +17,22 @@ from fqsqueezer_amd import hostpipe as hp
 from fqsqueezer_amd.codec import DnaCodec
 from fqsqueezer_amd.synth import read_id, synth_reads
 units = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-reads = synth_reads(1_000_000, 150, 7_500_000, 2)
+# [reads genome gs seed reps roles]: another file (e.g. 10000000 300000000 300 19 1 1,4,5,6,8 = the bench's large-file row)
+n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+genome = int(sys.argv[3]) if len(sys.argv) > 3 else 7_500_000
+gs = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+seed = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+reps = int(sys.argv[6]) if len(sys.argv) > 6 else 2
+roles = [int(x) for x in sys.argv[7].split(",")] if len(sys.argv) > 7 else [1, 2, 3, 4, 5, 6, 7, 8]
+reads = synth_reads(n_reads, 150, genome, seed)
 rec = hp.Records([read_id(i) for i in range(len(reads))], reads, reads)
-header = hp.make_header(64, "se_sorted", 8)
+header = hp.make_header(64, "se_sorted", gs)
+groups = None
+if n_reads > 2_000_000:
+    from fqsqueezer_amd.codec import sort_order
+    groups = sort_order(reads.reshape(-1), np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(150), device=0)
 dev = []
-for idx in hp.form_blocks(rec, "se_sorted"):
+for idx in hp.form_blocks(rec, "se_sorted", groups=groups):
     bases, off = hp.block_arrays(rec, idx)
     dev.append((torch.from_numpy(np.ascontiguousarray(bases)).cuda(), torch.from_numpy(off.view(np.int64)).cuda(), off))
 nb = [int(o[-1]) for _, _, o in dev]
@@ -30,7 +41,7 @@ nb = [int(o[-1]) for _, _, o in dev]
 def one(role):
     os.environ["FQSX_WHATIF"] = f"{role},{units if role else 0}"
     best = None
-    for rep in range(2):
+    for rep in range(reps):
         c = DnaCodec(header, device=0, lib_path=LIB)
         marks = [time.perf_counter()]
         tot = 0
@@ -50,8 +61,8 @@ names = {0: "none", 1: "resolving wave (per chunk iteration)", 2: "models wave (
 base = one(0)
 chunks_per_read = 2.2
 n_reads = len(reads)
-out = {"units": units, "us_per_event": round(units * 0.213, 3), "baseline": base, "roles": {}}
-for role in (1, 2, 3, 4, 5, 6, 7, 8):
+out = {"file": [n_reads, genome, gs, seed], "units": units, "us_per_event": round(units * 0.213, 3), "baseline": base, "roles": {}}
+for role in roles:
     r = one(role)
     assert r["dna_bytes"] == base["dna_bytes"]
     # events per worker over the file (rough): chunk iterations ~ reads/64 workers * 2.2 ...; report the raw slowdowns, and the
