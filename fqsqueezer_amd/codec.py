@@ -159,7 +159,7 @@ class DnaCodec:
             raise FqsxError(f"fqsx_dna_capacity: {rc}: {self._lib.fqsx_last_error().decode()}")
         d = {"smers": a[0], "bmers": a[1], "smer_slots": a[2], "bmer_slots": a[3], "siv_bytes": a[4], "ctx_slots": a[5],
              "contexts": a[6], "device_bytes": a[7], "device_bytes_peak": a[8], "growths": a[9], "pairs": a[10], "pair_slots": a[11],
-             "table_bytes_held": a[13], "pair_bytes_held": a[14]}
+             "table_bytes_held": a[13], "pair_bytes_held": a[14], "siv_bytes_held": a[15]}
         d["bytes_per_bmer"] = round(a[3] * a[12] / a[1], 2) if a[1] else 0.0
         d["bytes_per_smer"] = round(a[2] * a[12] / a[0], 2) if a[0] else 0.0
         return d

@@ -15,6 +15,7 @@
 #include "fqsx_qual.h"
 #include "../../include/fqsx.h"
 #include "fqsx_vm.h"
+#include <sys/resource.h>
 
 #ifndef FQSX_EMU
 #include <dlfcn.h>
@@ -517,6 +518,10 @@ FQ_KERNEL void k_shard_apply(DevCfg cfg, u32 kind, const u64 *items, u32 n) {
 #endif
   for (u32 e = first; e < n; e += stride) {
     const u64 item = items[e];
+    if (kind == MAIL_P && cfg.siv_part) {   // a transition an owner on another rank logged: only the count index is a replica
+      if (item) siv_idx_move(cfg, item >> 4, (u32)((item >> 2) & 3), (u32)(item & 3));
+      continue;
+    }
     if (kind == MAIL_P) {
       const u64 idx = item >> 2, val = item & 3;
       u64 *wp = cfg.siv + (idx >> 5);
@@ -635,8 +640,10 @@ struct fqsx_dna {
     std::vector<fqsx_vm::Handle> h;   // [T] own (created) and imported chunks
     std::vector<u8> mapped;           // [T] chunk o is mapped (and its handle held)
     u64 own_bytes = 0;                // physical memory of this rank's own chunks
+    u32 own_mod = 0;                  // chunk c lives on rank c % world (0), or -- the p-mer vector's owner ranges -- (c % own_mod) % world
     bool live = false;
-  } vm_s, vm_b, vm_pk, vm_pv;         // s-mer and b-mer table; the pair table's key and value arrays
+  } vm_s, vm_b, vm_pk, vm_pv, vm_siv; // s-mer and b-mer table; the pair table's key and value arrays; the p-mer vector (4096 chunks)
+  u32 *d_plog_n;                      // counter of the p-mer transition log (DevCfg.p_log_n)
   u64 vm_own_bytes;   // physical table memory held by this rank
 };
 
@@ -845,18 +852,19 @@ int ktab_alloc(fqsx_dna *c, KTab &t, u32 n_sub, u64 cap, u32 k, u32 cbits, bool 
 #define VMCHK(x) do { std::string e_; if (g_vm_dbg) fprintf(stderr, "[fqsx vm] %s\n", #x); if ((x)) { g_err = "partitioned tables: " + e_; return FQSX_E_HIP; } } while (0)
 static const bool g_vm_dbg = getenv("FQSX_VM_DEBUG") != nullptr;
 // one chunk out of the range (its memory goes back to the device once every rank that imported it has let go of it too)
+u32 vt_rank(const fqsx_dna *c, const fqsx_dna::VmTab &v, u32 o) { return (v.own_mod ? o % v.own_mod : o) % c->shard_world; }
 void vtab_drop(fqsx_dna *c, fqsx_dna::VmTab &v, u32 o) {
   if (!v.live || !v.mapped[o]) return;
   std::string e;
   (void)fqsx_vm::unmap(v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, e);
   (void)fqsx_vm::release(v.h[o], e);
   v.mapped[o] = 0;
-  if (o % c->shard_world == c->shard_rank) { c->dev_bytes -= v.chunk_bytes; c->vm_own_bytes -= v.chunk_bytes; v.own_bytes -= v.chunk_bytes; }
+  if (vt_rank(c, v, o) == c->shard_rank) { c->dev_bytes -= v.chunk_bytes; c->vm_own_bytes -= v.chunk_bytes; v.own_bytes -= v.chunk_bytes; }
 }
 void vtab_free(fqsx_dna *c, fqsx_dna::VmTab &v) {
   if (!v.live) return;
   std::string e;
-  for (u32 o = 0; o < c->T; ++o) vtab_drop(c, v, o);
+  for (u32 o = 0; o < (u32)v.h.size(); ++o) vtab_drop(c, v, o);
 #ifdef FQSX_EMU
   (void)fqsx_vm::unreserve(v.va, v.va_bytes, e);
 #else
@@ -872,8 +880,8 @@ void vtab_free(fqsx_dna *c, fqsx_dna::VmTab &v) {
   v = fqsx_dna::VmTab();
 }
 // the address range of T sub-tables with `cap` 8-byte slots each (*stride: slots from one sub-table to the next); nothing mapped yet
-int vtab_reserve_raw(fqsx_dna *c, fqsx_dna::VmTab &v, u64 cap, u64 *stride_out) {
-  const u32 T = c->T;
+int vtab_reserve_raw(fqsx_dna *c, fqsx_dna::VmTab &v, u64 cap, u64 *stride_out, u32 n_chunks = 0) {
+  const u32 T = n_chunks ? n_chunks : c->T;
 #ifndef FQSX_EMU
   // a chunk is at least 2 MiB (and 2 MiB-aligned, below): with 4 KiB-granular chunks the 1 M-read file ran 7 % slower than on
   // hipMalloc'ed tables (blocks 0-69: 10 %) -- page-table fragments of the size of the chunk
@@ -919,26 +927,38 @@ int vtab_create_own(fqsx_dna *c, fqsx_dna::VmTab &v, u32 o) {
 }
 // Collective: every rank hands the descriptors of its own chunks to every other rank and maps what it receives
 int vtab_exchange(fqsx_dna *c, fqsx_dna::VmTab &v) {
-  const u32 T = c->T, G = c->shard_world, me = c->shard_rank;
+  const u32 T = (u32)v.h.size(), G = c->shard_world, me = c->shard_rank;
   if (G == 1) return FQSX_OK;
-  std::vector<int> mine;
-  for (u32 o = me; o < T; o += G) {
-    int fd = -1;
-    VMCHK(fqsx_vm::export_fd(v.h[o], &fd, e_));
-    mine.push_back(fd);
-  }
-  for (u32 i = 1; i < G; ++i) VMCHK(fqsx_vm::send_fds(c->mesh.peer[(me + i) % G], mine.data(), (u32)mine.size(), e_));
-  for (int fd : mine) close(fd);
-  for (u32 i = 1; i < G; ++i) {
-    const u32 q = (me + G - i) % G, n_q = (T - q + G - 1) / G;
-    std::vector<int> theirs(n_q, -1);
-    VMCHK(fqsx_vm::recv_fds(c->mesh.peer[q], theirs.data(), n_q, e_));
-    for (u32 j = 0; j < n_q; ++j) {
-      const u32 o = q + j * G;
-      VMCHK(fqsx_vm::import_fd(theirs[j], &v.h[o], e_));
-      close(theirs[j]);
-      VMCHK(fqsx_vm::map(c->device, v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, v.h[o], e_));
-      v.mapped[o] = 1;
+  // (in rounds of at most 128 chunks per rank, so that a table of thousands of chunks -- the p-mer vector -- never has more
+  // descriptors open at once than a process may hold; every rank walks the same rounds)
+  std::vector<std::vector<u32>> of(G);
+  for (u32 o = 0; o < T; ++o) of[vt_rank(c, v, o)].push_back(o);
+  size_t longest = 0;
+  for (u32 q = 0; q < G; ++q) longest = std::max(longest, of[q].size());
+  const size_t R = 128;
+  for (size_t r0 = 0; r0 < longest; r0 += R) {
+    std::vector<int> mine;
+    for (size_t j = r0; j < std::min(of[me].size(), r0 + R); ++j) {
+      int fd = -1;
+      VMCHK(fqsx_vm::export_fd(v.h[of[me][j]], &fd, e_));
+      mine.push_back(fd);
+    }
+    if (!mine.empty())
+      for (u32 i = 1; i < G; ++i) VMCHK(fqsx_vm::send_fds(c->mesh.peer[(me + i) % G], mine.data(), (u32)mine.size(), e_));
+    for (int fd : mine) close(fd);
+    for (u32 i = 1; i < G; ++i) {
+      const u32 q = (me + G - i) % G;
+      if (r0 >= of[q].size()) continue;
+      const u32 n_q = (u32)(std::min(of[q].size(), r0 + R) - r0);
+      std::vector<int> theirs(n_q, -1);
+      VMCHK(fqsx_vm::recv_fds(c->mesh.peer[q], theirs.data(), n_q, e_));
+      for (u32 j = 0; j < n_q; ++j) {
+        const u32 o = of[q][r0 + j];
+        VMCHK(fqsx_vm::import_fd(theirs[j], &v.h[o], e_));
+        close(theirs[j]);
+        VMCHK(fqsx_vm::map(c->device, v.va + (u64)o * v.chunk_bytes, v.chunk_bytes, v.h[o], e_));
+        v.mapped[o] = 1;
+      }
     }
   }
   return FQSX_OK;
@@ -1736,6 +1756,7 @@ void fqsx_dna_destroy(fqsx_dna *c) {
   vtab_free(c, c->vm_b);
   vtab_free(c, c->vm_pk);
   vtab_free(c, c->vm_pv);
+  vtab_free(c, c->vm_siv);
   fqsx_vm::mesh_close(c->mesh);
   std::vector<void *> a = c->allocs;
   for (void *p : a) dfree(c, p);
@@ -2117,10 +2138,15 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   LAUNCH(c, 2, k_shard_merge3, 3 * T, 64, cfg, (const u64 *)c->d_xrecv[0], (const u64 *)c->d_xrecv[1], (const u64 *)c->d_xrecv[2], (const u32 *)c->d_cglob);
   // ---- insert phase of own owners
   if ((rc = d2d(c, c->d_small, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
+  if (cfg.siv_part) {   // the owners log every field they change straight into the all-gather's p-mer items (zero = no item)
+    cfg.p_log = c->d_items + off_k[MAIL_P];
+    if (M[MAIL_P]) LAUNCH(c, 2, k_zero_words, (u32)std::min<u64>(REHASH_GRID, (M[MAIL_P] + 255) / 256), 256, cfg.p_log, M[MAIL_P], 0u);
+    if ((rc = dzero(c, c->d_plog_n, sizeof(u32)))) return rc;
+  }
   LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
   // ---- one all-gather
   for (u32 k = 0; k < 3; ++k)
-    if (n_items[(u64)k * G + me]) LAUNCH(c, 2, k_shard_collect, REHASH_GRID, 256, cfg, k, c->d_items + off_k[k]);
+    if (n_items[(u64)k * G + me] && !(k == MAIL_P && cfg.siv_part)) LAUNCH(c, 2, k_shard_collect, REHASH_GRID, 256, cfg, k, c->d_items + off_k[k]);
   LAUNCH(c, 2, k_shard_siv_delta, 1, 64, cfg, (const u64 *)c->d_small, c->d_items + off_siv);
   if (FW) LAUNCH(c, 2, k_shard_fill_pack, 1, 64, cfg, c->d_items + off_fill, n_own_max, n_fill);
   if (c->paired && PM) LAUNCH(c, 2, k_shard_pe_pack, T, 64, cfg, c->d_items + off_pe);
@@ -2129,7 +2155,7 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   for (u32 q = 0; q < G; ++q)
     if (q != me || c->shard_apply_own)
       for (u32 k = 0; k < 3; ++k)
-        if (n_items[(u64)k * G + q]) LAUNCH(c, 2, k_shard_apply, REHASH_GRID, 256, cfg, k, (const u64 *)(c->d_gathered + (u64)q * W + off_k[k]), (u32)n_items[(u64)k * G + q]);
+        if (n_items[(u64)k * G + q] && !(k == MAIL_P && cfg.siv_part && q == me)) LAUNCH(c, 2, k_shard_apply, REHASH_GRID, 256, cfg, k, (const u64 *)(c->d_gathered + (u64)q * W + off_k[k]), (u32)n_items[(u64)k * G + q]);
   LAUNCH(c, 2, k_shard_siv_sum, 1, 64, cfg, (const u64 *)c->d_small, (const u64 *)c->d_gathered, W, off_siv);
   if (FW) LAUNCH(c, 2, k_shard_fill_unpack, 1, 64, cfg, (const u64 *)c->d_gathered, W, off_fill, n_own_max, n_fill);
   // ---- paired-end: every rank holds every source's triples (the all-gather above) and applies them to its replica of the pair
@@ -2201,6 +2227,40 @@ int tables_to_chunks(fqsx_dna *c) {
       if ((rc = vtab_create_own(c, c->vm_pk, o)) || (rc = vtab_create_own(c, c->vm_pv, o))) return rc;
     if ((rc = vtab_exchange(c, c->vm_pk)) || (rc = vtab_exchange(c, c->vm_pv))) return rc;
     c->cfg.pe_part = c->shard_world > 1 ? 1u : 0u;
+  }
+  // the p-mer vector (application.h:51 siv_pmer; owner of an index: its top 12 bits mod T, dna.cpp:658): 4096 owner ranges = 4096
+  // chunks, each on its owner's rank -- where a range is as large as a chunk may be small (2 MiB on the GPU: the 16 GiB vector of the
+  // default geometry has 4 MiB ranges); smaller vectors stay replicas.  The count index (1/256 of the vector) stays a replica.
+  if (c->shard_world > 1 && !(getenv("FQSX_SIV_REPLICA") && atoi(getenv("FQSX_SIV_REPLICA")))) {
+    const u64 siv_bytes = (1ull << (2 * c->cfg.pmer)) / 4, range_bytes = siv_bytes / 4096;
+#ifndef FQSX_EMU
+    const u64 min_chunk = std::max<u64>(c->vm_gran, 2ull << 20);
+#else
+    const u64 min_chunk = c->vm_gran;
+#endif
+    if (range_bytes >= min_chunk && range_bytes % c->vm_gran == 0 && c->cfg.pmer_mod_shift == 2 * c->cfg.pmer - 12) {
+      rlimit rl;   // (own chunks keep a descriptor each in the emulation build; exports are transient)
+      if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur < 16384 && rl.rlim_cur < rl.rlim_max) {
+        rl.rlim_cur = std::min<rlim_t>(rl.rlim_max, 16384);
+        (void)setrlimit(RLIMIT_NOFILE, &rl);
+      }
+      dfree(c, c->cfg.siv);
+      c->cfg.siv = nullptr;
+      u64 stride = 0;
+      c->vm_siv = fqsx_dna::VmTab();
+      if ((rc = vtab_reserve_raw(c, c->vm_siv, range_bytes / sizeof(u64), &stride, 4096))) return rc;
+      if (stride != range_bytes / sizeof(u64)) { g_err = "p-mer vector ranges do not tile the address range"; return FQSX_E_HIP; }
+      c->vm_siv.own_mod = c->T;
+      for (u32 r = 0; r < 4096; ++r)
+        if (vt_rank(c, c->vm_siv, r) == c->shard_rank && (rc = vtab_create_own(c, c->vm_siv, r))) return rc;
+      if ((rc = vtab_exchange(c, c->vm_siv))) return rc;
+      c->cfg.siv = (u64 *)c->vm_siv.va;
+      c->cfg.siv_part = 1;
+      void *p = nullptr;
+      if ((rc = dalloc(c, &p, 2 * sizeof(u32), true))) return rc;
+      c->d_plog_n = (u32 *)p;
+      c->cfg.p_log_n = c->d_plog_n;
+    }
   }
 #ifndef FQSX_EMU
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -2498,6 +2558,7 @@ int fqsx_dna_capacity(fqsx_dna *c, uint64_t out[16]) {
   }
   out[12] = sizeof(u64);   // bytes per global-table slot
   out[13] = (c->vm_s.live ? c->vm_s.own_bytes : c->gs_cap * T * sizeof(u64)) + (c->vm_b.live ? c->vm_b.own_bytes : c->gb_cap * T * sizeof(u64));   // s- + b-mer table memory this rank holds
+  out[15] = c->vm_siv.live ? c->vm_siv.own_bytes : out[4];   // p-mer vector memory this rank holds
   if (c->paired) out[14] = c->vm_pk.live ? c->vm_pk.own_bytes + c->vm_pv.own_bytes : c->gpe_cap * T * 2 * sizeof(u64);   // pair-table memory this rank holds
   return FQSX_OK;
 }

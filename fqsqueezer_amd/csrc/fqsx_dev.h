@@ -4870,6 +4870,14 @@ FQ_DEV void insert_phase_body(const DevCfg &cfg, SM *sm, u32 tid, u32 kind) {
         if (seen == old) {
           nf += f == 0;
           siv_idx_move(cfg, idx, (u32)f, (u32)f + 1);
+          if (cfg.siv_part) {   // the other ranks' replicas of the count index follow from this log (the vector itself they read here)
+#ifndef FQSX_EMU
+            const u32 at = atomicAdd(cfg.p_log_n, 1u);
+#else
+            const u32 at = (*cfg.p_log_n)++;
+#endif
+            cfg.p_log[at] = (idx << 4) | (f << 2) | (f + 1);
+          }
           break;
         }
         old = seen;

@@ -216,6 +216,10 @@ struct DevCfg {
                                // through peer mappings, so the kernels that write own sub-tables end with a system-scope release and
                                // the kernels that look k-mers up start behind a system-scope acquire (fqsx_plat.h)
   u32 pe_part;                 // sharded mode, partitioned tables: the pair table is partitioned too -- a rank applies the triples of its own owners only
+  u32 siv_part, pad_siv_;      // sharded mode, partitioned tables: the p-mer vector is partitioned too (its 4096 owner ranges are chunks on their
+                               // owners' ranks); the count index stays a replica on every rank, kept up from the owners' transition log:
+  u64 *p_log;                  // this phase's (index << 4 | old << 2 | new) of every field an owner of this rank changed (zero-padded) ...
+  u32 *p_log_n;                // ... and their number
   const u8 *vmap;              // [256] owner -> position of its group in the partitioned mailbox: identity, or rank-major
                                // (all owners of rank 0, then rank 1, ...) so that what goes to one rank is contiguous
   u32 *shard_cnt;              // [3][T][T] entries source s pushed for owner o in this phase (own sources; else 0)

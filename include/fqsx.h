@@ -112,7 +112,7 @@ int fqsx_dna_stats(fqsx_dna *, uint64_t out[64]);
  * [7] device bytes held now [8] ... at most so far (old + new table during a growth included) [9] table growth events
  * [10] minimizer pairs stored (paired-end) [11] pair-table slots (16 bytes each) [12] bytes per k-mer table slot
  * [13] bytes of s- + b-mer table memory this rank holds (all of it, or its owners' share with partitioned tables)
- * [14] bytes of pair-table memory this rank holds (likewise). */
+ * [14] bytes of pair-table memory this rank holds (likewise) [15] bytes of the p-mer vector this rank holds (likewise). */
 int fqsx_dna_capacity(fqsx_dna *, uint64_t out[16]);
 
 /* One GPU's capacity mode (no counterpart in the reference, whose sub-tables are separate heap vectors that grow one by one,
@@ -164,8 +164,10 @@ int fqsx_shard_traffic(fqsx_dna *, uint64_t out[4]);
  * (hipMemCreate -> POSIX descriptor over a Unix socket -> hipMemImportFromShareableHandle -> hipMemMap), so that every rank
  * sees one table in one address range and a look-up of a foreign sub-table is a load over xGMI.  Writes stay with the owner
  * (insert phase); the phase's collectives order them before the next look-ups.  The all-gather of a phase then carries no
- * k-mer items, only the owners' occupancy counters, the p-mer items and statistics and the paired-end triples (the p-mer
- * vector stays replicated).  A paired-end codec's pair table (fqs/application.h:54 ht_pe_mers, owner function
+ * k-mer items, only the owners' occupancy counters, the p-mer items and statistics and the paired-end triples.  The p-mer
+ * vector (fqs/application.h:51 siv_pmer, owner function fqs/dna.cpp:658) is partitioned as well when its 4096 owner ranges
+ * reach the chunk granule (2 MiB: the 16 GiB vector of the default geometry; smaller vectors stay replicas): a range lives on
+ * its owner's rank, the count index over the vector stays a replica that follows the owners' log of changed fields.  A paired-end codec's pair table (fqs/application.h:54 ht_pe_mers, owner function
  * fqs/ht_kmer.h:599-602) is partitioned the same way: every rank receives every source's triples but applies those of its
  * own owners only, and a fourth one-word all-reduce closes such a phase (the inserts follow the phase's last collective).
  * Streams are bit-identical to the one-GPU run's.

@@ -230,13 +230,17 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.skipif(os.environ.get("FQSX_SLOW") != "1", reason="5 M pairs on eight workers over two ranks: minutes; set FQSX_SLOW=1")
 def test_partitioned_tables_c18_paired_end_full_size_against_the_reference(tmp_path):
+    """BASELINE configs[2]'s file over two ranks with partitioned k-mer tables AND a partitioned pair table, against the reference's
+    per-block DNA digests: the file's first 16 blocks by default (about a minute: most of it is generating and sorting the 5 M pairs),
+    all 256 with FQSX_SLOW=1 (220 s; run in full in round 4: profiles/r04_partitioned_pair_table_c18.txt)."""
     if not os.path.exists(os.path.join(ROOT, "tests", "golden", "c18_pe5M_s_q8_t8.json")):
         pytest.skip("c18 golden has not been generated (tools/make_golden.py)")
     script = tmp_path / "w.py"
     script.write_text(C18_WORKER)
     env = dict(os.environ, FQSX_ROOT=ROOT)
+    if os.environ.get("FQSX_SLOW") != "1":
+        env.setdefault("FQSX_FULLSIZE_BLOCKS", "16")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29565", str(script)]
     r = subprocess.run(cmd, env=env, text=True, timeout=1150, stdout=subprocess.PIPE, stderr=subprocess.PIPE)

@@ -102,7 +102,7 @@ cap, cap1 = sh.codec.capacity(), one.capacity()
 assert (cap["smers"], cap["bmers"]) == (cap1["smers"], cap1["bmers"])     # every rank knows every sub-table's occupancy
 assert cap["growths"] >= 2, cap                                              # the tables grew on the way (from 64-slot sub-tables)
 lst = [None] * world
-dist.all_gather_object(lst, (tr, cap["table_bytes_held"], 8 * (cap["smer_slots"] + cap["bmer_slots"]), cap["pair_bytes_held"], 16 * cap["pair_slots"]))
+dist.all_gather_object(lst, (tr, cap["table_bytes_held"], 8 * (cap["smer_slots"] + cap["bmer_slots"]), cap["pair_bytes_held"], 16 * cap["pair_slots"], cap["siv_bytes_held"], cap["siv_bytes"]))
 if rank == 0:
     assert tr["all_to_all_bytes"] > 0 and tr["all_gather_bytes"] > 0
     held, whole = [x[1] for x in lst], lst[0][2]
@@ -110,6 +110,10 @@ if rank == 0:
         # (a sub-table is one chunk: its capacity rounded up to the allocation granule, a page in this build)
         slack = 2 * T * 4096
         assert whole <= sum(held) <= whole + slack and max(held) <= (whole + slack) * ((T + world - 1) // world) // T, (held, whole)
+        # the p-mer vector: its 4096 owner ranges (16 KiB each at this geometry) live on their owners' ranks -- (range % T) % world
+        sheld, swhole = [x[5] for x in lst], lst[0][6]
+        share = [sum(1 for r in range(4096) if (r % T) % world == q) for q in range(world)]
+        assert sum(sheld) == swhole and sheld == [swhole // 4096 * n for n in share], (sheld, swhole, share)
         # the pair table of a paired-end file with them (key and value array: two chunks per sub-table); it grew on the way
         pheld, pwhole = [x[3] for x in lst], lst[0][4]
         if mode.startswith("pe"):
@@ -117,7 +121,7 @@ if rank == 0:
             assert (cap["pairs"], cap["pair_slots"]) == (cap1["pairs"], cap1["pair_slots"])   # (the owners' occupancies travel with the all-gather)
     else:
         assert all(h == whole for h in held), (held, whole)
-        assert all(x[3] == x[4] for x in lst), lst
+        assert all(x[3] == x[4] and x[5] == x[6] for x in lst), lst
     print("NATIVE_SHARDED_OK", world, T, mode, "partitioned" if part else "replicas", held, whole, lst[0][0])
 dist.destroy_process_group()
 '''
