@@ -350,15 +350,43 @@ FQ_KERNEL64 void k_shard_counts(DevCfg cfg, u32 *dst, u32 status) {   // grid = 
 // after the all-reduce of the counts: out[0/1] = table demand of the coming insert phase (occupied + incoming slots of the
 // fullest s- / b-mer sub-table: every rank holds a replica of every sub-table, so every rank computes the same numbers),
 // out[2] = the device error word
-FQ_KERNEL64 void k_shard_need(DevCfg cfg, const u32 *C, u64 *out) {
+// Column sums of the all-reduced count matrix, once per phase for everybody who needs them (k_shard_need, the merge waves):
+// cs[(kind * (G + 1)) * T + o] = entries of `kind` for owner o, cs[(kind * (G + 1) + 1 + q) * T + o] = those pushed by the sources
+// of rank q.  One thread per (kind, owner): neighbouring threads read neighbouring words of a matrix row.
+FQ_KERNEL void k_shard_colsum(DevCfg cfg, const u32 *C, u32 *cs) {
+  const u32 T = cfg.T, G = cfg.shard_world;
+#ifndef FQSX_EMU
+  const u32 stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
+#else
+  const u32 stride = 1, first = 0;
+#endif
+  for (u32 i = first; i < 3 * T; i += stride) {
+    const u32 kind = i / T, o = i % T;
+    const u32 *Ck = C + (u64)kind * T * T;
+    u32 tot = 0;
+    for (u32 q = 0; q < G; ++q) {
+      u32 n = 0;
+      for (u32 s = q; s < T; s += 8 * G) {   // eight loads in flight (a thread's column walk is a chain of L2 round trips otherwise)
+        u32 v[8];
+#pragma unroll
+        for (u32 x = 0; x < 8; ++x) v[x] = s + x * G < T ? Ck[(u64)(s + x * G) * T + o] : 0u;
+#pragma unroll
+        for (u32 x = 0; x < 8; ++x) n += v[x];
+      }
+      cs[((u64)kind * (G + 1) + 1 + q) * T + o] = n;
+      tot += n;
+    }
+    cs[((u64)kind * (G + 1)) * T + o] = tot;
+  }
+}
+FQ_KERNEL64 void k_shard_need(DevCfg cfg, const u32 *cs, u64 *out, u64 *stats_before) {
   const u32 T = cfg.T;
   for (u32 which = 0; which < 2; ++which) {
     const KTab &t = which ? cfg.g_b : cfg.g_s;
-    const u32 *Ck = C + (u64)(which ? MAIL_B : MAIL_S) * T * T;
+    const u32 *tot = cs + (u64)(which ? MAIL_B : MAIL_S) * (cfg.shard_world + 1) * T;
     u64 need = 0;
     for (u32 o = FQ_LANE; o < T; o += FQ_WAVE) {
-      u64 n = t.filled[o];
-      for (u32 s = 0; s < T; ++s) n += Ck[(u64)s * T + o];
+      const u64 n = (u64)t.filled[o] + tot[o];
       need = n > need ? n : need;
     }
 #if FQ_WAVE > 1
@@ -367,6 +395,8 @@ FQ_KERNEL64 void k_shard_need(DevCfg cfg, const u32 *C, u64 *out) {
     if (FQ_LANE == 0) out[which] = need;
   }
   if (FQ_LANE == 0) out[2] = cfg.err[0];
+  if (stats_before)   // (the p-mer statistics before the phase's inserts: what the all-gather's delta is taken against)
+    for (u32 i = FQ_LANE; i < 2; i += FQ_WAVE) stats_before[i] = cfg.siv_stats[i];
 }
 // this rank's paired-end triples, sources in ascending order -> out (the all-gather's payload)
 FQ_KERNEL64 void k_shard_pe_pack(DevCfg cfg, u64 *out) {   // grid = T (source)
@@ -424,20 +454,43 @@ FQ_KERNEL64 void k_shard_fill_unpack(DevCfg cfg, const u64 *gathered, u64 stride
     }
   }
 }
+// (partitioned tables: the statistics' delta and the counters in one launch, and the sum and the counters behind the all-gather)
+FQ_KERNEL64 void k_shard_pack2(DevCfg cfg, const u64 *before, u64 *out_siv, u64 *out_fill, u32 n_max, u32 n_arr) {
+  for (u32 i = FQ_LANE; i < 2; i += FQ_WAVE) out_siv[i] = cfg.siv_stats[i] - before[i];
+  for (u32 i = FQ_LANE; i < n_arr * n_max; i += FQ_WAVE) {
+    const u32 which = i / n_max, o = cfg.shard_rank + (i % n_max) * cfg.shard_world;
+    out_fill[i] = o < cfg.T ? (which == 2 ? cfg.g_pe.filled : which ? cfg.g_b.filled : cfg.g_s.filled)[o] : 0;
+  }
+}
+FQ_KERNEL64 void k_shard_unpack2(DevCfg cfg, const u64 *before, const u64 *gathered, u64 stride, u64 off_siv, u64 off_fill, u32 n_max, u32 n_arr) {
+  for (u32 i = FQ_LANE; i < 2; i += FQ_WAVE) {
+    u64 v = before[i];
+    for (u32 q = 0; q < cfg.shard_world; ++q) v += gathered[(u64)q * stride + off_siv + i];
+    cfg.siv_stats[i] = v;
+  }
+  for (u32 q = 0; q < cfg.shard_world; ++q) {
+    if (q == cfg.shard_rank) continue;
+    for (u32 i = FQ_LANE; i < n_arr * n_max; i += FQ_WAVE) {
+      const u32 which = i / n_max, o = q + (i % n_max) * cfg.shard_world;
+      if (o < cfg.T) (which == 2 ? cfg.g_pe.filled : which ? cfg.g_b.filled : cfg.g_s.filled)[o] = (u32)gathered[(u64)q * stride + off_fill + i];
+    }
+  }
+}
 // Received entries -> this rank's owners' groups in (owner, source, push) order (the order InsertKmersToHT drains
 // its column in).  recv = the chunks of ranks 0..G-1 one after the other; the chunk of rank q holds, for every owner
 // of this rank in ascending order, the entries of q's sources in ascending order.  C = the summed count matrix.
-FQ_DEV void shard_merge_body(const DevCfg &cfg, u32 kind, u32 o, const u64 *recv, const u32 *C, u32 *col, u32 *pre);
+// cs: the matrix's column sums (k_shard_colsum), or null (the step-wise driver: every wave sums the columns it needs itself)
+FQ_DEV void shard_merge_body(const DevCfg &cfg, u32 kind, u32 o, const u64 *recv, const u32 *C, const u32 *cs, u32 *col, u32 *pre, u32 *soff);
 FQ_KERNEL64 void k_shard_merge(DevCfg cfg, u32 kind, const u64 *recv, const u32 *C) {   // grid = T (owner)
-  FQ_SHARED u32 col[256], pre[256];
-  shard_merge_body(cfg, kind, FQ_BLOCK, recv, C, col, pre);
+  FQ_SHARED u32 col[256], pre[256], soff[256];
+  shard_merge_body(cfg, kind, FQ_BLOCK, recv, C, nullptr, col, pre, soff);
 }
-FQ_KERNEL64 void k_shard_merge3(DevCfg cfg, const u64 *recv0, const u64 *recv1, const u64 *recv2, const u32 *C) {   // grid = 3 T: (kind, owner)
-  FQ_SHARED u32 col[256], pre[256];
+FQ_KERNEL64 void k_shard_merge3(DevCfg cfg, const u64 *recv0, const u64 *recv1, const u64 *recv2, const u32 *C, const u32 *cs) {   // grid = 3 T: (kind, owner)
+  FQ_SHARED u32 col[256], pre[256], soff[256];
   const u32 kind = FQ_BLOCK / cfg.T;
-  shard_merge_body(cfg, kind, FQ_BLOCK % cfg.T, kind == 0 ? recv0 : kind == 1 ? recv1 : recv2, C, col, pre);
+  shard_merge_body(cfg, kind, FQ_BLOCK % cfg.T, kind == 0 ? recv0 : kind == 1 ? recv1 : recv2, C, cs, col, pre, soff);
 }
-FQ_DEV void shard_merge_body(const DevCfg &cfg, u32 kind, u32 o, const u64 *recv, const u32 *C, u32 *col, u32 *pre) {
+FQ_DEV void shard_merge_body(const DevCfg &cfg, u32 kind, u32 o, const u64 *recv, const u32 *C, const u32 *cs, u32 *col, u32 *pre, u32 *soff) {
   const u32 T = cfg.T, G = cfg.shard_world, me = cfg.shard_rank;
   const Mail &m = cfg.mail[kind];
   const u32 *Ck = C + (u64)kind * T * T;
@@ -447,8 +500,10 @@ FQ_DEV void shard_merge_body(const DevCfg &cfg, u32 kind, u32 o, const u64 *recv
   for (u32 jb = 0; jb < n_own; jb += FQ_WAVE) {
     const u32 j = jb + FQ_LANE, o2 = me + j * G;
     u32 n = 0;
-    if (j < n_own)
-      for (u32 s = 0; s < T; ++s) n += Ck[(u64)s * T + o2];
+    if (j < n_own) {
+      if (cs) n = cs[((u64)kind * (G + 1)) * T + o2];
+      else for (u32 s = 0; s < T; ++s) n += Ck[(u64)s * T + o2];
+    }
     dst += wave_sum32(j < n_own && o2 < o ? n : 0u);
     tot += wave_sum32(j < n_own && o2 == o ? n : 0u);
   }
@@ -475,18 +530,31 @@ FQ_DEV void shard_merge_body(const DevCfg &cfg, u32 kind, u32 o, const u64 *recv
     for (u32 jb = 0; jb < n_own; jb += FQ_WAVE) {
       const u32 j = jb + FQ_LANE, o2 = me + j * G;
       u32 n = 0;
-      if (j < n_own)
-        for (u32 s = q; s < T; s += G) n += Ck[(u64)s * T + o2];
+      if (j < n_own) {
+        if (cs) n = cs[((u64)kind * (G + 1) + 1 + q) * T + o2];
+        else for (u32 s = q; s < T; s += G) n += Ck[(u64)s * T + o2];
+      }
       before += wave_sum32(j < n_own && o2 < o ? n : 0u);
       size += wave_sum32(j < n_own ? n : 0u);
     }
     u32 src = chunk0 + before;
-    for (u32 s = q; s < T; s += G) {
-      const u32 n = col[s], d = dst + pre[s];
-      for (u32 e = FQ_LANE; e < n; e += FQ_WAVE) m.sorted[d + e] = recv[src + e];
-      src += n;
+    for (u32 s = q; s < T; s += G) {   // where source s's entries for this owner start in recv
+      if (FQ_LANE == 0) soff[s] = src;
+      src += col[s];
     }
     chunk0 += size;
+  }
+  FQ_SYNC();
+  // the copy, one entry per lane whatever source it comes from: entry x of the owner's group belongs to the source s with
+  // pre[s] <= x < pre[s] + col[s] (binary search over the prefix; a loop over the sources is T dependent small copies)
+  for (u32 x = FQ_LANE; x < tot; x += FQ_WAVE) {
+    u32 lo = 0, hi = T;   // the last s with pre[s] <= x (sources without entries share a prefix value: the last of them counts)
+    while (hi - lo > 1) {
+      const u32 mid = (lo + hi) >> 1;
+      if (pre[mid] <= x) lo = mid; else hi = mid;
+    }
+    while (col[lo] == 0 && lo > 0) --lo;   // (not reached: pre[lo] <= x < tot means the last such source has entries; kept for safety)
+    m.sorted[dst + x] = recv[soff[lo] + (x - pre[lo])];
   }
 }
 // After the insert phase: what the replicas on the other ranks have to take over.  One item per applied entry of this
@@ -618,6 +686,7 @@ struct fqsx_dna {
   u64 *d_xbuf;        // received entries / upsert items
   u64 xbuf_cap;
   u32 *d_cglob;       // [3][T][T] (+ [T] paired-end triples per source) the all-reduced count matrix of the phase
+  u32 *d_colsum;      // [3][world + 1][T] its column sums (k_shard_colsum)
   u64 siv_before[2];
   // native sharded driver (fqsx_shard_attach / fqsx_shard_encode_block)
   fqsx_comm comm;     // the world's collectives (RCCL on the codec's stream, or the caller's)
@@ -1851,6 +1920,8 @@ int fqsx_shard_config(fqsx_dna *c, uint32_t rank, uint32_t world) {
     c->cfg.shard_cnt = (u32 *)p;
     if ((rc = dalloc(c, &p, (3ull * T * T + T + 1) * sizeof(u32), true))) return rc;
     c->d_cglob = (u32 *)p;
+    if ((rc = dalloc(c, &p, 3ull * (T + 1) * T * sizeof(u32), true))) return rc;   // (room for any world <= T)
+    c->d_colsum = (u32 *)p;
     if ((rc = dalloc(c, &p, 8 * sizeof(u64), true))) return rc;
     c->d_small = (u64 *)p;
     c->h_cglob.assign(3ull * T * T + T + 1, 0);
@@ -2058,7 +2129,8 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   LAUNCH(c, 2, k_part_count, part_grid, 64, cfg);
   LAUNCH(c, 2, k_shard_counts, 3 * T + 1, 64, cfg, c->d_cglob, 0u);   // (straight into the buffer the all-reduce runs on)
   COMMCHK(c->comm.allreduce_sum_u32(c->comm.ctx, c->d_cglob, NC), "all-reduce of the mailbox counts");   // collective 1
-  LAUNCH(c, 2, k_shard_need, 1, 64, cfg, (const u32 *)c->d_cglob, c->d_small + 2);
+  LAUNCH(c, 2, k_shard_colsum, (3 * T + 63) / 64, 64, cfg, (const u32 *)c->d_cglob, c->d_colsum);
+  LAUNCH(c, 2, k_shard_need, 1, 64, cfg, (const u32 *)c->d_colsum, c->d_small + 2, c->d_small);
   // ---- the phase's one host round trip: every transfer size, the table demand, the error word
   u64 small[3];
 #ifndef FQSX_EMU
@@ -2135,9 +2207,8 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   }
   for (u32 k = 0; k < 3; ++k) { send[k] = cfg.mail[k].sorted; recv[k] = c->d_xrecv[k]; }
   COMMCHK(c->comm.alltoallv_u64(c->comm.ctx, 3, send, sc.data(), recv, rcnt.data()), "all-to-all of the mailboxes");   // collective 2
-  LAUNCH(c, 2, k_shard_merge3, 3 * T, 64, cfg, (const u64 *)c->d_xrecv[0], (const u64 *)c->d_xrecv[1], (const u64 *)c->d_xrecv[2], (const u32 *)c->d_cglob);
+  LAUNCH(c, 2, k_shard_merge3, 3 * T, 64, cfg, (const u64 *)c->d_xrecv[0], (const u64 *)c->d_xrecv[1], (const u64 *)c->d_xrecv[2], (const u32 *)c->d_cglob, (const u32 *)c->d_colsum);
   // ---- insert phase of own owners
-  if ((rc = d2d(c, c->d_small, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
   if (cfg.siv_part) {   // the owners log every field they change straight into the all-gather's p-mer items (zero = no item)
     cfg.p_log = c->d_items + off_k[MAIL_P];
     if (M[MAIL_P]) LAUNCH(c, 2, k_zero_words, (u32)std::min<u64>(REHASH_GRID, (M[MAIL_P] + 255) / 256), 256, cfg.p_log, M[MAIL_P], 0u);
@@ -2147,8 +2218,8 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
   // ---- one all-gather
   for (u32 k = 0; k < 3; ++k)
     if (n_items[(u64)k * G + me] && !(k == MAIL_P && cfg.siv_part)) LAUNCH(c, 2, k_shard_collect, REHASH_GRID, 256, cfg, k, c->d_items + off_k[k]);
-  LAUNCH(c, 2, k_shard_siv_delta, 1, 64, cfg, (const u64 *)c->d_small, c->d_items + off_siv);
-  if (FW) LAUNCH(c, 2, k_shard_fill_pack, 1, 64, cfg, c->d_items + off_fill, n_own_max, n_fill);
+  if (FW) LAUNCH(c, 2, k_shard_pack2, 1, 64, cfg, (const u64 *)c->d_small, c->d_items + off_siv, c->d_items + off_fill, n_own_max, n_fill);
+  else LAUNCH(c, 2, k_shard_siv_delta, 1, 64, cfg, (const u64 *)c->d_small, c->d_items + off_siv);
   if (c->paired && PM) LAUNCH(c, 2, k_shard_pe_pack, T, 64, cfg, c->d_items + off_pe);
   COMMCHK(c->comm.allgather_u64(c->comm.ctx, c->d_items, W, c->d_gathered), "all-gather of the applied items");   // collective 3
   c->sh_gather_words += W * (G - 1);
@@ -2156,8 +2227,8 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
     if (q != me || c->shard_apply_own)
       for (u32 k = 0; k < 3; ++k)
         if (n_items[(u64)k * G + q] && !(k == MAIL_P && cfg.siv_part && q == me)) LAUNCH(c, 2, k_shard_apply, REHASH_GRID, 256, cfg, k, (const u64 *)(c->d_gathered + (u64)q * W + off_k[k]), (u32)n_items[(u64)k * G + q]);
-  LAUNCH(c, 2, k_shard_siv_sum, 1, 64, cfg, (const u64 *)c->d_small, (const u64 *)c->d_gathered, W, off_siv);
-  if (FW) LAUNCH(c, 2, k_shard_fill_unpack, 1, 64, cfg, (const u64 *)c->d_gathered, W, off_fill, n_own_max, n_fill);
+  if (FW) LAUNCH(c, 2, k_shard_unpack2, 1, 64, cfg, (const u64 *)c->d_small, (const u64 *)c->d_gathered, W, off_siv, off_fill, n_own_max, n_fill);
+  else LAUNCH(c, 2, k_shard_siv_sum, 1, 64, cfg, (const u64 *)c->d_small, (const u64 *)c->d_gathered, W, off_siv);
   // ---- paired-end: every rank holds every source's triples (the all-gather above) and applies them to its replica of the pair
   // table -- or, with partitioned tables, those of its own owners to its own sub-tables (k_pe_insert; the owners' occupancy
   // counters came with the all-gather, so the growth rule below sees the same numbers on every rank)
