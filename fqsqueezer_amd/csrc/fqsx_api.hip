@@ -47,11 +47,28 @@ extern "C" const char *fqsx_version(void) {
 // queue -- the inserts of that phase included -- does nothing.  The host finds the word with the end-of-block transfer,
 // grows the tables and takes the block up again at that phase's inserts (block_recover).  err[0]: device error word.
 FQ_DEV bool phase_skip(const DevCfg &cfg) { return (cfg.err[0] | cfg.err[1]) != 0; }
+#define FQSX_INS_THREADS 128   /* k_insert_phase: the inserting wave and the prefetching wave */
 // grid = 3 * T: (owner, mailbox kind), plus -- single-end encoding -- workgroups that clear the workers' local tables
 // (ClearKmersToHT, dna.cpp:2475-2488: the insert phase does not touch them), which saves that launch
-FQ_KERNEL64 void k_insert_phase(DevCfg cfg, u64 nb_slots, u64 ns_slots) {
+// 128 threads: wave 0 inserts, wave 1 touches the buckets of the batches ahead (insert_prefetch_body)
+#ifndef FQSX_EMU
+extern "C" __global__ __launch_bounds__(128)
+#else
+static
+#endif
+void k_insert_phase(DevCfg cfg, u64 nb_slots, u64 ns_slots) {
   FQ_SHARED InsShared sm;
   if (phase_skip(cfg)) return;
+#ifndef FQSX_EMU
+  if (threadIdx.x == 0) { sm.pf_done = 0; sm.pf_on = blockDim.x > 64 ? 1u : 0u; }
+  __syncthreads();
+  if (FQ_WAVE_ID == 1) {
+    if (FQ_BLOCK < 3 * cfg.T) insert_prefetch_body(cfg, &sm, FQ_BLOCK / 3, FQ_BLOCK % 3);
+    return;
+  }
+#else
+  sm.pf_done = 0; sm.pf_on = 0;
+#endif
   if (FQ_BLOCK >= 3 * cfg.T) {
     const u64 stride = (u64)(FQ_NBLOCKS - 3 * cfg.T) * FQ_WAVE, first = (u64)(FQ_BLOCK - 3 * cfg.T) * FQ_WAVE + FQ_LANE;
     for (u64 i = first; i < nb_slots; i += stride) cfg.l_b.slots[i] = 0;
@@ -713,6 +730,7 @@ struct fqsx_dna {
     bool live = false;
   } vm_s, vm_b, vm_pk, vm_pv, vm_siv; // s-mer and b-mer table; the pair table's key and value arrays; the p-mer vector (4096 chunks)
   u32 *d_plog_n;                      // counter of the p-mer transition log (DevCfg.p_log_n)
+  u32 ins_threads;                    // k_insert_phase: 128 = inserting wave + prefetching wave (FQSX_INS_PREFETCH=0: 64, the inserting wave alone)
   u64 vm_own_bytes;   // physical table memory held by this rank
 };
 
@@ -1393,7 +1411,7 @@ int clear_local_tables(fqsx_dna *c) {
 int insert_and_clear(fqsx_dna *c) {
   const u64 words = (c->cur_need_lb + c->cur_need_ls) * c->T;
   const u32 cgrid = (u32)std::min<u64>(2048, (words + 4095) / 4096 + 1);
-  LAUNCH(c, 1, k_insert_phase, 3 * c->T + cgrid, 64, c->cfg, c->cur_need_lb * c->T, c->cur_need_ls * c->T);
+  LAUNCH(c, 1, k_insert_phase, 3 * c->T + cgrid, c->ins_threads, c->cfg, c->cur_need_lb * c->T, c->cur_need_ls * c->T);
   return FQSX_OK;
 }
 // growth decision from the demand words (k_part_dstoff): a sub-table is at most half full after the coming inserts
@@ -1497,7 +1515,7 @@ int block_segment(fqsx_dna *c, u32 seg) {
       if (need * 2 > c->gpe_cap && (rc = grow_gpe(c, pow2_at_least(need * 2 + 2)))) return rc;
       if ((rc = pe_insert_and_clear(c))) return rc;
     }
-    LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
+    LAUNCH(c, 1, k_insert_phase, 3 * T, c->ins_threads, cfg, (u64)0, (u64)0);
     if ((rc = clear_local_tables(c))) return rc;
   }
   return FQSX_OK;
@@ -1607,6 +1625,7 @@ int create_impl(fqsx_dna *c, const u8 *h) {
   c->tab_small_pct = 40;
   if (const char *e = getenv("FQSX_TAB_AFTER_PCT")) c->tab_small_pct = c->tab_after_pct = (u32)std::min<u64>(c->tab_load_pct - 5, std::max<u64>(10, strtoull(e, nullptr, 10)));
   cfg.tab_load_pct = c->tab_load_pct;
+  c->ins_threads = (getenv("FQSX_INS_PREFETCH") && atoi(getenv("FQSX_INS_PREFETCH")) == 0) ? 64u : FQSX_INS_THREADS;
   if (const char *e = getenv("FQSX_WHATIF")) { u32 r = 0, u = 0; if (sscanf(e, "%u,%u", &r, &u) == 2) cfg.whatif = (r << 16) | (u & 0xffffu); }
   c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(1024, (1ull << 22) / T));
   if (const char *e = getenv("FQSX_GTAB_INIT")) c->gs_cap = c->gb_cap = pow2_at_least(std::max<u64>(64, strtoull(e, nullptr, 10)));   // (tests: growth from tiny tables)
@@ -2029,7 +2048,7 @@ int fqsx_shard_insert(fqsx_dna *c, uint64_t need_s, uint64_t need_b, uint64_t *c
   if (tab_over(c, need_s, c->gs_cap) && (rc = grow_global(c, cfg.g_s, c->gs_cap, tab_new_cap(c, need_s)))) return rc;
   if (tab_over(c, need_b, c->gb_cap) && (rc = grow_global(c, cfg.g_b, c->gb_cap, tab_new_cap(c, need_b)))) return rc;
   if ((rc = d2h_sync(c, c->siv_before, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
-  LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
+  LAUNCH(c, 1, k_insert_phase, 3 * T, c->ins_threads, cfg, (u64)0, (u64)0);
   u64 after[2];
   if ((rc = d2h_sync(c, after, cfg.siv_stats, 2 * sizeof(u64)))) return rc;
   siv_delta[0] = after[0] - c->siv_before[0];
@@ -2214,7 +2233,7 @@ int shard_phase_native(fqsx_dna *c, u32 seg) {
     if (M[MAIL_P]) LAUNCH(c, 2, k_zero_words, (u32)std::min<u64>(REHASH_GRID, (M[MAIL_P] + 255) / 256), 256, cfg.p_log, M[MAIL_P], 0u);
     if ((rc = dzero(c, c->d_plog_n, sizeof(u32)))) return rc;
   }
-  LAUNCH(c, 1, k_insert_phase, 3 * T, 64, cfg, (u64)0, (u64)0);
+  LAUNCH(c, 1, k_insert_phase, 3 * T, c->ins_threads, cfg, (u64)0, (u64)0);
   // ---- one all-gather
   for (u32 k = 0; k < 3; ++k)
     if (n_items[(u64)k * G + me] && !(k == MAIL_P && cfg.siv_part)) LAUNCH(c, 2, k_shard_collect, REHASH_GRID, 256, cfg, k, c->d_items + off_k[k]);

@@ -151,6 +151,7 @@ static_assert(sizeof(WgShared) <= 160u * 1024u, "WgShared must fit the 160 KB of
 struct InsShared {
   u32 mt[4][624];
   u32 mt_idx[4];
+  u32 pf_done, pf_on;   // batches the inserting wave has applied / a prefetching wave runs beside it (k_insert_phase)
   u64 ib_pos[64];
   u64 ib_hash[256];
   u64 bk_key[64];
@@ -812,10 +813,23 @@ FQ_DEV void insert_batch(const DevCfg &cfg, SM *sm, const KTab &t, u32 sub, cons
 template <class SM>
 FQ_DEV void insert_batch_k(const DevCfg &cfg, SM *sm, const KTab &t, u32 sub, u64 mykey, u32 n, u32 rng, const Cinc &ci,
                            u64 &nslots, u32 &err);
-template <class SM>
+// EXT_PF (the insert-phase kernel): a second wave of the workgroup touches the home buckets of the batches ahead (insert_prefetch_body),
+// so this wave sends for nothing itself -- a touch issued in front of a batch's probe walk holds that walk's loads back until the touch
+// (an HBM round trip) is home, because a wave's vector-memory operations retire in issue order -- and reports its progress instead.
+template <class SM, bool EXT_PF = false>
 FQ_DEV void insert_keys(const DevCfg &cfg, SM *sm, const KTab &t, u32 sub, const u64 *keys, u32 n, u32 rng, const Cinc &ci,
                         u64 &nslots, u32 &err) {
 #if FQ_WAVE > 1
+  if constexpr (EXT_PF) {
+    u64 nextk = FQ_LANE < n ? keys[FQ_LANE] : 0;
+    for (u32 o = 0; o < n && !err; o += FQ_WAVE) {
+      const u64 k = nextk;
+      if (o + FQ_WAVE + FQ_LANE < n) nextk = keys[o + FQ_WAVE + FQ_LANE];
+      insert_batch_k(cfg, sm, t, sub, k, n - o < FQ_WAVE ? n - o : FQ_WAVE, rng, ci, nslots, err);
+      lds_store_rel(&sm->pf_done, o / FQ_WAVE + 1);
+    }
+    return;
+  }
   // the keys of the next batch are fetched while the current one is applied (the list is read-only here)
   // ... and the home slots of the next batch are touched one batch ahead, so that the ordered walk of a batch finds
   // its cache lines (and address translations) in L2 instead of paying the HBM round trip inside the serial chain
@@ -4850,6 +4864,31 @@ FQ_DEV void siv_idx_move(const DevCfg &cfg, u64 idx, u32 from, u32 to) {
 // owner `tid` applies its group of mailbox `kind` (InsertKmersToHT, dna.cpp:2393-2472).  The three
 // mailboxes touch disjoint state (p-mer vector / ht_smer + cinc_s / ht_bmer + cinc_b), so they run as
 // three independent workgroups per owner.
+// The prefetching wave of an insert-phase workgroup: walks the owner's group a few batches ahead of the inserting wave and touches
+// every key's two home buckets, so that the inserting wave's ordered probe walks find them in L2.  It only reads.
+#if FQ_WAVE > 1
+template <class SM>
+FQ_DEV void insert_prefetch_body(const DevCfg &cfg, SM *sm, u32 tid, u32 kind) {
+  if (kind == MAIL_P) return;
+  const Mail &m = cfg.mail[kind];
+  const u32 lo = m.dst_off[tid], hi = m.dst_off[tid + 1], n = hi - lo;
+  const KTab &t = kind == MAIL_S ? cfg.g_s : cfg.g_b;
+  const u64 *s = t.slots + (u64)tid * t.stride, *keys = m.sorted + lo;
+  u64 acc = 0;
+  for (u32 o = 0; o < n; o += FQ_WAVE) {
+    u32 spins = 0;
+    while ((i32)(o / FQ_WAVE - lds_load_acq(&sm->pf_done)) > 4) {   // at most five batches ahead (their lines stay in L2 that long)
+      fq_sleep();
+      if (++spins > (1u << 18)) { keep_live(acc); return; }          // (the inserting wave gave up, or is far slower than ever seen: just stop)
+    }
+    if (o + FQ_LANE < n) {
+      const TabHome th = tab_home(t, keys[o + FQ_LANE] >> (64 - 2 * t.k));
+      acc ^= touch_load(&s[(u64)th.a * FQSX_BKT]) ^ touch_load(&s[(u64)th.b * FQSX_BKT]);
+    }
+  }
+  keep_live(acc);
+}
+#endif
 template <class SM>
 FQ_DEV void insert_phase_body(const DevCfg &cfg, SM *sm, u32 tid, u32 kind) {
   WState *ws = cfg.ws + tid;
@@ -4908,7 +4947,8 @@ FQ_DEV void insert_phase_body(const DevCfg &cfg, SM *sm, u32 tid, u32 kind) {
   for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) sm->mt[rng][i] = ws->mt[rng][i];
   if (FQ_LANE == 0) sm->mt_idx[rng] = ws->mt_idx[rng];
   FQ_SYNC();
-  insert_keys(cfg, sm, t, tid, m.sorted + lo, hi - lo, rng, ci, n_slots, err);
+  if (sm->pf_on) insert_keys<SM, true>(cfg, sm, t, tid, m.sorted + lo, hi - lo, rng, ci, n_slots, err);
+  else insert_keys(cfg, sm, t, tid, m.sorted + lo, hi - lo, rng, ci, n_slots, err);
   FQ_SYNC();
   for (u32 i = FQ_LANE; i < 624; i += FQ_WAVE) ws->mt[rng][i] = sm->mt[rng][i];
   n_slots = wave_sum64(n_slots);
