@@ -4864,6 +4864,9 @@ FQ_DEV void siv_idx_move(const DevCfg &cfg, u64 idx, u32 from, u32 to) {
 // owner `tid` applies its group of mailbox `kind` (InsertKmersToHT, dna.cpp:2393-2472).  The three
 // mailboxes touch disjoint state (p-mer vector / ht_smer + cinc_s / ht_bmer + cinc_b), so they run as
 // three independent workgroups per owner.
+#ifndef FQSX_PF_AHEAD
+#define FQSX_PF_AHEAD 4
+#endif
 // The prefetching wave of an insert-phase workgroup: walks the owner's group a few batches ahead of the inserting wave and touches
 // every key's two home buckets, so that the inserting wave's ordered probe walks find them in L2.  It only reads.
 #if FQ_WAVE > 1
@@ -4877,7 +4880,7 @@ FQ_DEV void insert_prefetch_body(const DevCfg &cfg, SM *sm, u32 tid, u32 kind) {
   u64 acc = 0;
   for (u32 o = 0; o < n; o += FQ_WAVE) {
     u32 spins = 0;
-    while ((i32)(o / FQ_WAVE - lds_load_acq(&sm->pf_done)) > 4) {   // at most five batches ahead (their lines stay in L2 that long)
+    while ((i32)(o / FQ_WAVE - lds_load_acq(&sm->pf_done)) > (i32)FQSX_PF_AHEAD) {   // a few batches ahead (their lines stay in L2 that long)
       fq_sleep();
       if (++spins > (1u << 18)) { keep_live(acc); return; }          // (the inserting wave gave up, or is far slower than ever seen: just stop)
     }
