@@ -4,7 +4,7 @@
 // sizes the per-block buffers, and drives the kernel schedule of one reads block:
 //
 //   for seg in 0..S:  k_encode_segment  (T workgroups, one wavefront = one worker)
-//                     k_insert_phase    (T workgroups, one per table owner)
+//                     k_insert_phase    (3 T workgroups: (owner, mailbox kind); an inserting and a prefetching wave each)
 //                     clear local tables
 //   k_finish_block
 //
