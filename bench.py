@@ -581,7 +581,9 @@ def guarded_sharded_main(a, rank, local_rank, world, emu_lib=None):
     import threading
     import torch.distributed as dist
     gpu = emu_lib is None
-    side = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
+    deadline_s = float(os.environ.get("FQSX_BENCH_SHARD_DEADLINE_S", "420"))
+    # (a rank that failed early waits in the agreement below until the slowest rank's deadline has passed: longer than the deadline)
+    side = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=deadline_s + 180))
     replicas = replicas_pass(a, rank, local_rank, world) if gpu else None
     res = {}
     store = None
@@ -608,7 +610,7 @@ def guarded_sharded_main(a, rank, local_rank, world, emu_lib=None):
 
     th = threading.Thread(target=body, daemon=True)
     th.start()
-    deadline = time.time() + float(os.environ.get("FQSX_BENCH_SHARD_DEADLINE_S", "420"))
+    deadline = time.time() + deadline_s
     while th.is_alive() and time.time() < deadline:
         th.join(1.0)
         try:
